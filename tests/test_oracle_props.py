@@ -1,0 +1,119 @@
+"""Property tests that pin what the KATs do not:
+they hold for the algorithm the oracle restates and are re-used, at full
+sizes, against the HIP path in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from synth import channel_centre, synth_cf32
+
+
+@pytest.mark.parametrize("M", [4, 20, 64])
+def test_tone_lands_in_its_channel(M):
+    nf = 64
+    n = np.arange(M * nf)
+    for k in (0, 1, M // 2, M - 1):
+        x = np.exp(1j * channel_centre(k, M) * n).astype(np.complex64)
+        y = O.Chan(M).process(x)
+        p = np.abs(y[:, 20:]).mean(axis=1)          # skip the 14-frame transient
+        assert np.argmax(p) == k
+        others = np.delete(p, k)
+        assert 20 * np.log10(p[k] / (others.max() + 1e-30)) > 75.0
+        assert abs(p[k] / M - 1.0) < 0.02           # prototype not normalised: gain ~ sum(h) ~ M
+
+
+def test_pfb_is_linear_and_frame_shift_invariant():
+    M, nf = 16, 40
+    rng = np.random.default_rng(1)
+    a = (rng.standard_normal(M * nf) + 1j * rng.standard_normal(M * nf)).astype(np.complex64)
+    b = (rng.standard_normal(M * nf) + 1j * rng.standard_normal(M * nf)).astype(np.complex64)
+    ya, yb, yab = O.Chan(M).process(a), O.Chan(M).process(b), O.Chan(M).process(a + 2 * b)
+    assert np.allclose(yab, ya + 2 * yb, rtol=0, atol=2e-4)
+    # delaying the input by 2 frames (2M samples, an even number of frames keeps the
+    # (-1)^t premix sign) delays every channel by 2 samples
+    d = np.concatenate([np.zeros(2 * M, np.complex64), a])[: M * nf]
+    yd = O.Chan(M).process(d)
+    assert np.allclose(yd[:, 2:], ya[:, :-2], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("M", [8, 20])
+def test_chunk_size_invariance_is_bit_exact(M):
+    x = synth_cf32(M * 96, M, seed=7)
+    whole = O.Chain(M, dc_block=True, agc_db=-3.0, demod="fm", kf=0.3).process(x)
+    c = O.Chain(M, dc_block=True, agc_db=-3.0, demod="fm", kf=0.3)
+    parts = [c.process(x[s * M:e * M]) for s, e in ((0, 1), (1, 33), (33, 33), (33, 96))]
+    assert np.array_equal(np.concatenate(parts, axis=1), whole)
+
+
+def test_dc_blocker_decay():
+    q = O.DcBlock(0.0005)
+    y = q.execute(np.ones(20000, dtype=np.complex64))
+    n = np.arange(20000)
+    assert np.allclose(y.real, (1 - 0.0005) ** n, atol=2e-4)
+    assert abs(y[-1]) < 1e-4 + (1 - 0.0005) ** 19999
+
+
+def test_nco_pow2_phase_is_periodic_and_exact():
+    M = 256
+    ch = O.Chan(M)
+    d = ch.dtheta
+    assert d == 0x80800000
+    assert (2 * M * d) % (1 << 32) == 0             # period 2M
+    x = np.ones(4 * M, dtype=np.complex64)
+    y = O.Nco(O.pfb_offset(M)).mix_down(x)
+    assert np.array_equal(y[: 2 * M], y[2 * M:])
+
+
+def test_freqdem_slope_and_first_sample():
+    kf = 0.3
+    dw = 0.2
+    n = np.arange(256)
+    r = np.exp(1j * dw * n).astype(np.complex64)
+    m = O.FreqDem(kf).demodulate_block(r)
+    assert np.allclose(m[1:], dw / (2 * np.pi * kf), atol=1e-6)
+    assert m[0] == 0.0                               # arg(conj(0)*r) with r=(1,0)
+    # sign-of-zero quirk of conjf(0)*r for r in the third quadrant: arg(-0 + 0j) = pi
+    m = O.FreqDem(kf).demodulate_block(np.array([-1 - 1j], dtype=np.complex64))
+    assert abs(m[0] - np.float32(np.pi) * np.float32(1 / (2 * np.pi * kf))) < 1e-6
+
+
+def test_agc_converges_to_unit_and_mutes_unless_signalhi():
+    # constant amplitude 0.01 -> g -> 100, rssi = -40 dB
+    x = (0.01 * np.exp(1j * 0.1 * np.arange(4000))).astype(np.complex64)
+    a = O.Agc(-50.0)                                  # -40 dB > -50 dB: squelch opens
+    y = a.execute_block(x)
+    st = a.state
+    assert st["mode"] == 3
+    assert abs(st["g"] - 100.0) / 100.0 < 1e-3
+    assert np.allclose(np.abs(y[-100:]), 1.0, atol=1e-3)
+    # threshold above the signal: always muted
+    b = O.Agc(-30.0)
+    yb = b.execute_block(x)
+    assert np.all(yb[200:] == 0)
+    # first samples: sample 0 moves ENABLED(1) -> RISE(2) (muted), sample 1 RISE -> SIGNALHI(3) (open),
+    # provided rssi = -20log10(g) starts above the threshold (g0 = 1000 -> -60 dB)
+    c = O.Agc(-70.0)
+    yc = c.execute_block(x[:8])
+    assert np.all(yc[:1] == 0) and np.all(yc[1:] != 0)
+
+
+def test_mix_is_left_fold():
+    rng = np.random.default_rng(3)
+    ch = rng.standard_normal((7, 50)).astype(np.float32)
+    want = ch[0].copy()
+    for k in range(1, 7):
+        want = (want + ch[k]).astype(np.float32)
+    assert np.array_equal(O.mix_f32(ch), want)
+
+
+def test_chain_mix_matches_manual_composition():
+    M = 8
+    x = synth_cf32(M * 64, M, seed=11)
+    full = O.Chain(M, dc_block=True, agc_db=0.0, demod="fm", kf=0.6, mix=False).process(x)
+    mixed = O.Chain(M, dc_block=True, agc_db=0.0, demod="fm", kf=0.6, mix=True).process(x)
+    assert np.array_equal(mixed, O.mix_f32(full))
+    # and the chain equals dc -> chan -> fm composed by hand
+    d = O.DcBlock().execute(x)
+    c = O.Chan(M).process(d)
+    f = np.stack([O.FreqDem(0.6).demodulate_block(c[k]) for k in range(M)])
+    assert np.array_equal(f, full)
