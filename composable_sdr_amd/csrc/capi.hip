@@ -1,0 +1,597 @@
+// C ABI of libcsdr_hip.so (see include/csdr.h).  Handle management, device buffers,
+// stream state, and the per-chunk launch sequences.  Product code: no CPU fallback,
+// nothing from oracle/.
+#include "../../include/csdr.h"
+#include "csdr_internal.h"
+#include "fused.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+namespace csdr {
+const char *last_error();
+}
+using namespace csdr;
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+namespace {
+
+struct DevGuard {
+    int prev = -1; bool ok = true;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (dev >= 0 && dev != prev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int check_device(int32_t want, int *out_dev)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (hipGetDeviceCount: %s); libcsdr_hip has no CPU fallback",
+                  e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return CSDR_ERR_NODEV;
+    }
+    int dev = want;
+    if (dev < 0) { CSDR_HIP(hipGetDevice(&dev)); }
+    if (dev >= n) { set_error("device %d out of range (%d visible)", dev, n); return CSDR_ERR_INVALID; }
+    *out_dev = dev;
+    return 0;
+}
+
+template <class T> int dev_alloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (!count) count = 1;
+    CSDR_HIP(hipMalloc((void **)p, count * sizeof(T)));
+    return 0;
+}
+
+DcParams make_dc(float alpha)
+{
+    DcParams d;
+    d.a1 = -1.0f + alpha;                 // iirfilt_crcf_create_dc_blocker
+    d.beta = -d.a1;
+    for (int i = 0; i < 9; i++) d.beta_pow_thr[i] = (float)std::pow((double)d.beta, (double)(DC_PER_THREAD << i));
+    d.beta_blk = std::pow((double)d.beta, (double)DC_BLOCK);
+    return d;
+}
+
+struct KernelTimer {
+    std::vector<hipEvent_t> ev;          // pairs
+    size_t used = 0;
+    double acc_ms = 0.0; uint32_t launches = 0;
+    bool enabled = false;
+    int begin(hipStream_t s) {
+        if (!enabled) return 0;
+        if (used + 2 > ev.size()) {
+            if (ev.size() >= 4096) { int r = drain(); if (r) return r; }
+            else for (int i = 0; i < 2; i++) { hipEvent_t e; CSDR_HIP(hipEventCreate(&e)); ev.push_back(e); }
+        }
+        CSDR_HIP(hipEventRecord(ev[used], s));
+        return 0;
+    }
+    int end(hipStream_t s) {
+        if (!enabled) return 0;
+        CSDR_HIP(hipEventRecord(ev[used + 1], s));
+        used += 2;
+        return 0;
+    }
+    int drain() {
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            CSDR_HIP(hipEventSynchronize(ev[i + 1]));
+            float ms = 0.f;
+            CSDR_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            acc_ms += ms; launches++;
+        }
+        used = 0;
+        return 0;
+    }
+    void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); used = 0; }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------
+struct csdr_dcblock {
+    int device; uint32_t max_n; DcParams dc;
+    float2 *d_state = nullptr, *d_scratch = nullptr, *d_x = nullptr, *d_y = nullptr;
+};
+struct csdr_nco {
+    int device; uint32_t max_n; uint32_t theta, d_theta;
+    float2 *d_x = nullptr, *d_y = nullptr;
+};
+struct csdr_agc {
+    int device; uint32_t C, max_n; AgcParams p; AgcState *d_st = nullptr; float2 *d_z = nullptr;
+};
+struct csdr_freqdem {
+    int device; uint32_t C, max_n; float ref; float2 *d_rp[2] = {nullptr, nullptr}; int cur = 0;
+    float2 *d_z = nullptr; float *d_f = nullptr;
+};
+
+struct csdr_chain {
+    csdr_chain_cfg cfg;
+    int device;
+    uint32_t M, p, C, c0, max_nf; uint64_t max_nx;
+    bool use_fused = false;
+    std::string path;
+    // design
+    std::vector<float> taps;
+    uint32_t theta = 0, d_theta = 0, tab_len = 0, tab_pos = 0;
+    DcParams dc; AgcParams agc; float fm_ref = 0.f;
+    // device memory
+    float *d_taps = nullptr;
+    float2 *d_tw = nullptr, *d_nco_tab = nullptr, *d_dcstate = nullptr, *d_scratch = nullptr;
+    float2 *d_u = nullptr, *d_hist_tmp = nullptr, *d_A = nullptr, *d_B = nullptr;
+    AgcState *d_agc = nullptr;
+    float2 *d_rp[2] = {nullptr, nullptr}; int rp_cur = 0;
+    // host-API staging
+    float2 *d_in_stage = nullptr; void *d_out_stage = nullptr;
+    FusedPlan *fused = nullptr;
+    KernelTimer timer;
+    std::string timed_kernel;
+};
+
+extern "C" {
+
+const char *csdr_last_error(void) { return csdr::last_error(); }
+const char *csdr_version(void) { return "csdr-hip gfx950 0.1"; }
+
+int csdr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// dcBlocker
+// ---------------------------------------------------------------------------
+int csdr_dcblock_create(float alpha, uint32_t max_samples, csdr_dcblock **out)
+{
+    if (!out || !(alpha > 0.f && alpha < 1.f)) { set_error("dcblock: bad arguments"); return CSDR_ERR_INVALID; }
+    int dev; int r = check_device(-1, &dev); if (r) return r;
+    csdr_dcblock *h = new (std::nothrow) csdr_dcblock();
+    if (!h) return CSDR_ERR_NOMEM;
+    h->device = dev; h->max_n = max_samples ? max_samples : 1u << 20; h->dc = make_dc(alpha);
+    if ((r = dev_alloc(&h->d_state, 1)) || (r = dev_alloc(&h->d_scratch, 2 * (size_t)(h->max_n / DC_BLOCK + 2))) ||
+        (r = dev_alloc(&h->d_x, h->max_n)) || (r = dev_alloc(&h->d_y, h->max_n))) { csdr_dcblock_destroy(h); return r; }
+    CSDR_HIP(hipMemset(h->d_state, 0, sizeof(float2)));
+    *out = h;
+    return CSDR_OK;
+}
+
+int csdr_dcblock_process_device(csdr_dcblock *h, const void *d_x, uint32_t n, void *d_y, void *stream)
+{
+    if (!h) { set_error("dcblock: null handle"); return CSDR_ERR_INVALID; }
+    if (n > h->max_n) { set_error("dcblock: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
+    NcoParams nco{};
+    return launch_dc_mix((const float2 *)d_x, (float2 *)d_y, n, true, h->dc, h->d_state, h->d_scratch, false, nco,
+                         nullptr, (hipStream_t)stream);
+}
+
+int csdr_dcblock_process(csdr_dcblock *h, const float *x, uint32_t n, float *y)
+{
+    if (!h || (n && (!x || !y))) { set_error("dcblock: null argument"); return CSDR_ERR_INVALID; }
+    if (n > h->max_n) { set_error("dcblock: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
+    if (!n) return CSDR_OK;
+    CSDR_HIP(hipMemcpy(h->d_x, x, sizeof(float2) * n, hipMemcpyHostToDevice));
+    int r = csdr_dcblock_process_device(h, h->d_x, n, h->d_y, nullptr);
+    if (r) return r;
+    CSDR_HIP(hipMemcpy(y, h->d_y, sizeof(float2) * n, hipMemcpyDeviceToHost));
+    return CSDR_OK;
+}
+
+int csdr_dcblock_destroy(csdr_dcblock *h)
+{
+    if (!h) return CSDR_OK;
+    (void)hipFree(h->d_state); (void)hipFree(h->d_scratch); (void)hipFree(h->d_x); (void)hipFree(h->d_y);
+    delete h;
+    return CSDR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// mixDown / mixUp
+// ---------------------------------------------------------------------------
+int csdr_nco_create(float freq, uint32_t max_samples, csdr_nco **out)
+{
+    if (!out || !std::isfinite(freq)) { set_error("nco: bad arguments"); return CSDR_ERR_INVALID; }
+    int dev; int r = check_device(-1, &dev); if (r) return r;
+    csdr_nco *h = new (std::nothrow) csdr_nco();
+    if (!h) return CSDR_ERR_NOMEM;
+    h->device = dev; h->max_n = max_samples ? max_samples : 1u << 20;
+    h->theta = 0; h->d_theta = nco_freq_word(freq);
+    if ((r = dev_alloc(&h->d_x, h->max_n)) || (r = dev_alloc(&h->d_y, h->max_n))) { csdr_nco_destroy(h); return r; }
+    *out = h;
+    return CSDR_OK;
+}
+
+static int nco_mix(csdr_nco *h, const float *x, uint32_t n, float *y, int up)
+{
+    if (!h || (n && (!x || !y))) { set_error("nco: null argument"); return CSDR_ERR_INVALID; }
+    if (n > h->max_n) { set_error("nco: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
+    if (!n) return CSDR_OK;
+    CSDR_HIP(hipMemcpy(h->d_x, x, sizeof(float2) * n, hipMemcpyHostToDevice));
+    NcoParams nco{}; nco.theta0 = h->theta; nco.d_theta = h->d_theta; nco.up = up;
+    DcParams dc{};
+    int r = launch_dc_mix(h->d_x, h->d_y, n, false, dc, nullptr, nullptr, true, nco, nullptr, nullptr);
+    if (r) return r;
+    CSDR_HIP(hipMemcpy(y, h->d_y, sizeof(float2) * n, hipMemcpyDeviceToHost));
+    h->theta += n * h->d_theta;
+    return CSDR_OK;
+}
+int csdr_nco_mix_down(csdr_nco *h, const float *x, uint32_t n, float *y) { return nco_mix(h, x, n, y, 0); }
+int csdr_nco_mix_up(csdr_nco *h, const float *x, uint32_t n, float *y) { return nco_mix(h, x, n, y, 1); }
+int csdr_nco_get_words(const csdr_nco *h, uint32_t *theta, uint32_t *d_theta)
+{
+    if (!h) return CSDR_ERR_INVALID;
+    if (theta) *theta = h->theta;
+    if (d_theta) *d_theta = h->d_theta;
+    return CSDR_OK;
+}
+int csdr_nco_destroy(csdr_nco *h)
+{
+    if (!h) return CSDR_OK;
+    (void)hipFree(h->d_x); (void)hipFree(h->d_y);
+    delete h;
+    return CSDR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// automaticGainControl (nchan instances)
+// ---------------------------------------------------------------------------
+static AgcParams make_agc(float thr_db)
+{
+    AgcParams p; p.alpha = 0.1f; p.g_thr = agc_gain_threshold(thr_db); p.timeout = 1000u;
+    return p;
+}
+
+int csdr_agc_create(float threshold_db, uint32_t nchan, uint32_t max_samples, csdr_agc **out)
+{
+    if (!out || !nchan || !std::isfinite(threshold_db)) { set_error("agc: bad arguments"); return CSDR_ERR_INVALID; }
+    int dev; int r = check_device(-1, &dev); if (r) return r;
+    csdr_agc *h = new (std::nothrow) csdr_agc();
+    if (!h) return CSDR_ERR_NOMEM;
+    h->device = dev; h->C = nchan; h->max_n = max_samples ? max_samples : 4096; h->p = make_agc(threshold_db);
+    if ((r = dev_alloc(&h->d_st, nchan)) || (r = dev_alloc(&h->d_z, (size_t)nchan * h->max_n))) { csdr_agc_destroy(h); return r; }
+    if ((r = launch_agc_init(h->d_st, nchan, nullptr))) { csdr_agc_destroy(h); return r; }
+    CSDR_HIP(hipDeviceSynchronize());
+    *out = h;
+    return CSDR_OK;
+}
+int csdr_agc_process(csdr_agc *h, const float *x, uint32_t n, float *y)
+{
+    if (!h || (n && (!x || !y))) { set_error("agc: null argument"); return CSDR_ERR_INVALID; }
+    if (n > h->max_n) { set_error("agc: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
+    if (!n) return CSDR_OK;
+    const size_t bytes = sizeof(float2) * (size_t)h->C * n;
+    CSDR_HIP(hipMemcpy(h->d_z, x, bytes, hipMemcpyHostToDevice));
+    int r = launch_agc(h->d_z, h->C, n, h->d_st, h->p, nullptr);
+    if (r) return r;
+    CSDR_HIP(hipMemcpy(y, h->d_z, bytes, hipMemcpyDeviceToHost));
+    return CSDR_OK;
+}
+int csdr_agc_destroy(csdr_agc *h)
+{
+    if (!h) return CSDR_OK;
+    (void)hipFree(h->d_st); (void)hipFree(h->d_z);
+    delete h;
+    return CSDR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fmDemodulator (nchan instances)
+// ---------------------------------------------------------------------------
+static float fm_ref_of(float kf) { return (float)(1.0 / (2.0 * 3.14159265358979323846 * (double)kf)); }
+
+int csdr_freqdem_create(float kf, uint32_t nchan, uint32_t max_samples, csdr_freqdem **out)
+{
+    if (!out || !nchan || !(kf > 0.f)) { set_error("freqdem: bad arguments (kf must be > 0)"); return CSDR_ERR_INVALID; }
+    int dev; int r = check_device(-1, &dev); if (r) return r;
+    csdr_freqdem *h = new (std::nothrow) csdr_freqdem();
+    if (!h) return CSDR_ERR_NOMEM;
+    h->device = dev; h->C = nchan; h->max_n = max_samples ? max_samples : 4096; h->ref = fm_ref_of(kf);
+    if ((r = dev_alloc(&h->d_rp[0], nchan)) || (r = dev_alloc(&h->d_rp[1], nchan)) ||
+        (r = dev_alloc(&h->d_z, (size_t)nchan * h->max_n)) || (r = dev_alloc(&h->d_f, (size_t)nchan * h->max_n))) {
+        csdr_freqdem_destroy(h); return r;
+    }
+    CSDR_HIP(hipMemset(h->d_rp[0], 0, sizeof(float2) * nchan));
+    CSDR_HIP(hipMemset(h->d_rp[1], 0, sizeof(float2) * nchan));
+    *out = h;
+    return CSDR_OK;
+}
+int csdr_freqdem_process(csdr_freqdem *h, const float *x, uint32_t n, float *m)
+{
+    if (!h || (n && (!x || !m))) { set_error("freqdem: null argument"); return CSDR_ERR_INVALID; }
+    if (n > h->max_n) { set_error("freqdem: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
+    if (!n) return CSDR_OK;
+    CSDR_HIP(hipMemcpy(h->d_z, x, sizeof(float2) * (size_t)h->C * n, hipMemcpyHostToDevice));
+    int r = launch_fm(h->d_z, h->d_f, h->C, n, h->ref, h->d_rp[h->cur], h->d_rp[h->cur ^ 1], nullptr);
+    if (r) return r;
+    h->cur ^= 1;
+    CSDR_HIP(hipMemcpy(m, h->d_f, sizeof(float) * (size_t)h->C * n, hipMemcpyDeviceToHost));
+    return CSDR_OK;
+}
+int csdr_freqdem_destroy(csdr_freqdem *h)
+{
+    if (!h) return CSDR_OK;
+    (void)hipFree(h->d_rp[0]); (void)hipFree(h->d_rp[1]); (void)hipFree(h->d_z); (void)hipFree(h->d_f);
+    delete h;
+    return CSDR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fused chain
+// ---------------------------------------------------------------------------
+void csdr_chain_cfg_default(csdr_chain_cfg *cfg, uint32_t channels)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = sizeof(*cfg);
+    cfg->channels = channels ? channels : 1;
+    cfg->dc_block = 1;
+    cfg->dc_alpha = 0.0005f;
+    cfg->agc_threshold_db = 0.0f;
+    cfg->demod = CSDR_DEMOD_NONE;
+    cfg->kf = 0.3f;
+    cfg->device = -1;
+    cfg->max_frames = 4096;
+    cfg->pfb_m = 7;
+    cfg->pfb_as = 80.0f;
+}
+
+static int chain_init_state(csdr_chain *h, hipStream_t s)
+{
+    h->theta = 0; h->tab_pos = 0; h->rp_cur = 0;
+    CSDR_HIP(hipMemsetAsync(h->d_dcstate, 0, sizeof(float2), s));
+    if (h->d_u) CSDR_HIP(hipMemsetAsync(h->d_u, 0, sizeof(float2) * (size_t)(h->p - 1) * h->M, s));
+    if (h->d_agc) { int r = launch_agc_init(h->d_agc, h->C, s); if (r) return r; }
+    if (h->d_rp[0]) {
+        CSDR_HIP(hipMemsetAsync(h->d_rp[0], 0, sizeof(float2) * h->C, s));
+        CSDR_HIP(hipMemsetAsync(h->d_rp[1], 0, sizeof(float2) * h->C, s));
+    }
+    if (h->fused) { int r = fused_reset(h->fused, s); if (r) return r; }
+    return 0;
+}
+
+int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
+{
+    if (!cfg || !out) { set_error("chain: null argument"); return CSDR_ERR_INVALID; }
+    if (cfg->struct_size != sizeof(csdr_chain_cfg)) { set_error("chain: cfg.struct_size %u != %zu", cfg->struct_size, sizeof(csdr_chain_cfg)); return CSDR_ERR_INVALID; }
+    if (cfg->channels < 1 || cfg->channels > (1u << 16)) { set_error("chain: channels %u out of range", cfg->channels); return CSDR_ERR_INVALID; }
+    if (cfg->demod > CSDR_DEMOD_FM) { set_error("chain: unknown demod %u", cfg->demod); return CSDR_ERR_INVALID; }
+    if (cfg->demod == CSDR_DEMOD_FM && !(cfg->kf > 0.f)) { set_error("chain: FM needs kf > 0"); return CSDR_ERR_INVALID; }
+    if (cfg->dc_block && !(cfg->dc_alpha > 0.f && cfg->dc_alpha < 1.f)) { set_error("chain: dc_alpha out of (0,1)"); return CSDR_ERR_INVALID; }
+    const uint32_t M = cfg->channels;
+    uint32_t c0 = cfg->chan_first, C = cfg->chan_count ? cfg->chan_count : M - c0;
+    if (c0 >= M || C == 0 || c0 + C > M) { set_error("chain: channel shard [%u,+%u) outside 0..%u", c0, C, M); return CSDR_ERR_INVALID; }
+    int dev; int r = check_device(cfg->device, &dev); if (r) return r;
+    DevGuard guard(dev);
+    if (!guard.ok) { set_error("chain: cannot select device %d", dev); return CSDR_ERR_HIP; }
+
+    csdr_chain *h = new (std::nothrow) csdr_chain();
+    if (!h) return CSDR_ERR_NOMEM;
+    h->cfg = *cfg; h->device = dev; h->M = M; h->C = C; h->c0 = c0;
+    const uint32_t m = cfg->pfb_m ? cfg->pfb_m : 7;
+    const float As = cfg->pfb_as > 0.f ? cfg->pfb_as : 80.0f;
+    h->p = 2 * m;
+    h->max_nf = cfg->max_frames ? cfg->max_frames : 4096;
+    h->max_nx = (uint64_t)h->max_nf * M;
+    if (h->max_nx > 0xffffffffull) { set_error("chain: max_frames*channels exceeds 2^32-1 samples"); delete h; return CSDR_ERR_INVALID; }
+    h->timer.enabled = (cfg->flags & CSDR_FLAG_TIME_KERNELS) != 0;
+    if (cfg->dc_block) h->dc = make_dc(cfg->dc_alpha);
+    if (cfg->agc_threshold_db != 0.0f) h->agc = make_agc(cfg->agc_threshold_db);
+    if (cfg->demod == CSDR_DEMOD_FM) h->fm_ref = fm_ref_of(cfg->kf);
+
+    auto fail = [&](int code) { csdr_chain_destroy(h); return code; };
+    if ((r = dev_alloc(&h->d_dcstate, 1))) return fail(r);
+    if ((r = dev_alloc(&h->d_scratch, 2 * (size_t)(h->max_nx / DC_BLOCK + 2)))) return fail(r);
+
+    if (M > 1) {
+        h->taps = design_pfb_taps(M, m, As);
+        h->d_theta = nco_freq_word(pfb_premix_freq(M));
+        h->tab_len = nco_period(h->d_theta, 1u << 17);
+        if ((r = dev_alloc(&h->d_taps, h->taps.size()))) return fail(r);
+        CSDR_HIP(hipMemcpy(h->d_taps, h->taps.data(), sizeof(float) * h->taps.size(), hipMemcpyHostToDevice));
+        if (h->tab_len) {
+            std::vector<float2> tab(h->tab_len);
+            for (uint32_t i = 0; i < h->tab_len; i++) { float c, s; nco_phasor(i * h->d_theta, &c, &s); tab[i] = make_float2(c, s); }
+            if ((r = dev_alloc(&h->d_nco_tab, h->tab_len))) return fail(r);
+            CSDR_HIP(hipMemcpy(h->d_nco_tab, tab.data(), sizeof(float2) * h->tab_len, hipMemcpyHostToDevice));
+        }
+        std::vector<float2> tw(M);
+        for (uint32_t i = 0; i < M; i++) {
+            double a = -2.0 * 3.14159265358979323846 * (double)i / (double)M;
+            tw[i] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        if ((r = dev_alloc(&h->d_tw, M))) return fail(r);
+        CSDR_HIP(hipMemcpy(h->d_tw, tw.data(), sizeof(float2) * M, hipMemcpyHostToDevice));
+    }
+    if (cfg->agc_threshold_db != 0.0f && (r = dev_alloc(&h->d_agc, C))) return fail(r);
+    if (cfg->demod == CSDR_DEMOD_FM && ((r = dev_alloc(&h->d_rp[0], C)) || (r = dev_alloc(&h->d_rp[1], C)))) return fail(r);
+
+    // Path selection: fused kernels cover power-of-two M without AGC; everything else
+    // (and anything with the sequential AGC tail) runs the generic multi-kernel path.
+    h->use_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && fused_supported(M, h->p) &&
+                   cfg->agc_threshold_db == 0.0f;
+    if (h->use_fused) {
+        FusedConfig fc{};
+        fc.M = M; fc.p = h->p; fc.C = C; fc.c0 = c0; fc.max_nf = h->max_nf;
+        fc.dc_block = cfg->dc_block != 0; fc.dc = h->dc; fc.fm = cfg->demod == CSDR_DEMOD_FM; fc.fm_ref = h->fm_ref;
+        fc.mix = cfg->mix != 0; fc.taps = h->taps.data(); fc.d_theta = h->d_theta;
+        if ((r = fused_create(fc, &h->fused))) return fail(r);
+        h->path = std::string("fused-") + fused_name(h->fused);
+        h->timed_kernel = fused_name(h->fused);
+    } else {
+        h->path = "generic";
+        h->timed_kernel = M > 1 ? "k_pfb_fir" : "k_dc_apply";
+        if (M > 1) {
+            if ((r = dev_alloc(&h->d_u, (size_t)(h->p - 1) * M + h->max_nx)) || (r = dev_alloc(&h->d_hist_tmp, (size_t)(h->p - 1) * M))) return fail(r);
+        }
+        if ((r = dev_alloc(&h->d_A, h->max_nx)) || (r = dev_alloc(&h->d_B, h->max_nx))) return fail(r);
+    }
+    if ((r = chain_init_state(h, nullptr))) return fail(r);
+    CSDR_HIP(hipDeviceSynchronize());
+
+    if (!(cfg->flags & CSDR_FLAG_QUIET)) {
+        // what the reference prints at create (Liquid.chs:577-579, 814-820, 714-716, 319-321)
+        printf("csdr chain [%s] on HIP device %d: channels=%u (shard %u..%u) taps=%u (m=%u, As=%.1f) "
+               "nco.d_theta=0x%08x dc_block=%u(alpha=%g) agc=%g dB demod=%s kf=%g mix=%u\n",
+               h->path.c_str(), dev, M, c0, c0 + C - 1, M > 1 ? M * h->p : 0, m, As, h->d_theta, cfg->dc_block,
+               cfg->dc_alpha, cfg->agc_threshold_db, cfg->demod == CSDR_DEMOD_FM ? "FM" : "none", cfg->kf, cfg->mix);
+        fflush(stdout);
+    }
+    *out = h;
+    return CSDR_OK;
+}
+
+uint32_t csdr_chain_out_elem_size(const csdr_chain *h) { return h && h->cfg.demod == CSDR_DEMOD_FM ? 4u : 8u; }
+
+static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d_out, hipStream_t s)
+{
+    const uint32_t M = h->M, nf = nx / M, C = h->C;
+    const bool fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix && M > 1, agc = h->d_agc != nullptr;
+    int r;
+    // where the channel-major CF32 lands
+    float2 *Z = (!fm && !mixo) ? (float2 *)d_out : h->d_A;
+    NcoParams nco{};
+    if (M > 1) {
+        const size_t hist = (size_t)(h->p - 1) * M;
+        nco.theta0 = h->theta; nco.d_theta = h->d_theta; nco.tab_len = h->tab_len; nco.tab_pos = h->tab_pos; nco.up = 0;
+        float2 *u_new = h->d_u + hist;
+        if ((r = launch_dc_mix(d_in, u_new, nx, h->cfg.dc_block != 0, h->dc, h->d_dcstate, h->d_scratch, true, nco, h->d_nco_tab, s))) return r;
+        if ((r = h->timer.begin(s))) return r;
+        if ((r = launch_pfb_fir(u_new, h->d_taps, h->d_A, M, h->p, nf, s))) return r;
+        if ((r = h->timer.end(s))) return r;
+        // keep the last (p-1) frames of premixed input as the next call's history
+        CSDR_HIP(hipMemcpyAsync(h->d_hist_tmp, h->d_u + nx, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
+        CSDR_HIP(hipMemcpyAsync(h->d_u, h->d_hist_tmp, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
+        if ((r = launch_dft(h->d_A, h->d_B, h->d_tw, M, nf, s))) return r;
+        if ((r = launch_transpose(h->d_B, Z, M, nf, h->c0, C, s))) return r;
+        h->theta += nx * h->d_theta;
+        if (h->tab_len) h->tab_pos = (uint32_t)(((uint64_t)h->tab_pos + nx) % h->tab_len);
+    } else {
+        if ((r = h->timer.begin(s))) return r;
+        if ((r = launch_dc_mix(d_in, Z, nx, h->cfg.dc_block != 0, h->dc, h->d_dcstate, h->d_scratch, false, nco, nullptr, s))) return r;
+        if ((r = h->timer.end(s))) return r;
+    }
+    if (agc && (r = launch_agc(Z, C, nf, h->d_agc, h->agc, s))) return r;
+    if (fm) {
+        float *F = mixo ? (float *)h->d_B : (float *)d_out;
+        if ((r = launch_fm(Z, F, C, nf, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s))) return r;
+        h->rp_cur ^= 1;
+        if (mixo && (r = launch_mix(F, (float *)d_out, C, nf, s))) return r;
+    } else if (mixo) {
+        if ((r = launch_mix((const float *)Z, (float *)d_out, C, 2 * nf, s))) return r;
+    }
+    return 0;
+}
+
+int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
+{
+    if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
+    if (n_out) *n_out = 0;
+    if (n_in == 0) return CSDR_OK;
+    if (!d_in || !d_out) { set_error("chain: null buffer"); return CSDR_ERR_INVALID; }
+    if (n_in % h->M) { set_error("chain: n_in=%u is not a multiple of channels=%u (the reference misbehaves here; Liquid.chs:832-862)", n_in, h->M); return CSDR_ERR_SIZE; }
+    if (n_in > h->max_nx) { set_error("chain: n_in=%u exceeds max_frames*channels=%llu", n_in, (unsigned long long)h->max_nx); return CSDR_ERR_SIZE; }
+    DevGuard guard(h->device);
+    if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nf = n_in / h->M;
+    int r;
+    if (h->use_fused) {
+        FusedCall fcall{};
+        fcall.d_in = (const float2 *)d_in; fcall.d_out = d_out; fcall.nf = nf; fcall.theta0 = h->theta;
+        if ((r = h->timer.begin(s))) return r;
+        if ((r = fused_process(h->fused, fcall, s))) return r;
+        if ((r = h->timer.end(s))) return r;
+        h->theta += n_in * h->d_theta;
+    } else {
+        if ((r = chain_generic(h, (const float2 *)d_in, n_in, d_out, s))) return r;
+    }
+    if (n_out) *n_out = (h->cfg.mix && h->M > 1) ? nf : h->C * nf;
+    return CSDR_OK;
+}
+
+int csdr_chain_process(csdr_chain *h, const float *in, uint32_t n_in, void *out, uint32_t *n_out)
+{
+    if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
+    if (n_out) *n_out = 0;
+    if (n_in == 0) return CSDR_OK;
+    if (!in || !out) { set_error("chain: null buffer"); return CSDR_ERR_INVALID; }
+    if (n_in % h->M) { set_error("chain: n_in=%u is not a multiple of channels=%u (the reference misbehaves here; Liquid.chs:832-862)", n_in, h->M); return CSDR_ERR_SIZE; }
+    if (n_in > h->max_nx) { set_error("chain: n_in=%u exceeds max_frames*channels=%llu", n_in, (unsigned long long)h->max_nx); return CSDR_ERR_SIZE; }
+    DevGuard guard(h->device);
+    if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
+    int r;
+    const size_t out_max = (size_t)h->C * h->max_nf * 8;
+    if (!h->d_in_stage && ((r = dev_alloc(&h->d_in_stage, h->max_nx)))) return r;
+    if (!h->d_out_stage) { CSDR_HIP(hipMalloc(&h->d_out_stage, out_max)); }
+    CSDR_HIP(hipMemcpy(h->d_in_stage, in, sizeof(float2) * (size_t)n_in, hipMemcpyHostToDevice));
+    uint32_t no = 0;
+    if ((r = csdr_chain_process_device(h, h->d_in_stage, n_in, h->d_out_stage, &no, nullptr))) return r;
+    CSDR_HIP(hipMemcpy(out, h->d_out_stage, (size_t)no * csdr_chain_out_elem_size(h), hipMemcpyDeviceToHost));
+    if (n_out) *n_out = no;
+    return CSDR_OK;
+}
+
+int csdr_chain_reset(csdr_chain *h)
+{
+    if (!h) return CSDR_ERR_INVALID;
+    DevGuard guard(h->device);
+    int r = chain_init_state(h, nullptr);
+    if (r) return r;
+    CSDR_HIP(hipDeviceSynchronize());
+    return CSDR_OK;
+}
+
+int csdr_chain_get_taps(const csdr_chain *h, float *taps, uint32_t n)
+{
+    if (!h || !taps) return CSDR_ERR_INVALID;
+    if (n > h->taps.size()) n = (uint32_t)h->taps.size();
+    memcpy(taps, h->taps.data(), sizeof(float) * n);
+    return (int)n;
+}
+int csdr_chain_get_nco(const csdr_chain *h, uint32_t *theta, uint32_t *d_theta)
+{
+    if (!h) return CSDR_ERR_INVALID;
+    if (theta) *theta = h->theta;
+    if (d_theta) *d_theta = h->d_theta;
+    return CSDR_OK;
+}
+const char *csdr_chain_path(const csdr_chain *h) { return h ? h->path.c_str() : ""; }
+
+const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *launches)
+{
+    if (!h) return "";
+    (void)h->timer.drain();
+    if (total_ms) *total_ms = h->timer.acc_ms;
+    if (launches) *launches = h->timer.launches;
+    h->timer.acc_ms = 0.0; h->timer.launches = 0;
+    return h->timed_kernel.c_str();
+}
+
+int csdr_chain_destroy(csdr_chain *h)
+{
+    if (!h) return CSDR_OK;
+    DevGuard guard(h->device);
+    (void)hipDeviceSynchronize();
+    if (h->fused) fused_destroy(h->fused);
+    h->timer.destroy();
+    void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
+                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_in_stage, h->d_out_stage};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return CSDR_OK;
+}
+
+}  // extern "C"

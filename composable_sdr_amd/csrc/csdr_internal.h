@@ -1,0 +1,93 @@
+// Internal declarations shared by the HIP translation units of libcsdr_hip.so.
+// Product code: must not include or link anything under oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace csdr {
+
+// ---- error plumbing -------------------------------------------------------
+void set_error(const char *fmt, ...);
+int  hip_fail(hipError_t e, const char *what, const char *file, int line);
+#define CSDR_HIP(call)                                                          \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) return ::csdr::hip_fail(e__, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// ---- host-side design (design.cpp) -----------------------------------------
+// Kaiser prototype of firpfbch_crcf_create_kaiser(ANALYZER, M, m, As)
+// (reference call: Liquid.chs:813).  Returns the M*2m taps the bank uses.
+std::vector<float> design_pfb_taps(uint32_t M, uint32_t m, float As);
+// nco_crcf_set_frequency's float -> uint32 phase-step conversion.
+uint32_t nco_freq_word(float freq);
+// Haskell-Float value of  -0.5*(M-1)/M*2*pi  (Liquid.chs:817).
+float pfb_premix_freq(uint32_t M);
+// cos/sin of one uint32 phase, evaluated like nco_crcf (VCO) does.
+void nco_phasor(uint32_t theta, float *c, float *s);
+// Period (in samples) of the phase sequence k*d_theta mod 2^32; 0 if > limit.
+uint32_t nco_period(uint32_t d_theta, uint32_t limit);
+// Smallest gain g for which rssi(g) = (float)(-20*log10(g)) is NOT above thr:
+// squelch "threshold exceeded"  <=>  g < returned value.
+float agc_gain_threshold(float threshold_db);
+
+// ---- device-side parameter blocks ------------------------------------------
+constexpr int DC_THREADS = 256;
+constexpr int DC_PER_THREAD = 8;
+constexpr int DC_BLOCK = DC_THREADS * DC_PER_THREAD;   // samples per scan block
+
+struct DcParams {
+    float a1;              // -(1-alpha)        (v0 = x - a1*v1)
+    float beta;            // 1-alpha as f32 = -a1
+    float beta_pow_thr[9]; // beta^(DC_PER_THREAD * 2^i), i=0..8
+    double beta_blk;       // beta^DC_BLOCK (f64)
+};
+
+struct NcoParams {
+    uint32_t theta0;       // phase of the first sample of this call
+    uint32_t d_theta;
+    uint32_t tab_len;      // 0: evaluate sincos on device; else period of the table
+    uint32_t tab_pos;      // index of the first sample of this call in the table
+    int      up;           // 1: multiply by v, 0: by conj(v)
+};
+
+struct AgcParams {
+    float alpha;           // 0.1
+    float g_thr;           // exceeded <=> g < g_thr
+    uint32_t timeout;      // 1000
+};
+
+// per-channel AGC state as kept on the device between chunks
+struct AgcState { float g, y2; int32_t mode; uint32_t timer; };
+
+// ---- generic kernels (kernels_generic.hip) ----------------------------------
+// DC blocker [+ NCO mix] of n samples: y[i] = mix(dcblock(x[i])).  `state` is the
+// device-resident v1 (float2), updated in place.  scratch: >= 2*ceil(n/DC_BLOCK)+2 float2.
+int launch_dc_mix(const float2 *x, float2 *y, uint32_t n, bool do_dc, const DcParams &dc,
+                  float2 *state, float2 *scratch, bool do_mix, const NcoParams &nco,
+                  const float2 *nco_tab, hipStream_t s);
+// X[t][j] = sum_n h[(M-1-j)+n*M] * u[(t-n)*M + j], u points at the first NEW sample and
+// has (p-1)*M samples of history in front of it.
+int launch_pfb_fir(const float2 *u, const float *taps, float2 *X, uint32_t M, uint32_t p,
+                   uint32_t nf, hipStream_t s);
+// forward M-point DFT of every frame: Y[t][k].  tw: e^{-j 2 pi i/M}, i<M.
+int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s);
+// Z[c][t] = Y[t][c0 + c]  for c < C
+int launch_transpose(const float2 *Y, float2 *Z, uint32_t M, uint32_t nf, uint32_t c0, uint32_t C,
+                     hipStream_t s);
+// per-channel AGC + squelch mute, in place on Z[C][nf]
+int launch_agc(float2 *Z, uint32_t C, uint32_t nf, AgcState *st, const AgcParams &p, hipStream_t s);
+// F[c][t] = arg(conj(prev)*Z[c][t]) * ref ; rp_in/rp_out: per-channel r'
+int launch_fm(const float2 *Z, float *F, uint32_t C, uint32_t nf, float ref, const float2 *rp_in,
+              float2 *rp_out, hipStream_t s);
+// out[i] = ((in[0][i] + in[1][i]) + ...) + in[C-1][i], row length E floats
+int launch_mix(const float *in, float *out, uint32_t C, uint32_t E, hipStream_t s);
+int launch_agc_init(AgcState *st, uint32_t C, hipStream_t s);
+
+// ---- fused kernels (kernels_fused.hip) --------------------------------------
+struct FusedPlan;   // opaque per-handle plan
+bool fused_supported(uint32_t M, uint32_t p);
+
+}  // namespace csdr

@@ -1,0 +1,130 @@
+// Host-side filter / oscillator design for libcsdr_hip.so (product code).
+// Mirrors what the reference obtains from liquid-dsp at object creation:
+//   firpfbch_crcf_create_kaiser(0, M, 7, 80.0)            Liquid.chs:813
+//   nco_crcf_create(LIQUID_VCO) + set_frequency(offset)    Liquid.chs:816-818
+//   agc_crcf_squelch_set_threshold                         Liquid.chs:713
+#include "csdr_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace csdr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char *last_error() { return g_err; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return e == hipErrorOutOfMemory ? -5 : -2;
+}
+
+// Modified Bessel function I0 by its power series (converged to f64 precision).
+static double bessel_i0(double z)
+{
+    double q = 0.25 * z * z, term = 1.0, sum = 1.0;
+    for (int k = 1; k < 200; k++) {
+        term *= q / ((double)k * (double)k);
+        sum += term;
+        if (term < 1e-18 * sum) break;
+    }
+    return sum;
+}
+
+static double kaiser_beta(double As)
+{
+    As = std::fabs(As);
+    if (As > 50.0) return 0.1102 * (As - 8.7);
+    if (As > 21.0) return 0.5842 * std::pow(As - 21.0, 0.4) + 0.07886 * (As - 21.0);
+    return 0.0;
+}
+
+std::vector<float> design_pfb_taps(uint32_t M, uint32_t m, float As)
+{
+    const uint32_t N = 2 * M * m + 1;          // designed length; the bank uses N-1 taps
+    const double fc = 0.5 / (double)M;
+    const double beta = kaiser_beta(As), ib = bessel_i0(beta);
+    const double pi = 3.14159265358979323846;
+    std::vector<float> h((size_t)M * 2 * m);
+    for (uint32_t i = 0; i < N - 1; i++) {
+        double t = (double)i - 0.5 * (double)(N - 1);
+        double x = 2.0 * fc * t;
+        // liquid's sincf uses a cosine product below |x| < 0.01 (exact to ~1e-10 there)
+        double sinc = std::fabs(x) < 0.01
+                          ? std::cos(pi * x / 2) * std::cos(pi * x / 4) * std::cos(pi * x / 8)
+                          : std::sin(pi * x) / (pi * x);
+        double r = 2.0 * t / (double)(N - 1);
+        double a = 1.0 - r * r;
+        double w = bessel_i0(beta * std::sqrt(a > 0 ? a : 0)) / ib;
+        h[i] = (float)(sinc * w);
+    }
+    return h;
+}
+
+uint32_t nco_freq_word(float freq)
+{
+    float p = (float)((double)freq * 0.159154943091895);   // freq / 2pi, rounded to f32
+    float fpart = p - (float)((long)p);
+    if (fpart < 0.0f) fpart += 1.0f;
+    return (uint32_t)(fpart * (float)0xffffffffu);
+}
+
+float pfb_premix_freq(uint32_t M)
+{
+    // evaluated left to right in binary32 like the Haskell expression
+    float n = (float)M;
+    float a = -0.5f * (n - 1.0f);
+    a = a / n;
+    a = a * 2.0f;
+    a = a * (float)3.14159265358979323846;
+    return a;
+}
+
+void nco_phasor(uint32_t theta, float *c, float *s)
+{
+    // nco_crcf_get_phase(): 2*pi*theta/2^32 with theta converted to f32 first
+    float ph = (float)(2.0 * 3.14159265358979323846 * (double)(float)theta / 4294967296.0);
+    *c = cosf(ph);
+    *s = sinf(ph);
+}
+
+uint32_t nco_period(uint32_t d_theta, uint32_t limit)
+{
+    if (d_theta == 0) return 1;
+    // period = 2^32 / gcd(d_theta, 2^32) = 2^(32 - ctz(d_theta))
+    int tz = __builtin_ctz(d_theta);
+    uint64_t per = 1ull << (32 - tz);
+    return per <= limit ? (uint32_t)per : 0;
+}
+
+float agc_gain_threshold(float thr_db)
+{
+    // rssi(g) = (float)(-20*log10((double)g)) is non-increasing in g.  Find the smallest
+    // positive f32 g with rssi(g) <= thr by bisection on the f32 bit pattern.
+    auto exceeded = [&](float g) { return (float)(-20.0 * std::log10((double)g)) > thr_db; };
+    uint32_t lo = 0x00800000u;     // smallest normal: rssi ~ +758 dB -> exceeded
+    uint32_t hi = 0x7f7fffffu;     // FLT_MAX: rssi ~ -770 dB
+    float flo, fhi;
+    memcpy(&flo, &lo, 4); memcpy(&fhi, &hi, 4);
+    if (!exceeded(flo)) return 0.0f;                 // never exceeded
+    if (exceeded(fhi)) return INFINITY;              // always exceeded
+    while (hi - lo > 1) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        float fm; memcpy(&fm, &mid, 4);
+        if (exceeded(fm)) lo = mid; else hi = mid;
+    }
+    memcpy(&fhi, &hi, 4);
+    return fhi;
+}
+
+}  // namespace csdr

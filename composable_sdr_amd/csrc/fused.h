@@ -1,0 +1,31 @@
+// Interface between the C ABI (capi.hip) and the fused channelizer kernels
+// (kernels_fused.hip).  Product code.
+#pragma once
+#include "csdr_internal.h"
+
+namespace csdr {
+
+struct FusedConfig {
+    uint32_t M, p, C, c0, max_nf;
+    bool dc_block; DcParams dc;
+    bool fm; float fm_ref;
+    bool mix;
+    const float *taps;       // host, M*p
+    uint32_t d_theta;
+};
+
+struct FusedCall {
+    const float2 *d_in;      // nf*M new samples
+    void *d_out;             // [C][nf] CF32 / F32, or [nf] when mixing
+    uint32_t nf;
+    uint32_t theta0;         // NCO phase of the first sample
+};
+
+bool fused_supported(uint32_t M, uint32_t p);
+int  fused_create(const FusedConfig &cfg, FusedPlan **out);
+int  fused_reset(FusedPlan *plan, hipStream_t s);
+int  fused_process(FusedPlan *plan, const FusedCall &call, hipStream_t s);
+const char *fused_name(const FusedPlan *plan);
+void fused_destroy(FusedPlan *plan);
+
+}  // namespace csdr

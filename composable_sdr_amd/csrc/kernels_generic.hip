@@ -1,0 +1,419 @@
+// Generic (any channel count M, any chunk length) HIP kernels for gfx950.
+// One kernel per stage of the reference's chain; used for M that the fused kernels
+// do not cover, for the standalone Pipes (dcBlocker, mixDown/mixUp, AGC, freqdem)
+// and for the sequential AGC tail.  Wave = 64 lanes throughout.
+#include "csdr_internal.h"
+
+namespace csdr {
+
+// ---------------------------------------------------------------------------
+// DC blocker (iirfilt_crcf dc_blocker; Liquid.chs:575-589) as a 3-kernel chained
+// scan of the linear recurrence  v[n] = x[n] + beta*v[n-1],  y[n] = v[n] - v[n-1].
+//   k_dc_aggregate : per block of DC_BLOCK samples, A_b = sum beta^(B-1-i) x[i]
+//   k_dc_carry     : one workgroup scans the block carries c_{b+1} = beta^B c_b + A_b
+//   k_dc_apply     : re-runs the recurrence inside each block from its carry, in the
+//                    reference's operation order (v0 = x - a1*v1 ; y = v0 - v1),
+//                    then optionally applies the NCO mix and stores.
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float2 cmadd(float2 a, float s, float2 b)  // a*s + b
+{
+    return make_float2(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y));
+}
+
+// inclusive Hillis-Steele scan over the 256 per-thread aggregates held in LDS with
+// the decaying weight beta^(DC_PER_THREAD*d) per hop of distance d.
+__device__ __forceinline__ float2 block_scan_decay(float2 mine, float2 *sh, const DcParams &dc)
+{
+    const int q = threadIdx.x;
+    sh[q] = mine;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const int d = 1 << s;
+        float2 other = make_float2(0.f, 0.f);
+        if (q >= d) other = sh[q - d];
+        __syncthreads();
+        mine = cmadd(other, dc.beta_pow_thr[s], mine);
+        sh[q] = mine;
+        __syncthreads();
+    }
+    return mine;
+}
+
+__global__ __launch_bounds__(DC_THREADS) void k_dc_aggregate(const float2 *__restrict__ x, uint32_t n,
+                                                             DcParams dc, float2 *__restrict__ agg)
+{
+    __shared__ float2 sh[DC_THREADS];
+    const uint32_t base = blockIdx.x * DC_BLOCK + threadIdx.x * DC_PER_THREAD;
+    float2 a = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < DC_PER_THREAD; i++) {
+        float2 xi = (base + i < n) ? x[base + i] : make_float2(0.f, 0.f);
+        a = cmadd(a, dc.beta, xi);
+    }
+    float2 s = block_scan_decay(a, sh, dc);
+    if (threadIdx.x == DC_THREADS - 1) agg[blockIdx.x] = s;
+}
+
+// carries[b] = v just before block b (b = 0 .. nb-1).  Single workgroup.
+__global__ __launch_bounds__(256) void k_dc_carry(const float2 *__restrict__ agg, uint32_t nb,
+                                                  DcParams dc, const float2 *__restrict__ state,
+                                                  float2 *__restrict__ carries)
+{
+    __shared__ double shr[256], shi[256];
+    const int q = threadIdx.x;
+    const uint32_t K = (nb + 255) / 256;          // blocks per thread
+    const uint32_t b0 = q * K;
+    // local aggregate of my K blocks
+    double ar = 0.0, ai = 0.0;
+    for (uint32_t i = 0; i < K; i++) {
+        uint32_t b = b0 + i;
+        float2 A = (b < nb) ? agg[b] : make_float2(0.f, 0.f);
+        ar = ar * dc.beta_blk + A.x;
+        ai = ai * dc.beta_blk + A.y;
+    }
+    // inclusive scan across threads, hop weight beta_blk^(K*d)
+    shr[q] = ar; shi[q] = ai;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        double orr = 0.0, oi = 0.0;
+        if (q >= d) { orr = shr[q - d]; oi = shi[q - d]; }
+        __syncthreads();
+        double w = pow(dc.beta_blk, (double)K * (double)d);
+        ar += w * orr; ai += w * oi;
+        shr[q] = ar; shi[q] = ai;
+        __syncthreads();
+    }
+    // exclusive prefix of my range + the stream state decayed to my start
+    double er = (q > 0) ? shr[q - 1] : 0.0, ei = (q > 0) ? shi[q - 1] : 0.0;
+    const float2 st = state[0];
+    double w0 = pow(dc.beta_blk, (double)b0);
+    double cr = er + w0 * st.x, ci = ei + w0 * st.y;
+    for (uint32_t i = 0; i < K; i++) {
+        uint32_t b = b0 + i;
+        if (b >= nb) break;
+        carries[b] = make_float2((float)cr, (float)ci);
+        float2 A = agg[b];
+        cr = cr * dc.beta_blk + A.x;
+        ci = ci * dc.beta_blk + A.y;
+    }
+}
+
+__device__ __forceinline__ float2 nco_rotate(float2 v, uint32_t idx, const NcoParams &nco,
+                                             const float2 *__restrict__ tab)
+{
+    float c, s;
+    if (nco.tab_len) {
+        float2 cs = tab[(nco.tab_pos + idx) % nco.tab_len];
+        c = cs.x; s = cs.y;
+    } else {
+        uint32_t theta = nco.theta0 + idx * nco.d_theta;
+        float ph = (float)(6.283185307179586 * (double)(float)theta / 4294967296.0);
+        sincosf(ph, &s, &c);
+    }
+    if (!nco.up) s = -s;                            // multiply by conj(v)
+    return make_float2(v.x * c - v.y * s, v.x * s + v.y * c);
+}
+
+__global__ __launch_bounds__(DC_THREADS) void k_dc_apply(const float2 *__restrict__ x, float2 *__restrict__ y,
+                                                         uint32_t n, int do_dc, DcParams dc,
+                                                         const float2 *__restrict__ carries,
+                                                         float2 *__restrict__ state_out, int do_mix,
+                                                         NcoParams nco, const float2 *__restrict__ tab)
+{
+    __shared__ float2 sh[DC_THREADS];
+    const int q = threadIdx.x;
+    const uint32_t base = blockIdx.x * DC_BLOCK + q * DC_PER_THREAD;
+    float2 xs[DC_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < DC_PER_THREAD; i++)
+        xs[i] = (base + i < n) ? x[base + i] : make_float2(0.f, 0.f);
+
+    float2 v1 = make_float2(0.f, 0.f);
+    if (do_dc) {
+        float2 a = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < DC_PER_THREAD; i++) a = cmadd(a, dc.beta, xs[i]);
+        float2 incl = block_scan_decay(a, sh, dc);
+        (void)incl;
+        float2 excl = (q > 0) ? sh[q - 1] : make_float2(0.f, 0.f);
+        // carry decayed to my first sample: beta^(DC_PER_THREAD*q)
+        float w = (float)pow((double)dc.beta, (double)(DC_PER_THREAD * q));
+        const float2 c = carries[blockIdx.x];
+        v1 = cmadd(c, w, excl);
+    }
+#pragma unroll
+    for (int i = 0; i < DC_PER_THREAD; i++) {
+        if (base + i >= n) break;
+        float2 o = xs[i];
+        if (do_dc) {
+            // iirfilt_crcf_execute_norm: v0 = x - a1*v1 ; y = v0 - v1
+            float2 v0 = make_float2(__fsub_rn(xs[i].x, __fmul_rn(dc.a1, v1.x)),
+                                    __fsub_rn(xs[i].y, __fmul_rn(dc.a1, v1.y)));
+            o = make_float2(v0.x - v1.x, v0.y - v1.y);
+            v1 = v0;
+            if (base + i == n - 1) state_out[0] = v0;
+        }
+        if (do_mix) o = nco_rotate(o, base + i, nco, tab);
+        y[base + i] = o;
+    }
+}
+
+int launch_dc_mix(const float2 *x, float2 *y, uint32_t n, bool do_dc, const DcParams &dc,
+                  float2 *state, float2 *scratch, bool do_mix, const NcoParams &nco,
+                  const float2 *nco_tab, hipStream_t s)
+{
+    if (n == 0) return 0;
+    const uint32_t nb = (n + DC_BLOCK - 1) / DC_BLOCK;
+    float2 *agg = scratch, *carries = scratch + nb;
+    if (do_dc) {
+        hipLaunchKernelGGL(k_dc_aggregate, dim3(nb), dim3(DC_THREADS), 0, s, x, n, dc, agg);
+        hipLaunchKernelGGL(k_dc_carry, dim3(1), dim3(256), 0, s, agg, nb, dc, state, carries);
+    }
+    hipLaunchKernelGGL(k_dc_apply, dim3(nb), dim3(DC_THREADS), 0, s, x, y, n, (int)do_dc, dc, carries,
+                       state, (int)do_mix, nco, nco_tab);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Polyphase branch filters (firpfbch_crcf analyzer_push + dotprod; Liquid.chs:843).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pfb_fir(const float2 *__restrict__ u, const float *__restrict__ taps,
+                                                 float2 *__restrict__ X, uint32_t M, uint32_t p, uint64_t total)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const uint32_t j = (uint32_t)(gid % M);
+    const int64_t t = (int64_t)(gid / M);
+    float2 acc = make_float2(0.f, 0.f);
+    // oldest sample first, as dotprod_crcf walks the window
+    for (int nn = (int)p - 1; nn >= 0; nn--) {
+        const float h = taps[(M - 1 - j) + (uint32_t)nn * M];
+        const float2 v = u[(t - nn) * (int64_t)M + j];
+        acc.x = fmaf(h, v.x, acc.x);
+        acc.y = fmaf(h, v.y, acc.y);
+    }
+    X[gid] = acc;
+}
+
+int launch_pfb_fir(const float2 *u, const float *taps, float2 *X, uint32_t M, uint32_t p, uint32_t nf,
+                   hipStream_t s)
+{
+    const uint64_t total = (uint64_t)M * nf;
+    if (!total) return 0;
+    hipLaunchKernelGGL(k_pfb_fir, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, u, taps, X, M, p, total);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Forward DFT per frame.  Power-of-two M: in-LDS radix-2 (one workgroup per frame);
+// other M: direct O(M^2) sum (small channel counts such as README Example 3's 20).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fft_pow2(const float2 *__restrict__ X, float2 *__restrict__ Y,
+                                                  const float2 *__restrict__ tw, uint32_t M, uint32_t lg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float2 *a = reinterpret_cast<float2 *>(smem_raw);
+    const float2 *src = X + (uint64_t)blockIdx.x * M;
+    for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) {
+        uint32_t r = __brev(i) >> (32 - lg);
+        a[r] = src[i];
+    }
+    __syncthreads();
+    for (uint32_t len = 2; len <= M; len <<= 1) {
+        const uint32_t half = len >> 1, step = M / len;
+        for (uint32_t b = threadIdx.x; b < M / 2; b += blockDim.x) {
+            const uint32_t k = b % half, s0 = (b / half) * len;
+            const float2 w = tw[k * step];
+            const float2 lo = a[s0 + k], hi = a[s0 + k + half];
+            const float2 tt = make_float2(hi.x * w.x - hi.y * w.y, hi.x * w.y + hi.y * w.x);
+            a[s0 + k] = make_float2(lo.x + tt.x, lo.y + tt.y);
+            a[s0 + k + half] = make_float2(lo.x - tt.x, lo.y - tt.y);
+        }
+        __syncthreads();
+    }
+    float2 *dst = Y + (uint64_t)blockIdx.x * M;
+    for (uint32_t i = threadIdx.x; i < M; i += blockDim.x) dst[i] = a[i];
+}
+
+__global__ __launch_bounds__(256) void k_dft_direct(const float2 *__restrict__ X, float2 *__restrict__ Y,
+                                                    const float2 *__restrict__ tw, uint32_t M, uint64_t total)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const uint32_t k = (uint32_t)(gid % M);
+    const float2 *src = X + (gid / M) * M;
+    float sr = 0.f, si = 0.f;
+    uint32_t idx = 0;
+    for (uint32_t j = 0; j < M; j++) {
+        const float2 w = tw[idx], v = src[j];
+        sr += v.x * w.x - v.y * w.y;
+        si += v.x * w.y + v.y * w.x;
+        idx += k; if (idx >= M) idx -= M;
+    }
+    Y[gid] = make_float2(sr, si);
+}
+
+int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s)
+{
+    if (!nf) return 0;
+    if (M == 1) {
+        CSDR_HIP(hipMemcpyAsync(Y, X, sizeof(float2) * nf, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    if ((M & (M - 1)) == 0 && M <= 8192) {
+        uint32_t lg = 0; while ((1u << lg) < M) lg++;
+        unsigned th = M / 2 < 64 ? 64 : (M / 2 > 256 ? 256 : M / 2);
+        hipLaunchKernelGGL(k_fft_pow2, dim3(nf), dim3(th), M * sizeof(float2), s, X, Y, tw, M, lg);
+    } else {
+        const uint64_t total = (uint64_t)M * nf;
+        hipLaunchKernelGGL(k_dft_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, Y, tw, M, total);
+    }
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// [nf][M] -> channel-major [C][nf]  (the transpose of Liquid.chs:840-844)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose(const float2 *__restrict__ Y, float2 *__restrict__ Z,
+                                                   uint32_t M, uint32_t nf, uint32_t c0, uint32_t C)
+{
+    __shared__ float2 tile[32][33];
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const uint32_t cb = blockIdx.x * 32, tb = blockIdx.y * 32;
+    for (uint32_t r = ty; r < 32; r += 8) {
+        uint32_t t = tb + r, c = cb + tx;
+        if (t < nf && c < C) tile[r][tx] = Y[(uint64_t)t * M + c0 + c];
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < 32; r += 8) {
+        uint32_t c = cb + r, t = tb + tx;
+        if (t < nf && c < C) Z[(uint64_t)c * nf + t] = tile[tx][r];
+    }
+}
+
+int launch_transpose(const float2 *Y, float2 *Z, uint32_t M, uint32_t nf, uint32_t c0, uint32_t C, hipStream_t s)
+{
+    if (!nf || !C) return 0;
+    hipLaunchKernelGGL(k_transpose, dim3((C + 31) / 32, (nf + 31) / 32), dim3(256), 0, s, Y, Z, M, nf, c0, C);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// agc_crcf + squelch, one lane per channel walking its samples in order
+// (agcExecuteBlock, Liquid.chs:695-705).  Exactly sequential per channel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_agc_init(AgcState *st, uint32_t C)
+{
+    uint32_t c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    // agcCreate (Liquid.chs:707-717): signal level 1e-3 -> g = 1000, y2' = 1, squelch ENABLED
+    st[c].g = 1.0f / 1e-3f; st[c].y2 = 1.0f; st[c].mode = 1; st[c].timer = 1000u;
+}
+
+int launch_agc_init(AgcState *st, uint32_t C, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_agc_init, dim3((C + 63) / 64), dim3(64), 0, s, st, C);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+__device__ __forceinline__ float2 agc_step(float2 x, AgcState &q, const AgcParams &p)
+{
+    float2 y = make_float2(x.x * q.g, x.y * q.g);
+    const float y2 = __fadd_rn(__fmul_rn(y.x, y.x), __fmul_rn(y.y, y.y));
+    // (1.0 - alpha)*y2' + alpha*y2 : evaluated in f64 like the C expression
+    q.y2 = (float)((1.0 - (double)p.alpha) * (double)q.y2 + (double)__fmul_rn(p.alpha, y2));
+    if (q.y2 > 1e-6f) q.g *= expf(-0.5f * p.alpha * logf(q.y2));
+    if (q.g > 1e6f) q.g = 1e6f;
+    const bool ex = q.g < p.g_thr;                    // rssi > threshold
+    switch (q.mode) {
+    case 1: q.mode = ex ? 2 : 1; break;               // ENABLED
+    case 2: q.mode = ex ? 3 : 4; break;               // RISE
+    case 3: q.mode = ex ? 3 : 4; break;               // SIGNALHI
+    case 4: q.mode = ex ? 3 : 5; q.timer = p.timeout; break;   // FALL
+    case 5:                                           // SIGNALLO
+        q.timer--;
+        if (q.timer == 0) q.mode = 6; else if (ex) q.mode = 3;
+        break;
+    case 6: q.mode = 1; break;                        // TIMEOUT
+    default: break;
+    }
+    if (q.mode != 3) y = make_float2(0.f, 0.f);       // reference mute rule (Liquid.chs:703-704)
+    return y;
+}
+
+__global__ __launch_bounds__(64) void k_agc(float2 *__restrict__ Z, uint32_t C, uint32_t nf,
+                                            AgcState *__restrict__ st, AgcParams p)
+{
+    const uint32_t c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    AgcState q = st[c];
+    float2 *row = Z + (uint64_t)c * nf;
+    for (uint32_t t = 0; t < nf; t++) row[t] = agc_step(row[t], q, p);
+    st[c] = q;
+}
+
+int launch_agc(float2 *Z, uint32_t C, uint32_t nf, AgcState *st, const AgcParams &p, hipStream_t s)
+{
+    if (!nf || !C) return 0;
+    hipLaunchKernelGGL(k_agc, dim3((C + 63) / 64), dim3(64), 0, s, Z, C, nf, st, p);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// freqdem (Liquid.chs:303-334): m = arg(conj(r') r) / (2 pi kf)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fm(const float2 *__restrict__ Z, float *__restrict__ F, uint32_t nf,
+                                            uint64_t total, float ref, const float2 *__restrict__ rp_in,
+                                            float2 *__restrict__ rp_out)
+{
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const uint32_t t = (uint32_t)(gid % nf);
+    const uint32_t c = (uint32_t)(gid / nf);
+    const float2 r = Z[gid];
+    const float2 rp = t ? Z[gid - 1] : rp_in[c];
+    const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
+    const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
+    F[gid] = atan2f(im, re) * ref;
+    if (t == nf - 1) rp_out[c] = r;
+}
+
+int launch_fm(const float2 *Z, float *F, uint32_t C, uint32_t nf, float ref, const float2 *rp_in,
+              float2 *rp_out, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)C * nf;
+    if (!total) return 0;
+    hipLaunchKernelGGL(k_fm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Z, F, nf, total, ref, rp_in, rp_out);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// mix (Trans.hs:119-122): strict left fold over the channel list
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mix(const float *__restrict__ in, float *__restrict__ out, uint32_t C, uint32_t E)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= E) return;
+    float acc = in[i];
+    for (uint32_t c = 1; c < C; c++) acc = __fadd_rn(acc, in[(uint64_t)c * E + i]);
+    out[i] = acc;
+}
+
+int launch_mix(const float *in, float *out, uint32_t C, uint32_t E, hipStream_t s)
+{
+    if (!E) return 0;
+    hipLaunchKernelGGL(k_mix, dim3((E + 255) / 256), dim3(256), 0, s, in, out, C, E);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace csdr

@@ -1,0 +1,255 @@
+"""Host-side mirror of the reference's DSP blocks (src/ComposableSDR/Liquid.chs) and of
+the Pipe protocol (src/ComposableSDR/Types.hs:51-55, 93-131) over the C ABI.
+
+A Pipe is (start, process, done); `start` creates the native object, `process` maps one
+array to one array, `done` destroys it -- exactly the life-cycle addPipe/unPipe drive.
+Names follow the reference: dcBlocker, mixDown, mixUp, automaticGainControl,
+fmDemodulator, firpfbchChannelizer.  `Chain` is the fused replacement for
+`mix . mux (replicate nch demod) . firpfbchChannelizer nc` (apps/SoapySDR.hs:218-225).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import CsdrError, check, lib, DEMOD_FM, DEMOD_NONE
+
+
+def _c64(x):
+    return np.ascontiguousarray(x, dtype=np.complex64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Pipe:
+    """Pipe {_start, _process, _done} (Types.hs:51-55)."""
+
+    def __init__(self, start, process, done):
+        self._start, self._process, self._done = start, process, done
+
+    # Category instance: (.) = compose (Types.hs:101-103); `self . other` runs other first
+    def __matmul__(self, other):
+        return compose(self, other)
+
+
+def compose(p1, p2):
+    """compose (Types.hs:93-99): process = process2 >=> process1; done2 before done1."""
+    def start():
+        return (p1._start(), p2._start())
+
+    def process(r, a):
+        return p1._process(r[0], p2._process(r[1], a))
+
+    def done(r):
+        p2._done(r[1])
+        p1._done(r[0])
+    return Pipe(start, process, done)
+
+
+class _Handle:
+    """Owns one native handle; destroy is idempotent."""
+
+    def __init__(self, h, destroy):
+        self.h, self._destroy = h, destroy
+
+    def close(self):
+        if self.h:
+            check(self._destroy(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def dcBlocker(alpha=0.0005, max_samples=1 << 20):
+    """dcBlocker (Liquid.chs:575-589): iirfilt_crcf_create_dc_blocker(0.0005)."""
+    def start():
+        h = C.c_void_p()
+        check(lib().csdr_dcblock_create(alpha, max_samples, C.byref(h)))
+        return _Handle(h, lib().csdr_dcblock_destroy)
+
+    def process(r, a):
+        x = _c64(a)
+        y = np.empty_like(x)
+        check(lib().csdr_dcblock_process(r.h, _ptr(x), x.size, _ptr(y)))
+        return y
+    return Pipe(start, process, lambda r: r.close())
+
+
+def _mixer(f, up, max_samples):
+    def start():
+        h = C.c_void_p()
+        check(lib().csdr_nco_create(f, max_samples, C.byref(h)))
+        return _Handle(h, lib().csdr_nco_destroy)
+
+    def process(r, a):
+        x = _c64(a)
+        y = np.empty_like(x)
+        fn = lib().csdr_nco_mix_up if up else lib().csdr_nco_mix_down
+        check(fn(r.h, _ptr(x), x.size, _ptr(y)))
+        return y
+    return Pipe(start, process, lambda r: r.close())
+
+
+def mixDown(f, max_samples=1 << 20):
+    """mixDown f (Liquid.chs:798-799): y = x * conj(nco)."""
+    return _mixer(f, False, max_samples)
+
+
+def mixUp(f, max_samples=1 << 20):
+    """mixUp f (Liquid.chs:808-809): y = x * nco."""
+    return _mixer(f, True, max_samples)
+
+
+def automaticGainControl(tres, nchan=1, max_samples=4096):
+    """automaticGainControl tres (Liquid.chs:727-728); nchan independent instances, input
+    and output channel-major [nchan][n] (1-D arrays are treated as one channel)."""
+    def start():
+        h = C.c_void_p()
+        check(lib().csdr_agc_create(tres, nchan, max_samples, C.byref(h)))
+        return _Handle(h, lib().csdr_agc_destroy)
+
+    def process(r, a):
+        x = _c64(a)
+        n = x.size // nchan
+        y = np.empty_like(x)
+        check(lib().csdr_agc_process(r.h, _ptr(x), n, _ptr(y)))
+        return y
+    return Pipe(start, process, lambda r: r.close())
+
+
+def fmDemodulator(kf, nchan=1, max_samples=4096):
+    """fmDemodulator kf (Liquid.chs:333-334)."""
+    def start():
+        h = C.c_void_p()
+        check(lib().csdr_freqdem_create(kf, nchan, max_samples, C.byref(h)))
+        return _Handle(h, lib().csdr_freqdem_destroy)
+
+    def process(r, a):
+        x = _c64(a)
+        n = x.size // nchan
+        m = np.empty(x.shape, dtype=np.float32)
+        check(lib().csdr_freqdem_process(r.h, _ptr(x), n, _ptr(m)))
+        return m
+    return Pipe(start, process, lambda r: r.close())
+
+
+@dataclass
+class ChainConfig:
+    channels: int = 1
+    dc_block: bool = True
+    dc_alpha: float = 0.0005
+    agc: float = 0.0            # -a; 0 = off
+    demod: str = "none"         # "none" (DeNo) | "fm" (DeNBFM kf)
+    kf: float = 0.3
+    mix: bool = False
+    chan_first: int = 0
+    chan_count: int = 0
+    device: int = -1
+    max_frames: int = 4096
+    flags: int = _lib.FLAG_QUIET
+    pfb_m: int = 7
+    pfb_as: float = 80.0
+
+
+class Chain:
+    """The fused chain object behind `csdr_chain_*`."""
+
+    def __init__(self, cfg: ChainConfig = None, **kw):
+        cfg = cfg or ChainConfig(**kw)
+        self.cfg = cfg
+        c = _lib.ChainCfg()
+        lib().csdr_chain_cfg_default(C.byref(c), cfg.channels)
+        c.channels = cfg.channels
+        c.dc_block, c.dc_alpha = int(cfg.dc_block), cfg.dc_alpha
+        c.agc_threshold_db = cfg.agc
+        c.demod = {"none": DEMOD_NONE, "fm": DEMOD_FM}[cfg.demod]
+        c.kf, c.mix = cfg.kf, int(cfg.mix)
+        c.chan_first, c.chan_count = cfg.chan_first, cfg.chan_count
+        c.device, c.max_frames, c.flags = cfg.device, cfg.max_frames, cfg.flags
+        c.pfb_m, c.pfb_as = cfg.pfb_m, cfg.pfb_as
+        h = C.c_void_p()
+        check(lib().csdr_chain_create(C.byref(c), C.byref(h)))
+        self._h = _Handle(h, lib().csdr_chain_destroy)
+        self.M = cfg.channels
+        self.C = cfg.chan_count or (cfg.channels - cfg.chan_first)
+        self.mixed = bool(cfg.mix) and self.M > 1
+        self.out_dtype = np.float32 if cfg.demod == "fm" else np.complex64
+
+    @property
+    def h(self):
+        if not self._h.h:
+            raise CsdrError(_lib.ERR_INVALID, "chain already destroyed")
+        return self._h.h
+
+    @property
+    def path(self):
+        return lib().csdr_chain_path(self.h).decode()
+
+    @property
+    def taps(self):
+        n = self.M * 2 * self.cfg.pfb_m
+        t = np.zeros(n, dtype=np.float32)
+        got = lib().csdr_chain_get_taps(self.h, _ptr(t), n)
+        return t[:max(got, 0)]
+
+    @property
+    def nco(self):
+        th, d = C.c_uint32(), C.c_uint32()
+        check(lib().csdr_chain_get_nco(self.h, C.byref(th), C.byref(d)))
+        return th.value, d.value
+
+    def out_shape(self, n_in):
+        nf = n_in // self.M
+        return (nf,) if self.mixed else (self.C, nf)
+
+    def process(self, x):
+        """One compacted chunk (host arrays) -> channel-major [C][nf] (or [nf] when mixing)."""
+        x = _c64(x)
+        out = np.empty(self.out_shape(x.size), dtype=self.out_dtype)
+        n_out = C.c_uint32()
+        check(lib().csdr_chain_process(self.h, _ptr(x), x.size, _ptr(out), C.byref(n_out)))
+        if x.size == 0:
+            return out
+        assert n_out.value == out.size, (n_out.value, out.size)
+        return out
+
+    def process_device(self, d_in_ptr, n_in, d_out_ptr, stream=0):
+        """Device-resident variant: raw device pointers (ints), enqueues on `stream`."""
+        n_out = C.c_uint32()
+        check(lib().csdr_chain_process_device(self.h, C.c_void_p(d_in_ptr), n_in, C.c_void_p(d_out_ptr),
+                                              C.byref(n_out), C.c_void_p(stream)))
+        return n_out.value
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_uint32()
+        name = lib().csdr_chain_kernel_time(self.h, C.byref(ms), C.byref(n))
+        return name.decode(), ms.value, n.value
+
+    def reset(self):
+        check(lib().csdr_chain_reset(self.h))
+
+    def close(self):
+        self._h.close()
+
+
+def firpfbchChannelizer(n, **kw):
+    """firpfbchChannelizer n (Liquid.chs:864-866): Pipe IO (Array CF32) [Array CF32].
+    Output is the list of n per-channel arrays the reference produces by slicing one
+    channel-major buffer (Liquid.chs:850-862); an empty input yields [empty]."""
+    def start():
+        return Chain(ChainConfig(channels=n, dc_block=False, **kw))
+
+    def process(r, a):
+        x = _c64(a)
+        if x.size == 0:
+            return [np.empty(0, dtype=np.complex64)]
+        y = r.process(x)
+        return [y[k] for k in range(y.shape[0])]
+    return Pipe(start, process, lambda r: r.close())

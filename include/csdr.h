@@ -1,0 +1,169 @@
+/*
+ * csdr.h -- C ABI of the MI355X-native DSP chain that replaces the liquid-dsp
+ * FFI calls behind ComposableSDR's Pipe blocks.
+ *
+ * Every block of the reference is
+ *     Pipe { _start :: IO r, _process :: r -> Array a -> IO (Array b), _done :: r -> IO () }
+ * (/root/reference/src/ComposableSDR/Types.hs:51-55) whose three fields wrap a
+ * liquid-dsp  *_create / *_execute_block / *_destroy  triple.  Each object
+ * below exports the same triple at the same (chunk) granularity:
+ *     int csdr_X_create (..., csdr_X **out);      <- _start
+ *     int csdr_X_process(csdr_X *, in, n, out);   <- _process (one whole chunk)
+ *     int csdr_X_destroy(csdr_X *);               <- _done
+ * Conventions:
+ *   - return 0 on success, <0 on error (so the Haskell side can reuse
+ *     Common.hs:32-33 `try`); never exit(); csdr_last_error() gives the text.
+ *     liquid-dsp 1.3.2 aborts the process on a bad configuration instead.
+ *   - in/out buffers are caller-owned and only touched during the call; CF32 is
+ *     interleaved little-endian float32 (re, im) = Types.hs:82-88.
+ *   - handles are opaque, single-threaded, independent of each other; all
+ *     stream state (DC-blocker v1, NCO phase, filterbank windows, per-channel
+ *     AGC / freqdem state) lives in the handle, so results do not depend on how
+ *     the stream is chunked.
+ *   - *_process takes host pointers and blocks; *_process_device takes device
+ *     pointers (HBM-resident data) and enqueues on a hipStream_t without
+ *     synchronising.
+ * All compute runs in hand-written HIP kernels for gfx950.  There is no CPU
+ * fallback: with no usable GPU every create returns CSDR_ERR_NODEV.
+ */
+#ifndef CSDR_H
+#define CSDR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSDR_OK            0
+#define CSDR_ERR_INVALID  (-1)  /* bad argument / configuration                         */
+#define CSDR_ERR_HIP      (-2)  /* HIP runtime error (text in csdr_last_error)          */
+#define CSDR_ERR_NODEV    (-3)  /* no gfx950 device visible                              */
+#define CSDR_ERR_SIZE     (-4)  /* chunk length not a multiple of the channel count, or
+                                   larger than the handle was created for                */
+#define CSDR_ERR_NOMEM    (-5)
+
+#define CSDR_DEMOD_NONE 0u      /* DeNo: per-channel CF32 out (SoapySDR.hs:236-243)      */
+#define CSDR_DEMOD_FM   1u      /* DeNBFM kf: freqdem, F32 out (SoapySDR.hs:244-251)     */
+
+/* cfg.flags */
+#define CSDR_FLAG_TIME_KERNELS 1u   /* bracket the dominant kernel with hipEvents         */
+#define CSDR_FLAG_FORCE_GENERIC 2u  /* use the any-M multi-kernel path even where a fused
+                                       kernel exists (for A/B tests)                      */
+#define CSDR_FLAG_QUIET 4u          /* do not print the configuration at create           */
+
+const char *csdr_last_error(void);
+int  csdr_device_count(void);
+/* library / build identification: "csdr-hip gfx950 <version>" */
+const char *csdr_version(void);
+
+/* ------------------------------------------------------------------------ *
+ * dcBlocker  (Liquid.chs:575-589)
+ *   replaces iirfilt_crcf_create_dc_blocker / _execute_block / _destroy
+ *   (imports at Liquid.chs:550-567).  y = DC-blocked x, same length.
+ * ------------------------------------------------------------------------ */
+typedef struct csdr_dcblock csdr_dcblock;
+int csdr_dcblock_create(float alpha, uint32_t max_samples, csdr_dcblock **out);
+int csdr_dcblock_process(csdr_dcblock *h, const float *x_cf32, uint32_t n, float *y_cf32);
+int csdr_dcblock_process_device(csdr_dcblock *h, const void *d_x, uint32_t n, void *d_y, void *stream);
+int csdr_dcblock_destroy(csdr_dcblock *h);
+
+/* ------------------------------------------------------------------------ *
+ * mixDown / mixUp  (Liquid.chs:782-809)
+ *   replaces nco_crcf_create(LIQUID_VCO) + set_frequency + mix_block_down/up
+ *   + destroy (imports at Liquid.chs:746-780).  freq in rad/sample.
+ * ------------------------------------------------------------------------ */
+typedef struct csdr_nco csdr_nco;
+int csdr_nco_create(float freq, uint32_t max_samples, csdr_nco **out);
+int csdr_nco_mix_down(csdr_nco *h, const float *x_cf32, uint32_t n, float *y_cf32);
+int csdr_nco_mix_up(csdr_nco *h, const float *x_cf32, uint32_t n, float *y_cf32);
+int csdr_nco_get_words(const csdr_nco *h, uint32_t *theta, uint32_t *d_theta);
+int csdr_nco_destroy(csdr_nco *h);
+
+/* ------------------------------------------------------------------------ *
+ * automaticGainControl tres  (Liquid.chs:693-728), `nchan` independent
+ * instances as created by mux / distribute_ (Trans.hs:106-129).
+ *   replaces agc_crcf_create + set_bandwidth 0.1 + set_signal_level 1e-3 +
+ *   squelch_enable + squelch_set_threshold tres + squelch_set_timeout 1000,
+ *   and per sample execute_block(n=1) + squelch_get_status + get_rssi with the
+ *   reference's mute rule "status /= SIGNALHI => 0" (imports :660-691).
+ *   x, y are channel-major [nchan][n] CF32.
+ * ------------------------------------------------------------------------ */
+typedef struct csdr_agc csdr_agc;
+int csdr_agc_create(float threshold_db, uint32_t nchan, uint32_t max_samples, csdr_agc **out);
+int csdr_agc_process(csdr_agc *h, const float *x_cf32, uint32_t n, float *y_cf32);
+int csdr_agc_destroy(csdr_agc *h);
+
+/* ------------------------------------------------------------------------ *
+ * fmDemodulator kf  (Liquid.chs:303-334), `nchan` independent instances.
+ *   replaces freqdem_create / freqdem_demodulate_block / freqdem_destroy
+ *   (imports :305-315).  x is [nchan][n] CF32, m is [nchan][n] F32.
+ * ------------------------------------------------------------------------ */
+typedef struct csdr_freqdem csdr_freqdem;
+int csdr_freqdem_create(float kf, uint32_t nchan, uint32_t max_samples, csdr_freqdem **out);
+int csdr_freqdem_process(csdr_freqdem *h, const float *x_cf32, uint32_t n, float *m_f32);
+int csdr_freqdem_destroy(csdr_freqdem *h);
+
+/* ------------------------------------------------------------------------ *
+ * The fused chain: everything assembleFold (apps/SoapySDR.hs:208-226) puts
+ * behind `compact`:
+ *     dcBlocker                                   (SoapySDR.hs:213-214)
+ *  -> firpfbchChannelizer M  = NCO pre-mix + firpfbch_crcf analyzer +
+ *     transpose to channel-major                  (Liquid.chs:811-866)
+ *  -> per channel: [automaticGainControl] -> [fmDemodulator kf]
+ *                                                 (SoapySDR.hs:190-199, 249)
+ *  -> [mix]                                       (Trans.hs:119-122)
+ * replacing  mix . mux (replicate nch demod) . firpfbchChannelizer nc  and
+ * firpfbchChannelizer nc + distribute_ (addPipe demod sink)  (SoapySDR.hs:218-225).
+ * For channels == 1 it is  demod  alone behind the DC blocker (SoapySDR.hs:226).
+ *
+ * process(): in = n_in CF32 samples, n_in a multiple of `channels`
+ *   (the reference's chunk is 4*channels*1024, SoapySDR.hs:215; the reference
+ *   misbehaves for other remainders, SURVEY.md a6 -> CSDR_ERR_SIZE here).
+ *   out = ONE contiguous channel-major buffer [chan_count][nf], nf = n_in/channels,
+ *   element CF32 (demod none) or F32 (FM); with mix: [nf] only.  The caller
+ *   slices it into per-channel arrays exactly like Liquid.chs:850-862.
+ *   *n_out = number of output ELEMENTS written.  n_in == 0 is a no-op.
+ * ------------------------------------------------------------------------ */
+typedef struct csdr_chain csdr_chain;
+
+typedef struct csdr_chain_cfg {
+    uint32_t struct_size;       /* = sizeof(csdr_chain_cfg)                              */
+    uint32_t channels;          /* -c M, >= 1                                            */
+    uint32_t dc_block;          /* 1: include dcBlocker (assembleFold always does)       */
+    float    dc_alpha;          /* 0.0005 (Liquid.chs:577)                               */
+    float    agc_threshold_db;  /* -a tres; 0 = no AGC (SoapySDR.hs:195-198)             */
+    uint32_t demod;             /* CSDR_DEMOD_*                                          */
+    float    kf;                /* DeNBFM kf                                             */
+    uint32_t mix;               /* --mix                                                 */
+    uint32_t chan_first;        /* channel shard [chan_first, chan_first+chan_count)     */
+    uint32_t chan_count;        /*   0 = all channels                                    */
+    int32_t  device;            /* HIP device ordinal, -1 = current device               */
+    uint32_t max_frames;        /* largest n_in/channels per call; 0 = 4096              */
+    uint32_t flags;             /* CSDR_FLAG_*                                           */
+    uint32_t pfb_m;             /* filter semi-length m, 0 = 7  (Liquid.chs:813)         */
+    float    pfb_as;            /* stop-band attenuation, 0 = 80 dB (Liquid.chs:813)     */
+} csdr_chain_cfg;
+
+void csdr_chain_cfg_default(csdr_chain_cfg *cfg, uint32_t channels);
+int  csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out);
+int  csdr_chain_process(csdr_chain *h, const float *in_cf32, uint32_t n_in, void *out, uint32_t *n_out);
+int  csdr_chain_process_device(csdr_chain *h, const void *d_in_cf32, uint32_t n_in,
+                               void *d_out, uint32_t *n_out, void *stream);
+int  csdr_chain_reset(csdr_chain *h);      /* back to the state right after create        */
+int  csdr_chain_destroy(csdr_chain *h);
+
+/* introspection used by the tests (mirrors what firpfbch_crcf_print / nco_crcf_print
+ * show at Liquid.chs:814-820) */
+uint32_t csdr_chain_out_elem_size(const csdr_chain *h);            /* 8 or 4 bytes        */
+int  csdr_chain_get_taps(const csdr_chain *h, float *taps, uint32_t n); /* first M*2m taps */
+int  csdr_chain_get_nco(const csdr_chain *h, uint32_t *theta, uint32_t *d_theta);
+const char *csdr_chain_path(const csdr_chain *h);                  /* "fused-..." | "generic" */
+/* CSDR_FLAG_TIME_KERNELS: accumulated duration of the dominant kernel's launches
+ * since the last call (synchronises the stream).  Returns the kernel's name. */
+const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSDR_H */

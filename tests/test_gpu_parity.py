@@ -1,0 +1,263 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Tolerances (north_star: "within a stated float tolerance"):
+
+  PFB / chain CF32 outputs : rel-RMS <= 1e-5, max-abs <= 1e-4 * max|ref|
+      (f32 FIR with fused multiply-add + f32 FFT of log2(M) stages vs. the oracle's f32
+       dot products + f64 DFT: expected ~3e-7 rel-RMS)
+  DC blocker               : max-abs <= 4e-6 * max|x| / alpha-normalised state (see test)
+  FM outputs               : compared modulo 1/kf (the atan2 branch cut), on samples whose
+                             |conj(r')r| exceeds 1e-3 of the channel's RMS power; abs <= 2e-5
+  AGC                      : gain trajectory rel 1e-4; squelch decisions: mismatch count 0
+  mix                      : the HIP path folds channels in the reference's left-to-right
+                             order: same tolerance as the unmixed output times sqrt(M)
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from synth import synth_cf32
+from util import max_abs_err, rel_rms, wrap_pm
+
+pytestmark = pytest.mark.gpu
+
+cs = pytest.importorskip("composable_sdr_amd")
+
+
+def _run_pipe(pipe, chunks):
+    r = pipe._start()
+    try:
+        return [pipe._process(r, c) for c in chunks]
+    finally:
+        pipe._done(r)
+
+
+# --------------------------------------------------------------------------- standalone Pipes
+def test_dcblocker_matches_oracle_across_chunks():
+    x = synth_cf32(300000, 16, seed=3)
+    cuts = [0, 1, 1000, 1024, 5000, 150000, 150000, 300000]     # includes an empty chunk
+    chunks = [x[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    got = np.concatenate(_run_pipe(cs.dcBlocker(), chunks))
+    want = O.DcBlock(0.0005).execute(x)
+    err = max_abs_err(got, want)
+    print("dcblock max-abs err", err, "rel-rms", rel_rms(got, want))
+    # The filter state |v| sits at ~ DC/alpha = 28, whose f32 ulp is 1.9e-6: the reference's
+    # own sequential f32 recurrence carries that much rounding noise in y = v0 - v1, so
+    # agreement is bounded by a few ulp(|v|), and both must be equally close to f64 truth.
+    assert err < 8e-6
+    assert rel_rms(got, want) < 8e-6
+    v, truth = 0j, np.empty(x.size, dtype=np.complex128)
+    xd, beta = x.astype(np.complex128), float(np.float32(1) - np.float32(0.0005))
+    for i in range(x.size):
+        v0 = xd[i] + beta * v
+        truth[i] = v0 - v
+        v = v0
+    e_gpu, e_orc = rel_rms(got, truth), rel_rms(want, truth)
+    print("vs f64 truth: gpu", e_gpu, "oracle", e_orc)
+    assert e_gpu < 2 * e_orc + 1e-7
+
+
+@pytest.mark.parametrize("M", [20, 256])
+def test_nco_mix_matches_oracle(M):
+    f = O.pfb_offset(M)
+    x = synth_cf32(70000, M, seed=5)
+    chunks = [x[:12345], x[12345:40000], x[40000:]]
+    got = np.concatenate(_run_pipe(cs.mixDown(f), chunks))
+    want = O.Nco(f).mix_down(x)
+    print("nco down", M, max_abs_err(got, want))
+    assert max_abs_err(got, want) < 1e-6
+    got = np.concatenate(_run_pipe(cs.mixUp(0.123), chunks))
+    want = O.Nco(0.123).mix_up(x)
+    assert max_abs_err(got, want) < 1e-6
+
+
+def test_freqdem_matches_oracle():
+    nchan, n = 5, 3000
+    rng = np.random.default_rng(2)
+    z = (rng.standard_normal((nchan, n)) + 1j * rng.standard_normal((nchan, n))).astype(np.complex64)
+    z[1, 100:200] = 0                                   # squelched stretch: arg(0) paths
+    kf = 0.3
+    pipe = cs.fmDemodulator(kf, nchan=nchan, max_samples=n)
+    parts = _run_pipe(pipe, [z[:, :1000].copy(), z[:, 1000:].copy()])
+    got = np.concatenate(parts, axis=1)
+    want = np.stack([O.FreqDem(kf).demodulate_block(z[k]) for k in range(nchan)])
+    d = wrap_pm(got.astype(np.float64) - want, 1.0 / kf)
+    print("freqdem max err", np.abs(d).max())
+    assert np.abs(d).max() < 2e-6
+    assert np.array_equal(got[1, 101:200], want[1, 101:200])    # exact zeros in, exact out
+
+
+def test_agc_matches_oracle_and_squelch_decisions():
+    nchan, n = 6, 6000
+    rng = np.random.default_rng(4)
+    amp = np.array([1e-3, 3e-3, 1e-2, 3e-2, 0.1, 1.0])[:, None]
+    z = amp * (rng.standard_normal((nchan, n)) + 1j * rng.standard_normal((nchan, n))) / np.sqrt(2)
+    z[2, 3000:] *= 1e-3                                   # level drop: FALL/SIGNALLO/TIMEOUT path
+    z = z.astype(np.complex64)
+    thr = -35.0                                           # between the 3e-3 and 1e-2 channels (x sqrt2 noise)
+    pipe = cs.automaticGainControl(thr, nchan=nchan, max_samples=n)
+    parts = _run_pipe(pipe, [z[:, :2500].copy(), z[:, 2500:].copy()])
+    got = np.concatenate(parts, axis=1)
+    want = np.stack([O.Agc(thr).execute_block(z[k]) for k in range(nchan)])
+    muted_got, muted_want = got == 0, want == 0
+    mism = int(np.sum(muted_got != muted_want))
+    print("agc squelch mismatches", mism, "open fraction", 1 - muted_want.mean())
+    assert mism == 0
+    assert 0.2 < 1 - muted_want.mean() < 0.9             # both regimes are exercised
+    op = ~muted_want
+    rel = np.abs(got[op] - want[op]) / (np.abs(want[op]) + 1e-12)
+    print("agc rel err max", rel.max())
+    assert rel.max() < 1e-4
+
+
+# --------------------------------------------------------------------------- the chain
+def _chain_case(M, nfs, **kw):
+    total = sum(nfs) * M
+    x = synth_cf32(total, M, seed=100 + M)
+    ch = cs.Chain(channels=M, max_frames=max(max(nfs), 1), **kw)
+    orc = O.Chain(M, dc_block=kw.get("dc_block", True), agc_db=kw.get("agc", 0.0),
+                  demod=kw.get("demod", "none"), kf=kw.get("kf", 0.3), mix=kw.get("mix", False))
+    got, want, pos = [], [], 0
+    for nf in nfs:
+        c = x[pos:pos + nf * M]
+        pos += nf * M
+        got.append(ch.process(c))
+        want.append(orc.process(c))
+    path = ch.path
+    ch.close()
+    ax = 0 if kw.get("mix", False) and M > 1 else 1
+    return np.concatenate(got, axis=ax), np.concatenate(want, axis=ax), path
+
+
+@pytest.mark.parametrize("M", [2, 4, 20, 64, 256])
+def test_chain_deno_matches_oracle(M):
+    got, want, path = _chain_case(M, [64, 1, 37, 0, 128])
+    r, e = rel_rms(got, want), max_abs_err(got, want)
+    print(f"chain DeNo M={M} [{path}] rel-rms {r:.3e} max-abs {e:.3e} ref max {np.abs(want).max():.3f}")
+    assert r < 1e-5
+    assert e < 1e-4 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("M", [1, 8, 20, 256])
+def test_chain_fm_matches_oracle(M):
+    kf = 0.3
+    ref = 1.0 / (2 * np.pi * kf)
+    got, want, path = _chain_case(M, [96, 32, 200], demod="fm", kf=kf)
+    _, r, _ = _chain_case(M, [96, 32, 200], demod="none")        # oracle's channel samples r
+    r = np.abs(r.reshape(want.shape))
+    d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
+    # The phase of r carries the channelizer's error divided by |r|: an absolute CF32 error e
+    # moves m by ref*e/|r|.  With the CF32 tolerance e <= 1e-4*max|r| (test above) that is
+    # |dm| * min(|r_t|,|r_t-1|) <= 2*ref*1e-4*max|r|; strong samples get a direct bound.
+    rmin = np.minimum(r, np.concatenate([np.zeros((r.shape[0], 1)), r[:, :-1]], axis=1))
+    weighted = d * rmin / r.max()
+    strong = rmin > 0.25 * r.max()
+    print(f"chain FM M={M} [{path}] median {np.median(d):.3e} weighted max {weighted.max():.3e} "
+          f"strong({strong.mean():.2f}) max {d[strong].max() if strong.any() else 0:.3e}")
+    assert weighted.max() < 2 * ref * 1e-4
+    assert np.median(d) < 2e-5
+    if strong.any():
+        assert d[strong].max() < 2e-5
+
+
+@pytest.mark.parametrize("M", [8, 64])
+def test_chain_agc_fm_matches_oracle(M):
+    kf = 0.3
+    # threshold between tone channels (PFB gain ~M on a 0.5/sqrt(M/4) tone) and noise-only ones
+    got, want, path = _chain_case(M, [512, 512, 1024], demod="fm", kf=kf, agc=10.0)
+    mg, mw = got == 0, want == 0
+    mism = int(np.sum(mg != mw))
+    d = wrap_pm(got.astype(np.float64) - want, 1.0 / kf)
+    print(f"chain AGC+FM M={M} [{path}] squelch mismatches {mism} open {1 - mw.mean():.3f} p99.9 {np.quantile(np.abs(d), 0.999):.3e}")
+    assert mism <= 2 * M          # at most the open/close edges
+    # AGC normalises every open channel to |y| = 1, so a weak channel's relative CF32 error
+    # (1e-5 of the strongest channel's amplitude) shows up un-attenuated in the phase
+    assert np.quantile(np.abs(d), 0.999) < 5e-4
+    assert np.median(np.abs(d)[~mw]) < 2e-5
+
+
+@pytest.mark.parametrize("demod", ["none", "fm"])
+def test_chain_mix_matches_oracle(demod):
+    M = 16
+    got, want, path = _chain_case(M, [64, 64], demod=demod, kf=0.6, mix=True)
+    assert got.shape == want.shape == (128,)
+    if demod == "fm":
+        e = np.abs(got.astype(np.float64) - want)
+        print("mix fm", np.quantile(e, 0.99), e.max())
+        # a single +-1/kf branch flip in any of the M summands shifts the sum by 1/kf
+        e = np.minimum(e, np.abs(wrap_pm(e, 1.0 / 0.6)))
+        assert np.quantile(e, 0.99) < 1e-4
+    else:
+        assert rel_rms(got, want) < 4e-6
+
+
+def test_chain_channel_shard_equals_slice_of_full():
+    M = 32
+    x = synth_cf32(M * 80, M, seed=9)
+    full = cs.Chain(channels=M, demod="fm").process(x)
+    part = cs.Chain(channels=M, demod="fm", chan_first=8, chan_count=12).process(x)
+    assert part.shape == (12, 80)
+    assert np.array_equal(part, full[8:20])
+
+
+def test_chain_chunk_size_invariance():
+    M = 64
+    x = synth_cf32(M * 300, M, seed=21)
+    whole = cs.Chain(channels=M, demod="fm", max_frames=300).process(x)
+    ch = cs.Chain(channels=M, demod="fm", max_frames=300)
+    parts = [ch.process(x[a * M:b * M]) for a, b in ((0, 7), (7, 8), (8, 150), (150, 300))]
+    got = np.concatenate(parts, axis=1)
+    d = wrap_pm(got.astype(np.float64) - whole, 1.0 / 0.3)
+    print("chunk invariance max diff", np.abs(d).max())
+    assert np.quantile(np.abs(d), 0.999) < 2e-5
+
+
+def test_chain_reset_restores_initial_state():
+    M = 16
+    x = synth_cf32(M * 50, M, seed=2)
+    ch = cs.Chain(channels=M, agc=-20.0)
+    a = ch.process(x)
+    ch.process(x)
+    ch.reset()
+    b = ch.process(x)
+    assert np.array_equal(a, b)
+
+
+def test_chain_edge_cases_and_errors():
+    M = 8
+    ch = cs.Chain(channels=M, max_frames=16)
+    out = ch.process(np.empty(0, dtype=np.complex64))            # empty chunk: no-op
+    assert out.size == 0
+    with pytest.raises(cs.CsdrError) as e:
+        ch.process(np.zeros(M * 3 + 1, dtype=np.complex64))      # not a multiple of M
+    assert e.value.code == -4
+    with pytest.raises(cs.CsdrError) as e:
+        ch.process(np.zeros(M * 17, dtype=np.complex64))         # larger than created for
+    assert e.value.code == -4
+    with pytest.raises(cs.CsdrError):
+        cs.Chain(channels=0)
+    with pytest.raises(cs.CsdrError):
+        cs.Chain(channels=8, demod="fm", kf=0.0)
+    with pytest.raises(cs.CsdrError):
+        cs.Chain(channels=8, chan_first=6, chan_count=4)
+    # the stream state survived the failed calls
+    y = ch.process(np.ones(M * 4, dtype=np.complex64))
+    assert y.shape == (M, 4)
+
+
+def test_chain_design_matches_kat():
+    ch = cs.Chain(channels=20)
+    assert ch.nco[1] == 0x86666600                               # KAT2
+    taps = ch.taps
+    assert taps.size == 280 and abs(taps[266] - 0.00075681) < 2e-8   # KAT1
+    assert np.max(np.abs(taps - O.Pfb(20).taps)) < 1e-9
+    assert cs.Chain(channels=256).nco[1] == 0x80800000
+
+
+def test_firpfbch_channelizer_pipe_splits_like_reference():
+    M = 4
+    x = synth_cf32(M * 32, M, seed=1)
+    outs = _run_pipe(cs.firpfbchChannelizer(M), [x, np.empty(0, np.complex64)])
+    assert len(outs[0]) == M and all(a.shape == (32,) for a in outs[0])
+    assert len(outs[1]) == 1 and outs[1][0].size == 0            # Liquid.chs:856-862 on nx = 0
+    want = O.Chan(M).process(x)
+    assert rel_rms(np.stack(outs[0]), want) < 2e-6
