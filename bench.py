@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MS/s of CF32 input through the 256-channel PFB + FM chain on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path over one batch of synthetic CF32 that is already
+resident in HBM: dcBlocker -> NCO pre-mix -> firpfbch(256, m=7, 80 dB) -> per-channel
+freqdem(kf) -> channel-major F32 [256][nf]  (BASELINE.json configs[2] with `-a 0`, the
+reference's own "no AGC" setting, apps/SoapySDR.hs:195-198; the AGC-enabled variant is
+measured beside it and reported under "agc_variant" -- see DESIGN.md section 6).
+
+Multi-GPU (--gpus N): one process per GPU; every rank runs the chain on its own time
+stripe of the stream (no data-path collective: FM/DeNo outputs of a stripe depend only
+on that stripe plus a 13-frame halo), so scaling is weak and value = total samples / max time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--frames", type=int, default=262144,
+                    help="frames per step (64 reference chunks of 4096 frames: 512 MiB of CF32 at M=256)")
+    ap.add_argument("--demod", default="fm", choices=["fm", "none"])
+    ap.add_argument("--kf", type=float, default=0.3)
+    ap.add_argument("--agc", type=float, default=0.0, help="squelch threshold dB (0 = AGC off)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-agc-variant", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(M, demod, kf, agc, x_host, seconds):
+    """The oracle (CPU restatement, 1 thread like the reference's non-threaded RTS) timed on a
+    bounded sample of the same workload: reference-sized chunks (4096 frames) of the same
+    synthetic stream, repeated until ~`seconds` of CPU work."""
+    import numpy as np
+    import oracle_lib as O
+    chain = O.Chain(M, dc_block=True, agc_db=agc, demod=demod, kf=kf)
+    chunk = 4096 * M
+    nchunks = x_host.size // chunk
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for i in range(nchunks):
+            chain.process(x_host[i * chunk:(i + 1) * chunk])
+            done += chunk
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(done / dt / 1e6, 3), "unit": "MS/s", "cores": 1, "kind": "port",
+            "sample": f"{done // chunk} chunks of 4096 frames x {M} ch ({done / 1e6:.1f} MS) of the same synthetic stream, "
+                      f"oracle/csdr_oracle.c single thread, {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libcsdr_hip has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import composable_sdr_amd as cs
+    from composable_sdr_amd import _lib
+    from synth import synth_cf32_torch
+
+    M, nf = a.channels, a.frames
+    nx = M * nf
+    out_elem = 4 if a.demod == "fm" else 8
+    # two input buffers (> the 256 MiB Infinity Cache together) alternate between steps;
+    # rank r's stripe is a different stretch of the stream (different seed offset)
+    xs = [synth_cf32_torch(nx, M, dev, seed=20260101 + 7919 * (2 * rank + i)) for i in range(2)]
+    out = torch.empty(M * nf * out_elem // 4, dtype=torch.float32, device=dev)
+    chain = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, max_frames=nf, device=local,
+                     flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        chain.process_device(xs[i & 1].data_ptr(), nx, out.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    chain.kernel_time()                         # drop warm-up launches
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    kname, kms, klaunches = chain.kernel_time()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    total_samples = float(nx) * a.steps * world
+    value = total_samples / dt / 1e6
+    alg_bytes_per_sample = 8 + out_elem                 # read CF32 once + write W
+    kavg_ms = kms / max(klaunches, 1)
+    achieved = (nx * alg_bytes_per_sample) / (kavg_ms * 1e-3) / 1e9 if klaunches else None
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tfile):
+        try:
+            tj = json.load(open(tfile))
+            key = f"{kname}|M={M}|nf={nf}"
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    res = {
+        "metric": "MS/s CF32 throughput, 256-ch PFB+FM pipeline", "value": round(value, 1), "unit": "MS/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"cfg3: {M}-ch firpfbch(m=7,As=80)+dcBlocker+freqdem(kf={a.kf}) on synthetic CF32, "
+                               f"AGC {'off (-a 0)' if a.agc == 0 else a.agc}, {nf} frames/step "
+                               f"({nx * 8 / 2**20:.0f} MiB in, {M * nf * out_elem / 2**20:.0f} MiB out), HBM-resident",
+                   "channels": M, "frames_per_step": nf, "demod": a.demod, "kf": a.kf, "agc_db": a.agc,
+                   "path": chain.path, "sharding": "time stripes, 1 per rank" if world > 1 else "none"},
+        "hbm_roofline_frac_whole_step": round(value * 1e6 * alg_bytes_per_sample / 1e9 / (HBM_PEAK_GBS * world), 4),
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                     "traffic": traffic, "launch_ms": round(kavg_ms, 4), "launches": klaunches,
+                     "alg_bytes_per_sample": alg_bytes_per_sample, "samples_per_launch": nx},
+    }
+
+    if world == 1 and not a.no_agc_variant and a.agc == 0.0:
+        # cfg3 with the AGC on: exactly-sequential per-channel AGC tail
+        nf2 = min(nf, 65536)
+        ch2 = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=10.0, max_frames=nf2, device=local, flags=_lib.FLAG_QUIET)
+        for i in range(2):
+            ch2.process_device(xs[0].data_ptr(), M * nf2, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        reps = 3
+        for i in range(reps):
+            ch2.process_device(xs[i & 1].data_ptr(), M * nf2, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        d2 = time.perf_counter() - t1
+        res["agc_variant"] = {"value": round(M * nf2 * reps / d2 / 1e6, 1), "unit": "MS/s", "agc_db": 10.0,
+                              "path": ch2.path, "strategy": "exact-sequential AGC (one lane per channel)",
+                              "frames_per_step": nf2}
+        ch2.close()
+
+    if world == 1 and not a.no_cpu_baseline:
+        x_host = xs[0][: 4096 * M * 4].cpu().numpy().view(np.complex64).reshape(-1)
+        res["cpu_baseline"] = cpu_baseline(M, a.demod, a.kf, a.agc, x_host, a.cpu_seconds)
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
