@@ -63,39 +63,6 @@ DcParams make_dc(float alpha)
     return d;
 }
 
-struct KernelTimer {
-    std::vector<hipEvent_t> ev;          // pairs
-    size_t used = 0;
-    double acc_ms = 0.0; uint32_t launches = 0;
-    bool enabled = false;
-    int begin(hipStream_t s) {
-        if (!enabled) return 0;
-        if (used + 2 > ev.size()) {
-            if (ev.size() >= 4096) { int r = drain(); if (r) return r; }
-            else for (int i = 0; i < 2; i++) { hipEvent_t e; CSDR_HIP(hipEventCreate(&e)); ev.push_back(e); }
-        }
-        CSDR_HIP(hipEventRecord(ev[used], s));
-        return 0;
-    }
-    int end(hipStream_t s) {
-        if (!enabled) return 0;
-        CSDR_HIP(hipEventRecord(ev[used + 1], s));
-        used += 2;
-        return 0;
-    }
-    int drain() {
-        for (size_t i = 0; i + 1 < used; i += 2) {
-            CSDR_HIP(hipEventSynchronize(ev[i + 1]));
-            float ms = 0.f;
-            CSDR_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
-            acc_ms += ms; launches++;
-        }
-        used = 0;
-        return 0;
-    }
-    void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); used = 0; }
-};
-
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -511,9 +478,7 @@ int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, vo
     if (h->use_fused) {
         FusedCall fcall{};
         fcall.d_in = (const float2 *)d_in; fcall.d_out = d_out; fcall.nf = nf; fcall.theta0 = h->theta;
-        if ((r = h->timer.begin(s))) return r;
-        if ((r = fused_process(h->fused, fcall, s))) return r;
-        if ((r = h->timer.end(s))) return r;
+        if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
         h->theta += n_in * h->d_theta;
     } else {
         if ((r = chain_generic(h, (const float2 *)d_in, n_in, d_out, s))) return r;
@@ -540,6 +505,11 @@ int csdr_chain_process(csdr_chain *h, const float *in, uint32_t n_in, void *out,
     uint32_t no = 0;
     if ((r = csdr_chain_process_device(h, h->d_in_stage, n_in, h->d_out_stage, &no, nullptr))) return r;
     CSDR_HIP(hipMemcpy(out, h->d_out_stage, (size_t)no * csdr_chain_out_elem_size(h), hipMemcpyDeviceToHost));
+    if (h->fused) {
+        unsigned st = 0;
+        if ((r = fused_status(h->fused, &st))) return r;
+        if (st) { set_error("chain: inter-workgroup wait timed out on the device (status 0x%x)", st); return CSDR_ERR_HIP; }
+    }
     if (n_out) *n_out = no;
     return CSDR_OK;
 }

@@ -86,6 +86,40 @@ int launch_fm(const float2 *Z, float *F, uint32_t C, uint32_t nf, float ref, con
 int launch_mix(const float *in, float *out, uint32_t C, uint32_t E, hipStream_t s);
 int launch_agc_init(AgcState *st, uint32_t C, hipStream_t s);
 
+// ---- hipEvent bracket around the dominant kernel (CSDR_FLAG_TIME_KERNELS) ----
+struct KernelTimer {
+    std::vector<hipEvent_t> ev;          // pairs
+    size_t used = 0;
+    double acc_ms = 0.0; uint32_t launches = 0;
+    bool enabled = false;
+    int begin(hipStream_t s) {
+        if (!enabled) return 0;
+        if (used + 2 > ev.size()) {
+            if (ev.size() >= 4096) { int r = drain(); if (r) return r; }
+            else for (int i = 0; i < 2; i++) { hipEvent_t e; CSDR_HIP(hipEventCreate(&e)); ev.push_back(e); }
+        }
+        CSDR_HIP(hipEventRecord(ev[used], s));
+        return 0;
+    }
+    int end(hipStream_t s) {
+        if (!enabled) return 0;
+        CSDR_HIP(hipEventRecord(ev[used + 1], s));
+        used += 2;
+        return 0;
+    }
+    int drain() {
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            CSDR_HIP(hipEventSynchronize(ev[i + 1]));
+            float ms = 0.f;
+            CSDR_HIP(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            acc_ms += ms; launches++;
+        }
+        used = 0;
+        return 0;
+    }
+    void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); used = 0; }
+};
+
 // ---- fused kernels (kernels_fused.hip) --------------------------------------
 struct FusedPlan;   // opaque per-handle plan
 bool fused_supported(uint32_t M, uint32_t p);

@@ -24,8 +24,10 @@ struct FusedCall {
 bool fused_supported(uint32_t M, uint32_t p);
 int  fused_create(const FusedConfig &cfg, FusedPlan **out);
 int  fused_reset(FusedPlan *plan, hipStream_t s);
-int  fused_process(FusedPlan *plan, const FusedCall &call, hipStream_t s);
+int  fused_process(FusedPlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
 const char *fused_name(const FusedPlan *plan);
+// sticky device-side error word (bit0/bit1: an inter-workgroup wait hit its spin limit); synchronises
+int  fused_status(FusedPlan *plan, unsigned *status);
 void fused_destroy(FusedPlan *plan);
 
 }  // namespace csdr

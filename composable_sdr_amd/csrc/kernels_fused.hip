@@ -1,21 +1,35 @@
-// Fused polyphase-channelizer kernel for gfx950 (wave64, 256 CUs, 160 KiB LDS/CU).
+// Single-pass fused channelizer kernel for gfx950 (wave64, 256 CUs, 160 KiB LDS/CU), M = 256.
 //
-//   premixed input u  ->  14-tap polyphase branch filters (sliding window in VGPRs)
-//                     ->  256-point forward DFT as 16 x 16 (two radix-16 passes in VGPRs,
-//                         exchanged through LDS)
-//                     ->  LDS transpose to channel-major
-//                     ->  per-channel tail (freqdem) -> coalesced row stores [C][nf]
+//   raw CF32 x  --DC blocker--> y --14-tap polyphase FIR + NCO pre-mix--> X_t[j]
+//               --256-point forward DFT (16 x 16)--> Y_t[k] --transpose--> channel-major
+//               --per-channel freqdem--> out[C][nf]          (8 B read + 4/8 B written per sample)
 //
-// One workgroup = 256 threads = one thread per polyphase branch j; it walks a run of
-// frames in batches of 16.  Thread roles per batch:
-//   FIR      thread j            : X_f[j] for f = 0..15 from a 13+16 deep register window
-//   pass 1   thread (f, b)       : Z_f[k1][b] = W256^(b k1) * sum_a X_f[16a+b] W16^(a k1)
-//   pass 2   thread (f, k1)      : Y_f[k1+16 k2] = sum_b Z_f[k1][b] W16^(b k2)
-//   tail     thread k            : 16 consecutive time samples of channel k
+// One workgroup (256 threads) produces one TILE of 16 frames (4096 input samples) and never
+// writes an intermediate to HBM.  The stream-long recurrences are cut at tile boundaries:
+//   * DC blocker (iirfilt_crcf, v[n] = x[n] + beta v[n-1], y = x - alpha v[n-1]) is a linear
+//     scan.  Each tile's zero-state aggregate A_b is published as two 8-byte {tag,value}
+//     granules as soon as the tile has been read; a tile's carry is the decayed sum of the
+//     previous ten aggregates (beta^40960 = 1.3e-9 truncation) -- a decoupled look-back that
+//     never chains, because an aggregate does not depend on any other workgroup.
+//   * The FIR needs the 13 frames before the tile: the workgroup re-reads the previous tile
+//     (an L2 hit: its owner is reading it at the same time) and re-runs the DC blocker on it.
+//   * freqdem needs the previous frame's channel sample: each tile publishes its last Y
+//     frame (2 KiB) and the successor picks it up in its tail phase.
+// Workgroups take their tile index from an atomic ticket, so every tile a workgroup waits on
+// belongs to a workgroup that has already started and publishes before it waits (no deadlock
+// under any dispatch order; inter-workgroup data uses agent-scope atomics only).
+//
+// Thread roles inside a tile (tid = 0..255):
+//   stage    thread q = run of 16 consecutive samples: serial DC scan, 16-lane DPP row scan
+//   FIR      thread j = polyphase branch j           : window of 13 + 16 frames in VGPRs
+//   pass 1   thread (f, b)  : Z_f[k1][b] = W256^(b k1) sum_a X_f[16a+b] W16^(a k1)
+//   pass 2   thread (f, k1) : Y_f[k1+16 k2] = sum_b Z_f[k1][b] W16^(b k2)
+//   tail     thread k       : 16 consecutive time samples of channel k
 // MFMA is not used: the path is streaming FIR/FFT bounded by HBM and VALU (north_star).
 //
-// Replaces per chunk: nf x firpfbch_crcf_analyzer_execute + the Haskell transpose
-// (Liquid.chs:840-849) + M x freqdem_demodulate_block (Liquid.chs:324-328).
+// Replaces per chunk: iirfilt_crcf_execute_block + nco_crcf_mix_block_down + nf x
+// firpfbch_crcf_analyzer_execute + the Haskell transpose (Liquid.chs:575-589, 828-862) and
+// M x freqdem_demodulate_block (Liquid.chs:324-328).
 #include "fused.h"
 
 #include <cmath>
@@ -27,12 +41,17 @@ namespace {
 
 constexpr int M256 = 256;
 constexpr int P = 14;            // taps per branch (2m, m = 7)
-constexpr int NB = 16;           // frames per batch
+constexpr int NB = 16;           // frames per tile
 constexpr int FS_X = 272;        // float2 stride between frames, FIR -> pass-1 layout
 constexpr int FS_Z = 289;        // float2 stride between frames, pass-1 -> pass-2 layout
 constexpr int RS_Z = 18;         // float2 stride between k1 rows inside a frame (16 + 2 pad)
 constexpr int RS_Y = 17;         // float2 stride between channel rows, pass-2 -> tail layout
-constexpr int LDS_F2 = 16 * FS_Z;   // 4624 float2 = 36992 B (largest of the three layouts)
+constexpr int LDS_F2 = 16 * FS_Z;   // 4624 float2 = 36992 B (largest layout)
+constexpr int E_OFF = 4096;      // float2 offset of the two 256-entry run-carry tables
+constexpr int LOOKBACK = 10;     // tiles; beta^(4096*10) ~ 1.3e-9 for alpha = 0.0005
+constexpr unsigned SPIN_LIMIT = 1u << 24;
+
+typedef unsigned long long u64;
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -40,8 +59,11 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b)
 {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-// multiply by -j
-__device__ __forceinline__ float2 mulmj(float2 a) { return make_float2(a.y, -a.x); }
+__device__ __forceinline__ float2 mulmj(float2 a) { return make_float2(a.y, -a.x); }   // * -j
+__device__ __forceinline__ float2 cfma(float2 a, float s, float2 b)                    // a*s + b
+{
+    return make_float2(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y));
+}
 
 // forward radix-4 butterfly (W4 = -j)
 __device__ __forceinline__ void bfly4(float2 &x0, float2 &x1, float2 &x2, float2 &x3)
@@ -58,23 +80,19 @@ __device__ __forceinline__ void bfly4(float2 &x0, float2 &x1, float2 &x2, float2
 __device__ __forceinline__ void fft16(float2 (&v)[16])
 {
     constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
-    // 4 butterflies over c (stride-4 subsequences): t[a][q] in v[a + 4q]
 #pragma unroll
     for (int a = 0; a < 4; a++) bfly4(v[a], v[a + 4], v[a + 8], v[a + 12]);
-    // twiddle W16^(a q) on element (a, q) = v[a + 4q]
-    v[1 + 4] = cmul(v[1 + 4], make_float2(C1, -S1));            // W^1
-    v[1 + 8] = cmul(v[1 + 8], make_float2(R2, -R2));            // W^2
-    v[1 + 12] = cmul(v[1 + 12], make_float2(S1, -C1));          // W^3
-    v[2 + 4] = cmul(v[2 + 4], make_float2(R2, -R2));            // W^2
-    v[2 + 8] = mulmj(v[2 + 8]);                                 // W^4 = -j
-    v[2 + 12] = cmul(v[2 + 12], make_float2(-R2, -R2));         // W^6
-    v[3 + 4] = cmul(v[3 + 4], make_float2(S1, -C1));            // W^3
-    v[3 + 8] = cmul(v[3 + 8], make_float2(-R2, -R2));           // W^6
-    v[3 + 12] = cmul(v[3 + 12], make_float2(-C1, S1));          // W^9
-    // 4 butterflies over a for each q: X[q + 4r]
+    v[1 + 4] = cmul(v[1 + 4], make_float2(C1, -S1));            // W16^1
+    v[1 + 8] = cmul(v[1 + 8], make_float2(R2, -R2));            // W16^2
+    v[1 + 12] = cmul(v[1 + 12], make_float2(S1, -C1));          // W16^3
+    v[2 + 4] = cmul(v[2 + 4], make_float2(R2, -R2));            // W16^2
+    v[2 + 8] = mulmj(v[2 + 8]);                                 // W16^4 = -j
+    v[2 + 12] = cmul(v[2 + 12], make_float2(-R2, -R2));         // W16^6
+    v[3 + 4] = cmul(v[3 + 4], make_float2(S1, -C1));            // W16^3
+    v[3 + 8] = cmul(v[3 + 8], make_float2(-R2, -R2));           // W16^6
+    v[3 + 12] = cmul(v[3 + 12], make_float2(-C1, S1));          // W16^9
 #pragma unroll
     for (int q = 0; q < 4; q++) bfly4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    // now v[4q + r] = X[q + 4r]: transpose the 4x4 index to natural order
 #pragma unroll
     for (int q = 0; q < 4; q++)
 #pragma unroll
@@ -85,161 +103,354 @@ __device__ __forceinline__ void fft16(float2 (&v)[16])
         }
 }
 
-struct FusedArgs {
-    const float2 *u;          // first NEW premixed sample; (P-1)*M samples of history before it
-    const float *taps;        // [P][M] prototype taps
-    const float2 *tw;         // W256^i, i < 256
-    void *out;                // [C][nf]
-    float2 *bound_first;      // [nwg][M]  Y of each run's first frame
-    float2 *bound_last;       // [nwg][M]  Y of each run's last frame
-    uint32_t nf, run;         // frames in this call, frames per workgroup (multiple of 16)
-    uint32_t c0, C;
-    float fm_ref;
+// atan2f for the freqdem tail: odd minimax polynomial of degree 17 on [0,1] (fit error 6e-9,
+// f32 evaluation error <= 1.2e-7 rad) + octant folding.  Signed zeros follow IEEE atan2
+// (atan2(+-0, -0) = +-pi, atan2(+-0, +0) = +-0), which is what cargf(conjf(0)*r) relies on.
+__device__ __forceinline__ float fast_atan2f(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float a = mn * __builtin_amdgcn_rcpf(mx);
+    a = (mx == 0.0f) ? 0.0f : a;
+    a = (mx == INFINITY) ? ((mn == INFINITY) ? 1.0f : 0.0f) : a;
+    const float z = a * a;
+    float p = 2.456645248e-03f;
+    p = fmaf(p, z, -1.440101303e-02f);
+    p = fmaf(p, z, 3.978060186e-02f);
+    p = fmaf(p, z, -7.234797627e-02f);
+    p = fmaf(p, z, 1.049891263e-01f);
+    p = fmaf(p, z, -1.416121870e-01f);
+    p = fmaf(p, z, 1.998590529e-01f);
+    p = fmaf(p, z, -3.333259821e-01f);
+    p = fmaf(p, z, 9.999998808e-01f);
+    float r = p * a;
+    r = (ay > ax) ? 1.57079632679489662f - r : r;
+    r = (__float_as_uint(x) >> 31) ? 3.14159265358979324f - r : r;
+    return copysignf(r, y);
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ float2 dpp2(float2 v) { return make_float2(dpp<CTRL>(v.x), dpp<CTRL>(v.y)); }
+
+struct TileArgs {
+    const float2 *x;            // new input, nf*256 samples
+    void *out;                  // [C][nf] F32 (FM) or CF32
+    const float *taps;          // [P][256] prototype taps h[i + n*256]
+    const float2 *tw;           // W256^i
+    const float2 *wpre;         // [2][256]: conj(nco phasor) of column j for even / odd global frames
+    const float2 *yhist_in; float2 *yhist_out;   // [13][256] DC-blocked samples before the call / after it
+    const float2 *vend_in;  float2 *vend_out;    // DC blocker state v1
+    const float2 *rp_in;    float2 *rp_out;      // [C] freqdem r'
+    unsigned *ticket;           // zeroed before every launch
+    u64 *agg;                   // [nb][2] {epoch, bits} granules: tile aggregates
+    u64 *ylast;                 // [nb][256] last Y frame of each tile
+    unsigned *yflag;            // [nb]
+    unsigned *status;           // sticky error word (spin limit hit)
+    uint32_t epoch, nf, nb, c0, C, parity0;
+    float alpha, beta, fm_ref;
+    float wtile[LOOKBACK + 2];  // beta^(4096 k)
+    float b16[16];              // beta^(16 r)
+    float b256[17];             // beta^(256 f)
+    float bj[16];               // beta^i
 };
 
-template <bool FM>
-__global__ __launch_bounds__(256) void k_fused256(FusedArgs A)
+// Stage one tile of raw samples into LDS (16-byte slots XOR-swizzled so that both the
+// run-major b128 accesses and the column-major b64 accesses are bank-conflict free) and run
+// the zero-state DC scan on it.  On return R holds z[n] = x[n] - alpha*s[n-1] (s = scan inside
+// the 16-sample run), E[q] the carry into run q from earlier runs of its frame, T[f] the
+// frame totals.  Ends with a barrier.
+__device__ __forceinline__ void stage_and_scan(const float4 *__restrict__ src, int nvalid, float2 *R, float2 *E,
+                                               float2 *T, const TileArgs &A, int tid)
 {
-    __shared__ __attribute__((aligned(16))) float2 lds[LDS_F2];
+    float4 *R4 = reinterpret_cast<float4 *>(R);
+    const int wave = tid >> 6, lane = tid & 63;
+    float4 raw[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int slot = 64 * (it * 4 + wave) + lane;          // 16-byte slot in LDS
+        const int q = slot >> 3;                               // run (16 samples)
+        const int i = (slot & 7) ^ ((q >> 1) & 7);             // which 16-byte piece of the run
+        raw[it] = ((q >> 4) < nvalid) ? src[8 * q + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; it++) R4[64 * (it * 4 + wave) + lane] = raw[it];
+    __syncthreads();
+
+    const int q = tid, sw = (q >> 1) & 7;
+    float2 s = make_float2(0.f, 0.f);
+    const float na = -A.alpha, be = A.beta;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float4 v = R4[8 * q + (i ^ sw)];
+        float2 x0 = make_float2(v.x, v.y), x1 = make_float2(v.z, v.w);
+        const float2 z0 = cfma(s, na, x0);
+        s = cfma(s, be, x0);
+        const float2 z1 = cfma(s, na, x1);
+        s = cfma(s, be, x1);
+        R4[8 * q + (i ^ sw)] = make_float4(z0.x, z0.y, z1.x, z1.y);
+    }
+    // inclusive decayed scan of the run totals across the 16 runs of a frame (one DPP row)
+    float2 t;
+    t = dpp2<0x111>(s); s = cfma(t, A.b16[1], s);
+    t = dpp2<0x112>(s); s = cfma(t, A.b16[2], s);
+    t = dpp2<0x114>(s); s = cfma(t, A.b16[4], s);
+    t = dpp2<0x118>(s); s = cfma(t, A.b16[8], s);
+    E[q] = dpp2<0x111>(s);                                     // v at my run's start (zero frame carry)
+    if ((q & 15) == 15) T[q >> 4] = s;                         // frame total
+    __syncthreads();
+}
+
+template <bool FM>
+__global__ __launch_bounds__(256) void k_tile256(TileArgs A)
+{
+    __shared__ __attribute__((aligned(16))) float2 R[LDS_F2];
     __shared__ float2 tw_s[M256];
+    __shared__ float2 Tt[2][16];        // frame totals: [0] own, [1] halo
+    __shared__ float2 Vin[2][17];       // v before frame f (full, with tile carry); [16] = after the tile
+    __shared__ float2 carry_s[2];       // c_b, c_{b-1}
+    __shared__ unsigned tile_s;
 
     const int tid = threadIdx.x;
-    const int64_t t0 = (int64_t)blockIdx.x * A.run;
-    const int64_t t1 = min((int64_t)A.nf, t0 + (int64_t)A.run);
-
+    if (tid == 0) tile_s = atomicAdd(A.ticket, 1u);
     tw_s[tid] = A.tw[tid];
+    __syncthreads();
+    const unsigned b = tile_s;
+    if (b >= A.nb) return;
+    const int nvalid = (int)min(16u, A.nf - 16u * b);
+    const int j = tid;
+    const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
+    float2 *E = R + E_OFF;
 
-    // branch taps: X[j] uses h[(M-1-j) + n*M]
-    float h[P];
+    // ---------------- own tile: stage, scan, publish the aggregate ----------------
+    stage_and_scan(reinterpret_cast<const float4 *>(A.x) + (size_t)b * 2048, nvalid, R, E, Tt[0], A, tid);
+
+    float2 nw[NB], old[NB];
 #pragma unroll
-    for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - tid) + n * M256];
+    for (int f = 0; f < NB; f++) { nw[f] = R[256 * f + col_off]; old[f] = make_float2(0.f, 0.f); }
 
-    // sliding window: old[3..15] = the 13 frames before the run
-    float2 old[NB], nw[NB];
-    const float2 *ucol = A.u + tid;
+    if (tid < 64) {
+        // zero-state frame chain of the own tile -> aggregate A_b, published as two granules
+        if (tid == 0) {
+            float2 v = make_float2(0.f, 0.f);
 #pragma unroll
-    for (int i = 3; i < NB; i++) old[i] = ucol[(t0 - NB + i) * M256];
-    old[0] = old[1] = old[2] = make_float2(0.f, 0.f);
+            for (int f = 0; f < 16; f++) { Vin[0][f] = v; v = cfma(v, A.b256[1], Tt[0][f]); }
+            Vin[0][16] = v;
+            __hip_atomic_store(&A.agg[2 * (size_t)b], ((u64)A.epoch << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&A.agg[2 * (size_t)b + 1], ((u64)A.epoch << 32) | __float_as_uint(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // ---------------- look-back: carries c_b (own tile) and c_{b-1} (halo tile) ----------------
+        const int lane = tid;
+        float2 cb = make_float2(0.f, 0.f), cp = make_float2(0.f, 0.f);
+        const int k = lane;                                  // lane k in 1..LOOKBACK looks at tile b-k
+        const bool need = (k >= 1 && k <= LOOKBACK && (int)b - k >= 0);
+        u64 g0 = 0, g1 = 0;
+        unsigned spins = 0;
+        bool ok = !need;
+        while (true) {
+            if (need && !ok) {
+                g0 = __hip_atomic_load(&A.agg[2 * (size_t)(b - k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g1 = __hip_atomic_load(&A.agg[2 * (size_t)(b - k) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(g0 >> 32) == A.epoch && (unsigned)(g1 >> 32) == A.epoch;
+            }
+            if (__all(ok)) break;
+            if (++spins > SPIN_LIMIT) { if (lane == 0) atomicOr(A.status, 1u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (need) {
+            const float2 Ak = make_float2(__uint_as_float((unsigned)g0), __uint_as_float((unsigned)g1));
+            cb = make_float2(Ak.x * A.wtile[k - 1], Ak.y * A.wtile[k - 1]);
+            if (k >= 2) cp = make_float2(Ak.x * A.wtile[k - 2], Ak.y * A.wtile[k - 2]);
+        }
+        if (lane == 0) {                                     // the stream state before this call
+            const float2 ve = A.vend_in[0];
+            if (b <= LOOKBACK) cb = make_float2(ve.x * A.wtile[b], ve.y * A.wtile[b]);
+            if (b >= 1 && b - 1 <= LOOKBACK) cp = make_float2(ve.x * A.wtile[b - 1], ve.y * A.wtile[b - 1]);
+        }
+        // sum over lanes 0..15 (one DPP row): the inclusive row_shr ladder ends in lane 15
+        cb = cadd(cb, dpp2<0x111>(cb)); cp = cadd(cp, dpp2<0x111>(cp));
+        cb = cadd(cb, dpp2<0x112>(cb)); cp = cadd(cp, dpp2<0x112>(cp));
+        cb = cadd(cb, dpp2<0x114>(cb)); cp = cadd(cp, dpp2<0x114>(cp));
+        cb = cadd(cb, dpp2<0x118>(cb)); cp = cadd(cp, dpp2<0x118>(cp));
+        if (lane == 15) { carry_s[0] = cb; carry_s[1] = cp; }
+    }
+    __syncthreads();                                            // own z consumed; carries ready
 
-    float2 prev = make_float2(0.f, 0.f);     // channel tid's previous sample (tail role)
-    const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
-    const bool vec_ok = (A.nf % 4u) == 0;
-
-    for (int64_t tb = t0; tb < t1; tb += NB) {
-        const int nvalid = (int)min((int64_t)NB, t1 - tb);
-        // ---- load 16 new frames of my branch ----
+    // ---------------- halo: the 13 frames before the tile ----------------
+    if (b > 0) {
+        stage_and_scan(reinterpret_cast<const float4 *>(A.x) + (size_t)(b - 1) * 2048, 16, R, E + 256, Tt[1], A, tid);
 #pragma unroll
-        for (int f = 0; f < NB; f++)
-            nw[f] = (f < nvalid) ? ucol[(tb + f) * M256] : make_float2(0.f, 0.f);
+        for (int f = 3; f < NB; f++) old[f] = R[256 * f + col_off];
+    } else {
+#pragma unroll
+        for (int f = 3; f < NB; f++) old[f] = A.yhist_in[(f - 3) * M256 + j];
+    }
+    if (tid < 32) {
+        // full frame chains: Vin[g][f] = v before frame f including the tile carry
+        const int g = tid >> 4, f = tid & 15;
+        const float2 c = carry_s[g];
+        if (g == 0) {
+            Vin[0][f] = cfma(c, A.b256[f], Vin[0][f]);
+            if (f == 0) Vin[0][16] = cfma(c, A.b256[16], Vin[0][16]);
+        } else if (b > 0) {
+            float2 v = make_float2(0.f, 0.f);
+            for (int ff = 0; ff < f; ff++) v = cfma(v, A.b256[1], Tt[1][ff]);
+            Vin[1][f] = cfma(c, A.b256[f], v);
+        }
+    }
+    __syncthreads();
 
-        // ---- polyphase FIR, oldest tap first (dotprod_crcf order) ----
+    // ---------------- finish the DC blocker: y = z - alpha*beta^i * (carry into the run) ----------------
+    {
+        const float kj = A.alpha * A.bj[j & 15];
+        const float br = A.b16[j >> 4];
 #pragma unroll
         for (int f = 0; f < NB; f++) {
-            float2 acc = make_float2(0.f, 0.f);
+            const float2 pc = cfma(Vin[0][f], br, E[16 * f + (j >> 4)]);
+            nw[f] = cfma(pc, -kj, nw[f]);
+        }
+        if (b > 0) {
+#pragma unroll
+            for (int f = 3; f < NB; f++) {
+                const float2 pc = cfma(Vin[1][f], br, E[256 + 16 * f + (j >> 4)]);
+                old[f] = cfma(pc, -kj, old[f]);
+            }
+        }
+    }
+    if (b == A.nb - 1) {
+        // stream state for the next call: DC v1 after the last frame, the last 13 frames of y
+        if (tid == 0) A.vend_out[0] = Vin[0][nvalid];
+        const int base = (int)A.nf - 13 - 16 * (int)b;        // tile-relative frame of yhist slot 0
+#pragma unroll
+        for (int f = 3; f < NB; f++) {
+            const int d = (f - 16) - base;
+            if (d >= 0 && d < 13) A.yhist_out[d * M256 + j] = old[f];
+        }
+#pragma unroll
+        for (int f = 0; f < NB; f++) {
+            const int d = f - base;
+            if (d >= 0 && d < 13 && f < nvalid) A.yhist_out[d * M256 + j] = nw[f];
+        }
+    }
+    __syncthreads();                                            // E / Vin consumed, R free
+
+    // ---------------- polyphase FIR + NCO pre-mix ----------------
+    // u[t][j] = y[t][j] * wpre[parity(t)][j] and X_t[j] = sum_n h[(255-j)+256n] u[t-n][j]:
+    // even and odd taps see the two phasors, so two partial sums and two complex products.
+    {
+        float h[P];
+#pragma unroll
+        for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j) + n * M256];
+        const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
+#pragma unroll
+        for (int f = 0; f < NB; f++) {
+            float2 ev = make_float2(0.f, 0.f), od = make_float2(0.f, 0.f);
 #pragma unroll
             for (int n = P - 1; n >= 0; n--) {
                 const int i = f - n;
                 const float2 s = (i >= 0) ? nw[i] : old[NB + i];
-                acc.x = fmaf(h[n], s.x, acc.x);
-                acc.y = fmaf(h[n], s.y, acc.y);
+                if (n & 1) od = cfma(s, h[n], od); else ev = cfma(s, h[n], ev);
             }
-            lds[f * FS_X + tid] = acc;
+            const float2 xa = cmul(ev, (f & 1) ? Wb : Wa), xb = cmul(od, (f & 1) ? Wa : Wb);
+            R[f * FS_X + j] = cadd(xa, xb);
         }
-#pragma unroll
-        for (int f = 0; f < NB; f++) old[f] = nw[f];
-        __syncthreads();                                        // B1: X complete
+    }
+    __syncthreads();                                            // X complete
 
-        // ---- pass 1: thread (f, b) ----
-        float2 v[16];
-        {
-            const int f = tid >> 4, b = tid & 15;
+    // ---------------- DFT pass 1: thread (f, b1) ----------------
+    float2 v[16];
+    {
+        const int f = tid >> 4, b1 = tid & 15;
 #pragma unroll
-            for (int a = 0; a < 16; a++) v[a] = lds[f * FS_X + 16 * a + b];
-            fft16(v);
+        for (int a = 0; a < 16; a++) v[a] = R[f * FS_X + 16 * a + b1];
+        fft16(v);
 #pragma unroll
-            for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], tw_s[b * k1]);
-            __syncthreads();                                    // B2: everyone has read X
+        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], tw_s[b1 * k1]);
+        __syncthreads();                                        // everyone has read X
 #pragma unroll
-            for (int k1 = 0; k1 < 16; k1++) lds[f * FS_Z + k1 * RS_Z + b] = v[k1];
-        }
-        __syncthreads();                                        // B3: Z complete
+        for (int k1 = 0; k1 < 16; k1++) R[f * FS_Z + k1 * RS_Z + b1] = v[k1];
+    }
+    __syncthreads();                                            // Z complete
 
-        // ---- pass 2: thread (f, k1) ----
-        {
-            const int f = tid >> 4, k1 = tid & 15;
+    // ---------------- DFT pass 2: thread (f, k1) ----------------
+    {
+        const int f = tid >> 4, k1 = tid & 15;
 #pragma unroll
-            for (int b = 0; b < 16; b++) v[b] = lds[f * FS_Z + k1 * RS_Z + b];
-            fft16(v);
-            __syncthreads();                                    // B4: everyone has read Z
+        for (int b1 = 0; b1 < 16; b1++) v[b1] = R[f * FS_Z + k1 * RS_Z + b1];
+        fft16(v);
+        __syncthreads();                                        // everyone has read Z
 #pragma unroll
-            for (int k2 = 0; k2 < 16; k2++) lds[(k1 + 16 * k2) * RS_Y + f] = v[k2];
-        }
-        __syncthreads();                                        // B5: Y complete
+        for (int k2 = 0; k2 < 16; k2++) R[(k1 + 16 * k2) * RS_Y + f] = v[k2];
+    }
+    __syncthreads();                                            // Y complete
 
-        // ---- tail: thread k = tid owns channel k, 16 consecutive samples ----
+    // ---------------- tail: thread k owns channel k ----------------
 #pragma unroll
-        for (int f = 0; f < NB; f++) v[f] = lds[tid * RS_Y + f];
-        if (tb == t0) A.bound_first[(size_t)blockIdx.x * M256 + tid] = v[0];
-        if (tb + NB >= t1) {
-            float2 last = v[0];
+    for (int f = 0; f < NB; f++) v[f] = R[tid * RS_Y + f];
+    const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
+    const size_t row = (size_t)(owned ? tid - A.c0 : 0) * A.nf + (size_t)16 * b;
+
+    if (FM) {
+        // publish my last valid frame for the next tile, then fetch the previous tile's
+        float2 last = v[0];
 #pragma unroll
-            for (int f = 1; f < NB; f++) if (f < nvalid) last = v[f];
-            A.bound_last[(size_t)blockIdx.x * M256 + tid] = last;
+        for (int f = 1; f < NB; f++) if (f < nvalid) last = v[f];
+        const u64 bits = ((u64)__float_as_uint(last.y) << 32) | __float_as_uint(last.x);
+        __hip_atomic_store(&A.ylast[(size_t)b * M256 + tid], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&A.yflag[b], A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b == A.nb - 1 && owned) A.rp_out[tid - A.c0] = last;
+
+        float2 prev;
+        if (b == 0) {
+            prev = owned ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
+        } else {
+            if (tid < 64) {
+                unsigned spins = 0;
+                while (__hip_atomic_load(&A.yflag[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) {
+                    if (++spins > SPIN_LIMIT) { if (tid == 0) atomicOr(A.status, 2u); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+            const u64 pb = __hip_atomic_load(&A.ylast[(size_t)(b - 1) * M256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            prev = make_float2(__uint_as_float((unsigned)pb), __uint_as_float((unsigned)(pb >> 32)));
         }
         if (owned) {
-            const size_t row = (size_t)(tid - A.c0) * A.nf + (size_t)tb;
-            if (FM) {
-                float m[NB];
+            float m[NB];
 #pragma unroll
-                for (int f = 0; f < NB; f++) {
-                    const float2 r = v[f];
-                    const float re = __fadd_rn(__fmul_rn(prev.x, r.x), __fmul_rn(prev.y, r.y));
-                    const float im = __fsub_rn(__fmul_rn(prev.x, r.y), __fmul_rn(prev.y, r.x));
-                    m[f] = atan2f(im, re) * A.fm_ref;
-                    prev = r;
-                }
-                float *o = (float *)A.out + row;
-                if (vec_ok && nvalid == NB) {
+            for (int f = 0; f < NB; f++) {
+                const float2 r = v[f];
+                // arg(conj(r') r): products rounded separately like the reference's C expression
+                const float re = __fadd_rn(__fmul_rn(prev.x, r.x), __fmul_rn(prev.y, r.y));
+                const float im = __fsub_rn(__fmul_rn(prev.x, r.y), __fmul_rn(prev.y, r.x));
+                m[f] = fast_atan2f(im, re) * A.fm_ref;
+                prev = r;
+            }
+            float *o = (float *)A.out + row;
+            if ((A.nf % 4u) == 0 && nvalid == NB) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = m[f];
-                }
+                for (int q = 0; q < 4; q++)
+                    *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
             } else {
-                float2 *o = (float2 *)A.out + row;
-                if ((A.nf % 2u) == 0 && nvalid == NB) {
 #pragma unroll
-                    for (int q = 0; q < 8; q++)
-                        *reinterpret_cast<float4 *>(o + 2 * q) = make_float4(v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = v[f];
-                }
+                for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = m[f];
             }
         }
-        __syncthreads();                                        // B6: Y consumed
+    } else if (owned) {
+        float2 *o = (float2 *)A.out + row;
+        if ((A.nf % 2u) == 0 && nvalid == NB) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                *reinterpret_cast<float4 *>(o + 2 * q) = make_float4(v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y);
+        } else {
+#pragma unroll
+            for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = v[f];
+        }
     }
-}
-
-// out[c][t0(w)] for every run start: freqdem against the previous run's last sample
-__global__ __launch_bounds__(256) void k_fm_fixup(const float2 *__restrict__ bound_first,
-                                                  const float2 *__restrict__ bound_last, const float2 *__restrict__ rp_in,
-                                                  float2 *__restrict__ rp_out, float *__restrict__ out, uint32_t nf,
-                                                  uint32_t run, uint32_t nwg, uint32_t c0, uint32_t C, float ref)
-{
-    const uint32_t k = threadIdx.x, w = blockIdx.x;
-    if (w == nwg) {                                  // extra block: save r' for the next call
-        if (k >= c0 && k < c0 + C) rp_out[k - c0] = bound_last[(size_t)(nwg - 1) * M256 + k];
-        return;
-    }
-    if (k < c0 || k >= c0 + C) return;
-    const float2 r = bound_first[(size_t)w * M256 + k];
-    const float2 rp = w ? bound_last[(size_t)(w - 1) * M256 + k] : rp_in[k - c0];
-    const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
-    const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
-    out[(size_t)(k - c0) * nf + (size_t)w * run] = atan2f(im, re) * ref;
 }
 
 }  // namespace
@@ -247,109 +458,112 @@ __global__ __launch_bounds__(256) void k_fm_fixup(const float2 *__restrict__ bou
 struct FusedPlan {
     FusedConfig cfg;
     std::string name;
-    size_t hist;                 // (p-1)*M
+    uint32_t max_nb = 0, epoch = 0;
+    uint64_t frames_done = 0;    // global frame counter (parity selects the premix phasor row)
     float *d_taps = nullptr;
-    float2 *d_tw = nullptr, *d_u = nullptr, *d_hist_tmp = nullptr, *d_dcstate = nullptr, *d_scratch = nullptr;
-    float2 *d_nco_tab = nullptr; uint32_t tab_len = 0, tab_pos = 0;
-    float2 *d_bfirst = nullptr, *d_blast = nullptr; uint32_t max_wg = 0;
-    float2 *d_rp[2] = {nullptr, nullptr}; int rp_cur = 0;
+    float2 *d_tw = nullptr, *d_wpre = nullptr;
+    float2 *d_yhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
+    int cur = 0;
+    unsigned *d_ticket = nullptr, *d_yflag = nullptr, *d_status = nullptr;
+    u64 *d_agg = nullptr, *d_ylast = nullptr;
     void *d_premix = nullptr;    // per-channel output before mixing
+    TileArgs proto;
 };
 
 bool fused_supported(uint32_t M, uint32_t p) { return M == 256 && p == P; }
-
-static uint32_t pick_run(uint32_t nf)
-{
-    // frames per workgroup: multiple of 16, aiming at >= ~2048 workgroups on large chunks
-    uint32_t run = (nf + 2047) / 2048;
-    run = (run + NB - 1) / NB * NB;
-    if (run < NB) run = NB;
-    return run;
-}
 
 int fused_create(const FusedConfig &cfg, FusedPlan **out)
 {
     FusedPlan *p = new FusedPlan();
     p->cfg = cfg;
-    p->name = cfg.fm ? "k_fused256<FM>" : "k_fused256<CF32>";
-    p->hist = (size_t)(cfg.p - 1) * cfg.M;
-    const uint64_t max_nx = (uint64_t)cfg.max_nf * cfg.M;
+    p->name = cfg.fm ? "k_tile256<FM>" : "k_tile256<CF32>";
+    p->max_nb = (cfg.max_nf + NB - 1) / NB;
     auto fail = [&](int r) { fused_destroy(p); return r; };
-#define ALLOC(ptr, count) do { hipError_t e = hipMalloc((void **)&(ptr), (count) ? (count) : 1); if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__)); } while (0)
+#define ALLOC(ptr, bytes) do { hipError_t e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 1); if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__)); } while (0)
     ALLOC(p->d_taps, sizeof(float) * cfg.M * cfg.p);
     ALLOC(p->d_tw, sizeof(float2) * cfg.M);
-    ALLOC(p->d_u, sizeof(float2) * (p->hist + max_nx));
-    ALLOC(p->d_hist_tmp, sizeof(float2) * p->hist);
-    ALLOC(p->d_dcstate, sizeof(float2));
-    ALLOC(p->d_scratch, sizeof(float2) * 2 * (max_nx / DC_BLOCK + 2));
-    p->max_wg = (cfg.max_nf + NB - 1) / NB;
-    ALLOC(p->d_bfirst, sizeof(float2) * (size_t)p->max_wg * cfg.M);
-    ALLOC(p->d_blast, sizeof(float2) * (size_t)p->max_wg * cfg.M);
-    if (cfg.fm) { ALLOC(p->d_rp[0], sizeof(float2) * cfg.C); ALLOC(p->d_rp[1], sizeof(float2) * cfg.C); }
+    ALLOC(p->d_wpre, sizeof(float2) * 2 * cfg.M);
+    for (int i = 0; i < 2; i++) {
+        ALLOC(p->d_yhist[i], sizeof(float2) * 13 * cfg.M);
+        ALLOC(p->d_vend[i], sizeof(float2));
+        ALLOC(p->d_rp[i], sizeof(float2) * cfg.C);
+    }
+    ALLOC(p->d_ticket, sizeof(unsigned));
+    ALLOC(p->d_status, sizeof(unsigned));
+    ALLOC(p->d_yflag, sizeof(unsigned) * p->max_nb);
+    ALLOC(p->d_agg, sizeof(u64) * 2 * p->max_nb);
+    ALLOC(p->d_ylast, sizeof(u64) * (size_t)cfg.M * p->max_nb);
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
 #undef ALLOC
     CSDR_HIP(hipMemcpy(p->d_taps, cfg.taps, sizeof(float) * cfg.M * cfg.p, hipMemcpyHostToDevice));
-    std::vector<float2> tw(cfg.M);
+    std::vector<float2> tw(cfg.M), wpre(2 * cfg.M);
     for (uint32_t i = 0; i < cfg.M; i++) {
         const double a = -2.0 * 3.14159265358979323846 * (double)i / (double)cfg.M;
         tw[i] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
-    CSDR_HIP(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * cfg.M, hipMemcpyHostToDevice));
-    p->tab_len = nco_period(cfg.d_theta, 1u << 17);
-    if (p->tab_len) {
-        std::vector<float2> tab(p->tab_len);
-        for (uint32_t i = 0; i < p->tab_len; i++) { float c, s; nco_phasor(i * cfg.d_theta, &c, &s); tab[i] = make_float2(c, s); }
-        hipError_t e = hipMalloc((void **)&p->d_nco_tab, sizeof(float2) * p->tab_len);
-        if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__));
-        CSDR_HIP(hipMemcpy(p->d_nco_tab, tab.data(), sizeof(float2) * p->tab_len, hipMemcpyHostToDevice));
+    // nco_crcf_mix_block_down multiplies by conj(cos + j sin) of theta = n*d_theta; for M = 256
+    // the phase sequence has period 2M: row 0 = even frames (n = j), row 1 = odd (n = M + j)
+    for (uint32_t i = 0; i < 2 * cfg.M; i++) {
+        float c, s;
+        nco_phasor(i * cfg.d_theta, &c, &s);
+        wpre[i] = make_float2(c, -s);
     }
+    CSDR_HIP(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * cfg.M, hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemcpy(p->d_wpre, wpre.data(), sizeof(float2) * 2 * cfg.M, hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemset(p->d_status, 0, sizeof(unsigned)));
+    CSDR_HIP(hipMemset(p->d_yflag, 0, sizeof(unsigned) * p->max_nb));
+    CSDR_HIP(hipMemset(p->d_agg, 0, sizeof(u64) * 2 * p->max_nb));
+
+    TileArgs &A = p->proto;
+    A = TileArgs{};
+    A.taps = p->d_taps; A.tw = p->d_tw; A.wpre = p->d_wpre;
+    A.ticket = p->d_ticket; A.agg = p->d_agg; A.ylast = p->d_ylast; A.yflag = p->d_yflag; A.status = p->d_status;
+    A.c0 = cfg.c0; A.C = cfg.C; A.fm_ref = cfg.fm_ref;
+    const double beta = cfg.dc_block ? (double)cfg.dc.beta : 0.0;
+    A.alpha = cfg.dc_block ? (float)(1.0 - beta) : 0.0f;    // alpha = 1 - beta with beta = f32(1 - 0.0005)
+    A.beta = (float)beta;
+    for (int k = 0; k < LOOKBACK + 2; k++) A.wtile[k] = (float)std::pow(beta, 4096.0 * k);
+    for (int k = 0; k < 16; k++) A.b16[k] = (float)std::pow(beta, 16.0 * k);
+    for (int k = 0; k < 17; k++) A.b256[k] = (float)std::pow(beta, 256.0 * k);
+    for (int k = 0; k < 16; k++) A.bj[k] = (float)std::pow(beta, (double)k);
     *out = p;
     return 0;
 }
 
 int fused_reset(FusedPlan *p, hipStream_t s)
 {
-    p->tab_pos = 0; p->rp_cur = 0;
-    CSDR_HIP(hipMemsetAsync(p->d_u, 0, sizeof(float2) * p->hist, s));
-    CSDR_HIP(hipMemsetAsync(p->d_dcstate, 0, sizeof(float2), s));
-    if (p->d_rp[0]) {
-        CSDR_HIP(hipMemsetAsync(p->d_rp[0], 0, sizeof(float2) * p->cfg.C, s));
-        CSDR_HIP(hipMemsetAsync(p->d_rp[1], 0, sizeof(float2) * p->cfg.C, s));
+    p->cur = 0; p->frames_done = 0;
+    for (int i = 0; i < 2; i++) {
+        CSDR_HIP(hipMemsetAsync(p->d_yhist[i], 0, sizeof(float2) * 13 * p->cfg.M, s));
+        CSDR_HIP(hipMemsetAsync(p->d_vend[i], 0, sizeof(float2), s));
+        CSDR_HIP(hipMemsetAsync(p->d_rp[i], 0, sizeof(float2) * p->cfg.C, s));
     }
     return 0;
 }
 
-int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s)
+int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *timer)
 {
     const FusedConfig &c = p->cfg;
-    const uint32_t nf = call.nf, nx = nf * c.M;
+    const uint32_t nf = call.nf;
     if (!nf) return 0;
     int r;
-    // stage 0 (separate pass for now): DC blocker + NCO pre-mix into u (history in front)
-    NcoParams nco{};
-    nco.theta0 = call.theta0; nco.d_theta = c.d_theta; nco.tab_len = p->tab_len; nco.tab_pos = p->tab_pos; nco.up = 0;
-    float2 *u_new = p->d_u + p->hist;
-    if ((r = launch_dc_mix(call.d_in, u_new, nx, c.dc_block, c.dc, p->d_dcstate, p->d_scratch, true, nco, p->d_nco_tab, s))) return r;
-    if (p->tab_len) p->tab_pos = (uint32_t)(((uint64_t)p->tab_pos + nx) % p->tab_len);
-
-    FusedArgs A{};
-    A.u = u_new; A.taps = p->d_taps; A.tw = p->d_tw;
+    TileArgs A = p->proto;
+    A.x = call.d_in;
     A.out = c.mix ? p->d_premix : call.d_out;
-    A.bound_first = p->d_bfirst; A.bound_last = p->d_blast;
-    A.nf = nf; A.run = pick_run(nf); A.c0 = c.c0; A.C = c.C; A.fm_ref = c.fm_ref;
-    const uint32_t nwg = (nf + A.run - 1) / A.run;
-    if (c.fm) {
-        hipLaunchKernelGGL(k_fused256<true>, dim3(nwg), dim3(256), 0, s, A);
-        hipLaunchKernelGGL(k_fm_fixup, dim3(nwg + 1), dim3(256), 0, s, p->d_bfirst, p->d_blast, p->d_rp[p->rp_cur],
-                           p->d_rp[p->rp_cur ^ 1], (float *)A.out, nf, A.run, nwg, c.c0, c.C, c.fm_ref);
-        p->rp_cur ^= 1;
-    } else {
-        hipLaunchKernelGGL(k_fused256<false>, dim3(nwg), dim3(256), 0, s, A);
-    }
+    A.yhist_in = p->d_yhist[p->cur]; A.yhist_out = p->d_yhist[p->cur ^ 1];
+    A.vend_in = p->d_vend[p->cur];   A.vend_out = p->d_vend[p->cur ^ 1];
+    A.rp_in = p->d_rp[p->cur];       A.rp_out = p->d_rp[p->cur ^ 1];
+    if (++p->epoch == 0) p->epoch = 1;
+    A.epoch = p->epoch; A.nf = nf; A.nb = (nf + NB - 1) / NB;
+    A.parity0 = (uint32_t)(p->frames_done & 1);
+    CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
+    if (timer && (r = timer->begin(s))) return r;
+    if (c.fm) hipLaunchKernelGGL(k_tile256<true>, dim3(A.nb), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL(k_tile256<false>, dim3(A.nb), dim3(256), 0, s, A);
+    if (timer && (r = timer->end(s))) return r;
     CSDR_HIP(hipGetLastError());
-    // keep the last (p-1) frames of premixed input as the next call's history
-    CSDR_HIP(hipMemcpyAsync(p->d_hist_tmp, p->d_u + nx, sizeof(float2) * p->hist, hipMemcpyDeviceToDevice, s));
-    CSDR_HIP(hipMemcpyAsync(p->d_u, p->d_hist_tmp, sizeof(float2) * p->hist, hipMemcpyDeviceToDevice, s));
+    p->cur ^= 1;
+    p->frames_done += nf;
     if (c.mix) {
         if ((r = launch_mix((const float *)p->d_premix, (float *)call.d_out, c.C, c.fm ? nf : 2 * nf, s))) return r;
     }
@@ -358,11 +572,17 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s)
 
 const char *fused_name(const FusedPlan *p) { return p->name.c_str(); }
 
+int fused_status(FusedPlan *p, unsigned *status)
+{
+    CSDR_HIP(hipMemcpy(status, p->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 void fused_destroy(FusedPlan *p)
 {
     if (!p) return;
-    void *ptrs[] = {p->d_taps, p->d_tw, p->d_u, p->d_hist_tmp, p->d_dcstate, p->d_scratch, p->d_nco_tab, p->d_bfirst,
-                    p->d_blast, p->d_rp[0], p->d_rp[1], p->d_premix};
+    void *ptrs[] = {p->d_taps, p->d_tw, p->d_wpre, p->d_yhist[0], p->d_yhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0],
+                    p->d_rp[1], p->d_ticket, p->d_yflag, p->d_status, p->d_agg, p->d_ylast, p->d_premix};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }

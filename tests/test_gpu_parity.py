@@ -261,3 +261,80 @@ def test_firpfbch_channelizer_pipe_splits_like_reference():
     assert len(outs[1]) == 1 and outs[1][0].size == 0            # Liquid.chs:856-862 on nx = 0
     want = O.Chan(M).process(x)
     assert rel_rms(np.stack(outs[0]), want) < 2e-6
+
+
+# --------------------------------------------------------------------------- fused M=256 kernel
+def test_fused256_ragged_chunks_and_state_carry():
+    """Chunks whose frame counts are not multiples of the 16-frame tile, shorter than the
+    13-frame FIR history, and longer than the look-back window, against the oracle."""
+    M = 256
+    nfs = [1, 5, 13, 16, 17, 3, 37, 200, 12, 400]
+    got, want, path = _chain_case(M, nfs)
+    assert path.startswith("fused")
+    r, e = rel_rms(got, want), max_abs_err(got, want)
+    print(f"fused ragged DeNo rel-rms {r:.3e} max-abs {e:.3e}")
+    assert r < 1e-5 and e < 1e-4 * np.abs(want).max()
+    got, want, _ = _chain_case(M, nfs, demod="fm", kf=0.3)
+    d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / 0.3))
+    print(f"fused ragged FM median {np.median(d):.3e} p99 {np.quantile(d, 0.99):.3e}")
+    assert np.median(d) < 2e-5 and np.quantile(d, 0.99) < 1e-3
+
+
+def test_fused256_reference_chunk_matches_oracle_and_generic():
+    """One reference-sized chunk (4096 frames = 256 tiles: every workgroup role, the full
+    look-back depth) and a second one for state carry; fused vs oracle vs the generic path."""
+    M, nf = 256, 4096
+    x = synth_cf32(2 * M * nf, M, seed=77)
+    from composable_sdr_amd import _lib
+    fused = cs.Chain(channels=M, demod="fm", kf=0.3, max_frames=nf)
+    gen = cs.Chain(channels=M, demod="fm", kf=0.3, max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_FORCE_GENERIC)
+    orc = O.Chain(M, demod="fm", kf=0.3)
+    assert fused.path.startswith("fused") and gen.path == "generic"
+    for i in range(2):
+        c = x[i * M * nf:(i + 1) * M * nf]
+        a, g, w = fused.process(c), gen.process(c), orc.process(c)
+        d = np.abs(wrap_pm(a.astype(np.float64) - w, 1.0 / 0.3))
+        dg = np.abs(wrap_pm(a.astype(np.float64) - g, 1.0 / 0.3))
+        tone = np.arange(M) % 4 == 1                         # channels that carry an FM tone
+        print(f"chunk {i}: fused-vs-oracle tone-ch max {d[tone].max():.3e} all median {np.median(d):.3e}; "
+              f"fused-vs-generic tone-ch max {dg[tone].max():.3e}")
+        assert d[tone].max() < 2e-5 and np.median(d) < 2e-5
+        assert dg[tone].max() < 2e-5
+
+
+def test_fused256_no_dc_block_and_shard():
+    M, nf = 256, 64
+    x = synth_cf32(M * nf, M, seed=5)
+    a = cs.Chain(channels=M, dc_block=False, max_frames=nf).process(x)
+    w = O.Chain(M, dc_block=False).process(x)
+    r = rel_rms(a, w)
+    print("fused no-DC rel-rms", r)
+    assert r < 1e-6                                           # without the DC blocker's f32 noise floor
+    part = cs.Chain(channels=M, chan_first=100, chan_count=56, max_frames=nf).process(x)
+    full = cs.Chain(channels=M, max_frames=nf).process(x)
+    assert np.array_equal(part, full[100:156])
+
+
+def test_fused256_dc_state_matches_long_stream():
+    """A strong DC offset makes the carried DC-blocker state matter: 64 chunks of 16 frames
+    must equal one chunk of 1024 frames (look-back across tiles == carry across calls)."""
+    M = 256
+    x = synth_cf32(M * 1024, M, seed=8, dc=0.3 + 0.2j)
+    one = cs.Chain(channels=M, max_frames=1024).process(x)
+    ch = cs.Chain(channels=M, max_frames=1024)
+    many = np.concatenate([ch.process(x[i * 16 * M:(i + 1) * 16 * M]) for i in range(64)], axis=1)
+    want = O.Chain(M).process(x)
+    # With |DC| = 0.36 the reference's filter state sits at |v| ~ 720 and its y = v0 - v1 carries
+    # ulp(720)/2 ~ 3e-5 of f32 cancellation noise; the HIP path evaluates y = x - alpha*v1 and is
+    # closer to exact arithmetic.  So: loose bound against the f32 oracle, tight bound against the
+    # oracle fed with an f64 DC blocker.
+    from scipy.signal import lfilter
+    beta = float(np.float32(1) - np.float32(0.0005))
+    yd = lfilter([1.0, -1.0], [1.0, -beta], x.astype(np.complex128)).astype(np.complex64)
+    want64 = O.Chain(M, dc_block=False).process(yd)
+    print("dc state: one-vs-many", rel_rms(one, many), "one-vs-oracle(f32 dc)", rel_rms(one, want),
+          "one-vs-oracle(f64 dc)", rel_rms(one, want64), "oracle f32-vs-f64", rel_rms(want, want64))
+    assert rel_rms(one, many) < 2e-6
+    assert rel_rms(one, want) < 2e-4
+    assert rel_rms(one, want64) < 2e-6
+    assert rel_rms(one, want64) < rel_rms(want, want64)
