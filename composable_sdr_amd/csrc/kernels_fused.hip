@@ -157,17 +157,12 @@ struct TileArgs {
     float bj[16];               // beta^i
 };
 
-// Stage one tile of raw samples into LDS (16-byte slots XOR-swizzled so that both the
-// run-major b128 accesses and the column-major b64 accesses are bank-conflict free) and run
-// the zero-state DC scan on it.  On return R holds z[n] = x[n] - alpha*s[n-1] (s = scan inside
-// the 16-sample run), E[q] the carry into run q from earlier runs of its frame, T[f] the
-// frame totals.  Ends with a barrier.
-__device__ __forceinline__ void stage_and_scan(const float4 *__restrict__ src, int nvalid, float2 *R, float2 *E,
-                                               float2 *T, const TileArgs &A, int tid)
+// Raw tile -> registers: 8 x 16 bytes per thread, addressed so that the LDS image below is
+// XOR-swizzled at 16-byte granularity (both the run-major b128 accesses and the column-major
+// b64 accesses are then bank-conflict free).
+__device__ __forceinline__ void tile_load(const float4 *__restrict__ src, int nvalid, float4 (&raw)[8], int tid)
 {
-    float4 *R4 = reinterpret_cast<float4 *>(R);
     const int wave = tid >> 6, lane = tid & 63;
-    float4 raw[8];
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const int slot = 64 * (it * 4 + wave) + lane;          // 16-byte slot in LDS
@@ -175,6 +170,16 @@ __device__ __forceinline__ void stage_and_scan(const float4 *__restrict__ src, i
         const int i = (slot & 7) ^ ((q >> 1) & 7);             // which 16-byte piece of the run
         raw[it] = ((q >> 4) < nvalid) ? src[8 * q + i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+}
+
+// Registers -> LDS, then the zero-state DC scan of the tile.  On return R holds
+// z[n] = x[n] - alpha*s[n-1] (s = scan inside the 16-sample run), E[q] the carry into run q from
+// earlier runs of its frame, T[f] the frame totals.  Ends with a barrier.
+__device__ __forceinline__ void stage_and_scan(const float4 (&raw)[8], float2 *R, float2 *E, float2 *T,
+                                               const TileArgs &A, int tid)
+{
+    float4 *R4 = reinterpret_cast<float4 *>(R);
+    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
     for (int it = 0; it < 8; it++) R4[64 * (it * 4 + wave) + lane] = raw[it];
     __syncthreads();
@@ -203,13 +208,29 @@ __device__ __forceinline__ void stage_and_scan(const float4 *__restrict__ src, i
     __syncthreads();
 }
 
+// Zero-state v before frame f of a tile, from its 16 frame totals: every 16-lane row runs the
+// same decayed DPP scan over T[0..15] and picks the entry of the frame before its own.
+__device__ __forceinline__ float2 frame_carry_zero_state(const float2 *T, const TileArgs &A, int tid)
+{
+    float2 s = T[tid & 15];
+    float2 t;
+    t = dpp2<0x111>(s); s = cfma(t, A.b256[1], s);
+    t = dpp2<0x112>(s); s = cfma(t, A.b256[2], s);
+    t = dpp2<0x114>(s); s = cfma(t, A.b256[4], s);
+    t = dpp2<0x118>(s); s = cfma(t, A.b256[8], s);
+    // lane r now holds v after frame r; I need v after frame (f-1), f = tid >> 4
+    const int f = (tid >> 4) & 15;
+    const int srcl = (tid & 48) | ((f - 1) & 15);
+    float2 r = make_float2(__shfl(s.x, srcl), __shfl(s.y, srcl));
+    return f ? r : make_float2(0.f, 0.f);
+}
+
 template <bool FM>
 __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
 {
     __shared__ __attribute__((aligned(16))) float2 R[LDS_F2];
     __shared__ float2 tw_s[M256];
     __shared__ float2 Tt[2][16];        // frame totals: [0] own, [1] halo
-    __shared__ float2 Vin[2][17];       // v before frame f (full, with tile carry); [16] = after the tile
     __shared__ float2 carry_s[2];       // c_b, c_{b-1}
     __shared__ unsigned tile_s;
 
@@ -224,8 +245,13 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
     float2 *E = R + E_OFF;
 
+    // ---------------- issue the global loads: own tile and the tile before it ----------------
+    float4 raw_o[8], raw_h[8];
+    tile_load(reinterpret_cast<const float4 *>(A.x) + (size_t)b * 2048, nvalid, raw_o, tid);
+    if (b > 0) tile_load(reinterpret_cast<const float4 *>(A.x) + (size_t)(b - 1) * 2048, 16, raw_h, tid);
+
     // ---------------- own tile: stage, scan, publish the aggregate ----------------
-    stage_and_scan(reinterpret_cast<const float4 *>(A.x) + (size_t)b * 2048, nvalid, R, E, Tt[0], A, tid);
+    stage_and_scan(raw_o, R, E, Tt[0], A, tid);
 
     float2 nw[NB], old[NB];
 #pragma unroll
@@ -236,8 +262,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         if (tid == 0) {
             float2 v = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int f = 0; f < 16; f++) { Vin[0][f] = v; v = cfma(v, A.b256[1], Tt[0][f]); }
-            Vin[0][16] = v;
+            for (int f = 0; f < 16; f++) v = cfma(v, A.b256[1], Tt[0][f]);
             __hip_atomic_store(&A.agg[2 * (size_t)b], ((u64)A.epoch << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&A.agg[2 * (size_t)b + 1], ((u64)A.epoch << 32) | __float_as_uint(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -280,48 +305,44 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
 
     // ---------------- halo: the 13 frames before the tile ----------------
     if (b > 0) {
-        stage_and_scan(reinterpret_cast<const float4 *>(A.x) + (size_t)(b - 1) * 2048, 16, R, E + 256, Tt[1], A, tid);
+        stage_and_scan(raw_h, R, E + 256, Tt[1], A, tid);
 #pragma unroll
         for (int f = 3; f < NB; f++) old[f] = R[256 * f + col_off];
     } else {
 #pragma unroll
         for (int f = 3; f < NB; f++) old[f] = A.yhist_in[(f - 3) * M256 + j];
     }
-    if (tid < 32) {
-        // full frame chains: Vin[g][f] = v before frame f including the tile carry
-        const int g = tid >> 4, f = tid & 15;
-        const float2 c = carry_s[g];
-        if (g == 0) {
-            Vin[0][f] = cfma(c, A.b256[f], Vin[0][f]);
-            if (f == 0) Vin[0][16] = cfma(c, A.b256[16], Vin[0][16]);
-        } else if (b > 0) {
-            float2 v = make_float2(0.f, 0.f);
-            for (int ff = 0; ff < f; ff++) v = cfma(v, A.b256[1], Tt[1][ff]);
-            Vin[1][f] = cfma(c, A.b256[f], v);
+
+    // ---------------- carry into every run: P[q] = beta^(16 r) * (v before frame f) + E[q] ----------------
+    {
+        const int fq = tid >> 4;
+        const float br = A.b16[tid & 15], bf = A.b256[fq];
+        const float2 v0 = cfma(carry_s[0], bf, frame_carry_zero_state(Tt[0], A, tid));
+        E[tid] = cfma(v0, br, E[tid]);
+        if (b > 0) {
+            const float2 v1 = cfma(carry_s[1], bf, frame_carry_zero_state(Tt[1], A, tid));
+            E[256 + tid] = cfma(v1, br, E[256 + tid]);
+        }
+        if (b == A.nb - 1 && tid == 16 * ((nvalid - 1) & 15) + 15) {
+            // DC blocker state after the last valid frame: v before it, advanced over that frame
+            // (the thread owning the frame's last run: v0 is v before frame nvalid-1)
+            A.vend_out[0] = cfma(v0, A.b256[1], Tt[0][nvalid - 1]);
         }
     }
     __syncthreads();
 
-    // ---------------- finish the DC blocker: y = z - alpha*beta^i * (carry into the run) ----------------
+    // ---------------- finish the DC blocker: y = z - alpha*beta^i * P[run] ----------------
     {
-        const float kj = A.alpha * A.bj[j & 15];
-        const float br = A.b16[j >> 4];
+        const float kj = -A.alpha * A.bj[j & 15];
 #pragma unroll
-        for (int f = 0; f < NB; f++) {
-            const float2 pc = cfma(Vin[0][f], br, E[16 * f + (j >> 4)]);
-            nw[f] = cfma(pc, -kj, nw[f]);
-        }
+        for (int f = 0; f < NB; f++) nw[f] = cfma(E[16 * f + (j >> 4)], kj, nw[f]);
         if (b > 0) {
 #pragma unroll
-            for (int f = 3; f < NB; f++) {
-                const float2 pc = cfma(Vin[1][f], br, E[256 + 16 * f + (j >> 4)]);
-                old[f] = cfma(pc, -kj, old[f]);
-            }
+            for (int f = 3; f < NB; f++) old[f] = cfma(E[256 + 16 * f + (j >> 4)], kj, old[f]);
         }
     }
     if (b == A.nb - 1) {
         // stream state for the next call: DC v1 after the last frame, the last 13 frames of y
-        if (tid == 0) A.vend_out[0] = Vin[0][nvalid];
         const int base = (int)A.nf - 13 - 16 * (int)b;        // tile-relative frame of yhist slot 0
 #pragma unroll
         for (int f = 3; f < NB; f++) {
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
             if (d >= 0 && d < 13 && f < nvalid) A.yhist_out[d * M256 + j] = nw[f];
         }
     }
-    __syncthreads();                                            // E / Vin consumed, R free
+    __syncthreads();                                            // P consumed, R free
 
     // ---------------- polyphase FIR + NCO pre-mix ----------------
     // u[t][j] = y[t][j] * wpre[parity(t)][j] and X_t[j] = sum_n h[(255-j)+256n] u[t-n][j]:
@@ -404,31 +425,35 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         if (tid == 0) __hip_atomic_store(&A.yflag[b], A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b == A.nb - 1 && owned) A.rp_out[tid - A.c0] = last;
 
+        float m[NB];
+        if (owned) {
+#pragma unroll
+            for (int f = 1; f < NB; f++) {
+                const float2 rp = v[f - 1], r = v[f];
+                // arg(conj(r') r): products rounded separately like the reference's C expression
+                const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
+                const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
+                m[f] = fast_atan2f(im, re) * A.fm_ref;
+            }
+        }
         float2 prev;
         if (b == 0) {
             prev = owned ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
         } else {
-            if (tid < 64) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(&A.yflag[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) {
-                    if (++spins > SPIN_LIMIT) { if (tid == 0) atomicOr(A.status, 2u); break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
+            unsigned spins = 0;
+            while (__hip_atomic_load(&A.yflag[b - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != A.epoch) {
+                if (++spins > SPIN_LIMIT) { if (tid == 0) atomicOr(A.status, 2u); break; }
+                __builtin_amdgcn_s_sleep(2);
             }
-            __syncthreads();
             const u64 pb = __hip_atomic_load(&A.ylast[(size_t)(b - 1) * M256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             prev = make_float2(__uint_as_float((unsigned)pb), __uint_as_float((unsigned)(pb >> 32)));
         }
         if (owned) {
-            float m[NB];
-#pragma unroll
-            for (int f = 0; f < NB; f++) {
-                const float2 r = v[f];
-                // arg(conj(r') r): products rounded separately like the reference's C expression
+            {
+                const float2 r = v[0];
                 const float re = __fadd_rn(__fmul_rn(prev.x, r.x), __fmul_rn(prev.y, r.y));
                 const float im = __fsub_rn(__fmul_rn(prev.x, r.y), __fmul_rn(prev.y, r.x));
-                m[f] = fast_atan2f(im, re) * A.fm_ref;
-                prev = r;
+                m[0] = fast_atan2f(im, re) * A.fm_ref;
             }
             float *o = (float *)A.out + row;
             if ((A.nf % 4u) == 0 && nvalid == NB) {
