@@ -62,6 +62,7 @@ SIGNATURES = {
     "csdr_chain_get_taps": (_i32, [_vp, _vp, _u32]),
     "csdr_chain_get_nco": (_i32, [_vp, _pu32, _pu32]),
     "csdr_chain_path": (C.c_char_p, [_vp]),
+    "csdr_chain_debug_trace": (_i32, [_vp, _vp, _u32]),
     "csdr_chain_kernel_time": (C.c_char_p, [_vp, C.POINTER(C.c_double), _pu32]),
 }
 

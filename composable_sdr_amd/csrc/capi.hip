@@ -538,6 +538,13 @@ int csdr_chain_get_nco(const csdr_chain *h, uint32_t *theta, uint32_t *d_theta)
     if (d_theta) *d_theta = h->d_theta;
     return CSDR_OK;
 }
+int csdr_chain_debug_trace(csdr_chain *h, unsigned long long *out, uint32_t ntiles)
+{
+    if (!h || !out) return CSDR_ERR_INVALID;
+    if (!h->fused) return 0;
+    (void)hipDeviceSynchronize();
+    return fused_trace(h->fused, out, ntiles);
+}
 const char *csdr_chain_path(const csdr_chain *h) { return h ? h->path.c_str() : ""; }
 
 const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *launches)

@@ -28,6 +28,8 @@ int  fused_process(FusedPlan *plan, const FusedCall &call, hipStream_t s, Kernel
 const char *fused_name(const FusedPlan *plan);
 // sticky device-side error word (bit0/bit1: an inter-workgroup wait hit its spin limit); synchronises
 int  fused_status(FusedPlan *plan, unsigned *status);
+// CSDR_TRACE=1: per-tile s_memtime stamps (16 per tile) of the last launches; returns tiles copied
+int  fused_trace(FusedPlan *plan, unsigned long long *out, uint32_t ntiles);
 void fused_destroy(FusedPlan *plan);
 
 }  // namespace csdr

@@ -33,6 +33,7 @@
 #include "fused.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace csdr {
@@ -52,6 +53,7 @@ constexpr int LOOKBACK = 10;     // tiles; beta^(4096*10) ~ 1.3e-9 for alpha = 0
 constexpr unsigned SPIN_LIMIT = 1u << 24;
 
 typedef unsigned long long u64;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -139,7 +141,7 @@ struct TileArgs {
     const float2 *x;            // new input, nf*256 samples
     void *out;                  // [C][nf] F32 (FM) or CF32
     const float *taps;          // [P][256] prototype taps h[i + n*256]
-    const float2 *tw;           // W256^i
+    const float2 *tw;           // pass-1 twiddles, tw[16*k1 + b1] = W256^(b1*k1)
     const float2 *wpre;         // [2][256]: conj(nco phasor) of column j for even / odd global frames
     const float2 *yhist_in; float2 *yhist_out;   // [13][256] DC-blocked samples before the call / after it
     const float2 *vend_in;  float2 *vend_out;    // DC blocker state v1
@@ -149,6 +151,7 @@ struct TileArgs {
     u64 *ylast;                 // [nb][256] last Y frame of each tile
     unsigned *yflag;            // [nb]
     unsigned *status;           // sticky error word (spin limit hit)
+    u64 *trace;                 // optional [nb][16] s_memtime stamps of thread 0 (CSDR_TRACE=1)
     uint32_t epoch, nf, nb, c0, C, parity0;
     float alpha, beta, fm_ref;
     float wtile[LOOKBACK + 2];  // beta^(4096 k)
@@ -225,6 +228,8 @@ __device__ __forceinline__ float2 frame_carry_zero_state(const float2 *T, const 
     return f ? r : make_float2(0.f, 0.f);
 }
 
+#define STAMP(i) do { if (A.trace && tid == 0) A.trace[(size_t)b * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 template <bool FM>
 __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
 {
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
     __syncthreads();
     const unsigned b = tile_s;
     if (b >= A.nb) return;
+    STAMP(0);   // ticket known
     const int nvalid = (int)min(16u, A.nf - 16u * b);
     const int j = tid;
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
@@ -252,6 +258,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
 
     // ---------------- own tile: stage, scan, publish the aggregate ----------------
     stage_and_scan(raw_o, R, E, Tt[0], A, tid);
+    STAMP(1);   // own tile loaded + scanned
 
     float2 nw[NB], old[NB];
 #pragma unroll
@@ -301,7 +308,9 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         cb = cadd(cb, dpp2<0x118>(cb)); cp = cadd(cp, dpp2<0x118>(cp));
         if (lane == 15) { carry_s[0] = cb; carry_s[1] = cp; }
     }
+    STAMP(2);   // look-back done (wave 0)
     __syncthreads();                                            // own z consumed; carries ready
+    STAMP(3);
 
     // ---------------- halo: the 13 frames before the tile ----------------
     if (b > 0) {
@@ -313,6 +322,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         for (int f = 3; f < NB; f++) old[f] = A.yhist_in[(f - 3) * M256 + j];
     }
 
+    STAMP(4);   // halo staged + scanned
     // ---------------- carry into every run: P[q] = beta^(16 r) * (v before frame f) + E[q] ----------------
     {
         const int fq = tid >> 4;
@@ -356,6 +366,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         }
     }
     __syncthreads();                                            // P consumed, R free
+    STAMP(5);   // DC blocker finished
 
     // ---------------- polyphase FIR + NCO pre-mix ----------------
     // u[t][j] = y[t][j] * wpre[parity(t)][j] and X_t[j] = sum_n h[(255-j)+256n] u[t-n][j]:
@@ -367,18 +378,21 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
 #pragma unroll
         for (int f = 0; f < NB; f++) {
-            float2 ev = make_float2(0.f, 0.f), od = make_float2(0.f, 0.f);
+            // complex x real multiply-accumulate as one packed f32 FMA per tap
+            v2f ev = {0.f, 0.f}, od = {0.f, 0.f};
 #pragma unroll
             for (int n = P - 1; n >= 0; n--) {
                 const int i = f - n;
-                const float2 s = (i >= 0) ? nw[i] : old[NB + i];
-                if (n & 1) od = cfma(s, h[n], od); else ev = cfma(s, h[n], ev);
+                const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
+                const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
+                if (n & 1) od = __builtin_elementwise_fma(sv, hv, od); else ev = __builtin_elementwise_fma(sv, hv, ev);
             }
-            const float2 xa = cmul(ev, (f & 1) ? Wb : Wa), xb = cmul(od, (f & 1) ? Wa : Wb);
+            const float2 xa = cmul(make_float2(ev.x, ev.y), (f & 1) ? Wb : Wa), xb = cmul(make_float2(od.x, od.y), (f & 1) ? Wa : Wb);
             R[f * FS_X + j] = cadd(xa, xb);
         }
     }
     __syncthreads();                                            // X complete
+    STAMP(6);   // FIR done
 
     // ---------------- DFT pass 1: thread (f, b1) ----------------
     float2 v[16];
@@ -388,12 +402,13 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         for (int a = 0; a < 16; a++) v[a] = R[f * FS_X + 16 * a + b1];
         fft16(v);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], tw_s[b1 * k1]);
+        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], tw_s[16 * k1 + b1]);
         __syncthreads();                                        // everyone has read X
 #pragma unroll
         for (int k1 = 0; k1 < 16; k1++) R[f * FS_Z + k1 * RS_Z + b1] = v[k1];
     }
     __syncthreads();                                            // Z complete
+    STAMP(7);   // pass 1 done
 
     // ---------------- DFT pass 2: thread (f, k1) ----------------
     {
@@ -406,6 +421,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         for (int k2 = 0; k2 < 16; k2++) R[(k1 + 16 * k2) * RS_Y + f] = v[k2];
     }
     __syncthreads();                                            // Y complete
+    STAMP(8);   // pass 2 done
 
     // ---------------- tail: thread k owns channel k ----------------
 #pragma unroll
@@ -424,6 +440,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         __syncthreads();
         if (tid == 0) __hip_atomic_store(&A.yflag[b], A.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (b == A.nb - 1 && owned) A.rp_out[tid - A.c0] = last;
+        STAMP(9);   // last frame published
 
         float m[NB];
         if (owned) {
@@ -448,6 +465,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
             const u64 pb = __hip_atomic_load(&A.ylast[(size_t)(b - 1) * M256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             prev = make_float2(__uint_as_float((unsigned)pb), __uint_as_float((unsigned)(pb >> 32)));
         }
+        STAMP(10);  // previous tile's last frame received
         if (owned) {
             {
                 const float2 r = v[0];
@@ -476,6 +494,278 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
             for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = v[f];
         }
     }
+    STAMP(11);  // stores issued
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Run kernel (large chunks): one workgroup walks a RUN of consecutive tiles.  The FIR window, the
+// DC-blocker state and the freqdem r' stay in registers from tile to tile, so there is no halo
+// re-staging, no look-back and no inter-workgroup hand-off at all; the price is a read-only
+// warm-up: the DC state at the run start is the decayed sum of the WU tiles before the run's
+// halo tile (beta^(4096*6) = 4.6e-6 of |v| ~ 40 is 9e-8 of the signal after the alpha factor).
+// The first freqdem output of every run but the first is finished by k_run_fixup.
+// ---------------------------------------------------------------------------------------------
+constexpr int WU = 6;
+
+struct RunArgs {
+    TileArgs t;
+    float2 *yfirst;             // [nruns][256] first Y frame of every run
+    uint32_t S;                 // tiles per run
+    float l2beta;               // log2(beta)
+};
+
+__device__ __forceinline__ float2 wg_sum(float2 v, float2 *red, int tid)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); }
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float2 r = cadd(cadd(red[0], red[1]), cadd(red[2], red[3]));
+    __syncthreads();
+    return r;
+}
+
+// v after frame 15 of a tile (zero state) from its frame totals; every lane gets the value
+__device__ __forceinline__ void frame_carries(const float2 *T, const TileArgs &A, int tid, float2 &before_mine, float2 &after_tile)
+{
+    float2 s = T[tid & 15];
+    float2 t;
+    t = dpp2<0x111>(s); s = cfma(t, A.b256[1], s);
+    t = dpp2<0x112>(s); s = cfma(t, A.b256[2], s);
+    t = dpp2<0x114>(s); s = cfma(t, A.b256[4], s);
+    t = dpp2<0x118>(s); s = cfma(t, A.b256[8], s);
+    const int f = (tid >> 4) & 15;
+    const int srcl = (tid & 48) | ((f - 1) & 15);
+    const float2 r = make_float2(__shfl(s.x, srcl), __shfl(s.y, srcl));
+    before_mine = f ? r : make_float2(0.f, 0.f);
+    const int endl = (tid & 48) | 15;
+    after_tile = make_float2(__shfl(s.x, endl), __shfl(s.y, endl));
+}
+
+template <bool FM>
+__global__ __launch_bounds__(256) void k_run256(RunArgs RA)
+{
+    const TileArgs &A = RA.t;
+    __shared__ __attribute__((aligned(16))) float2 R[LDS_F2];
+    __shared__ float2 tw_s[M256];
+    __shared__ float2 Tt[16];
+    __shared__ float2 red[4];
+
+    const int tid = threadIdx.x, j = tid;
+    const unsigned w = blockIdx.x;
+    const unsigned first = w * RA.S, last = min(first + RA.S, A.nb);     // tiles [first, last)
+    tw_s[tid] = A.tw[tid];
+    const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
+    float2 *E = R + E_OFF;
+    const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
+
+    float2 old[NB], nw[NB];
+#pragma unroll
+    for (int f = 0; f < NB; f++) old[f] = make_float2(0.f, 0.f);
+    float2 c;                                   // DC state v before the next tile (same in every lane)
+    float4 raw[8];
+
+    if (w == 0) {
+        c = A.vend_in[0];
+#pragma unroll
+        for (int f = 3; f < NB; f++) old[f] = A.yhist_in[(f - 3) * M256 + j];
+        __syncthreads();
+    } else {
+        // ---- warm-up: DC state before the halo tile (first-1) from the tiles before it ----
+        const unsigned halo = first - 1;
+        const unsigned h0 = halo > (unsigned)WU ? halo - WU : 0u;
+        float w0[8], w1[8];
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
+                const int i = (slot & 7) ^ ((q >> 1) & 7);
+                const int n = 16 * q + 2 * i;                       // sample index inside the tile
+                w0[it] = exp2f((float)(4095 - n) * RA.l2beta);
+                w1[it] = exp2f((float)(4094 - n) * RA.l2beta);
+            }
+        }
+        float2 acc = make_float2(0.f, 0.f);
+        for (unsigned t = h0; t < halo; t++) {
+            tile_load(x4 + (size_t)t * 2048, 16, raw, tid);
+            float2 p = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                p = cfma(make_float2(raw[it].x, raw[it].y), w0[it], p);
+                p = cfma(make_float2(raw[it].z, raw[it].w), w1[it], p);
+            }
+            acc = cfma(acc, A.b256[16], p);
+        }
+        float2 ch = wg_sum(acc, red, tid);                          // also orders tw_s
+        if (h0 == 0) ch = cfma(A.vend_in[0], exp2f((float)(4096u * halo) * RA.l2beta), ch);
+        // ---- halo tile: stage, scan, finish -> old[3..15]; its end state starts the run ----
+        tile_load(x4 + (size_t)halo * 2048, 16, raw, tid);
+        stage_and_scan(raw, R, E, Tt, A, tid);
+#pragma unroll
+        for (int f = 3; f < NB; f++) old[f] = R[256 * f + col_off];
+        const float kj = -A.alpha * A.bj[j & 15];
+        const float br = A.b16[tid & 15], bf = A.b256[tid >> 4];
+        float2 vb, ve;
+        frame_carries(Tt, A, tid, vb, ve);
+        E[tid] = cfma(cfma(ch, bf, vb), br, E[tid]);
+        c = cfma(ch, A.b256[16], ve);
+        __syncthreads();
+#pragma unroll
+        for (int f = 3; f < NB; f++) old[f] = cfma(E[16 * f + (j >> 4)], kj, old[f]);
+        __syncthreads();
+    }
+
+    const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
+    float2 prev = (w == 0 && owned) ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
+    float2 lastY = make_float2(0.f, 0.f);
+
+    tile_load(x4 + (size_t)first * 2048, (int)min(16u, A.nf - 16u * first), raw, tid);
+    for (unsigned b = first; b < last; b++) {
+        const int nvalid = (int)min(16u, A.nf - 16u * b);
+        // keep the per-phase LDS address arithmetic inside the iteration: hoisted out of the tile
+        // loop it would pin >100 VGPRs and halve the occupancy
+        int tid_i = tid;
+        asm volatile("" : "+v"(tid_i));
+        const int j_i = tid_i;
+        const int col_off_i = 16 * (j_i >> 4) + 2 * (((j_i & 15) >> 1) ^ (j_i >> 5)) + (j_i & 1);
+        // ---- stage + scan this tile, prefetch the next one ----
+        stage_and_scan(raw, R, E, Tt, A, tid_i);
+        if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, (int)min(16u, A.nf - 16u * (b + 1)), raw, tid_i);
+#pragma unroll
+        for (int f = 0; f < NB; f++) nw[f] = R[256 * f + col_off_i];
+        const float kj = -A.alpha * A.bj[j_i & 15];
+        const float br = A.b16[tid_i & 15], bf = A.b256[tid_i >> 4];
+        float2 vb, ve;
+        frame_carries(Tt, A, tid_i, vb, ve);
+        const float2 v0 = cfma(c, bf, vb);                          // v before my run's frame
+        E[tid_i] = cfma(v0, br, E[tid_i]);
+        if (b == A.nb - 1 && tid_i == 16 * ((nvalid - 1) & 15) + 15) A.vend_out[0] = cfma(v0, A.b256[1], Tt[nvalid - 1]);
+        c = cfma(c, A.b256[16], ve);
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < NB; f++) nw[f] = cfma(E[16 * f + (j_i >> 4)], kj, nw[f]);
+        if (b == A.nb - 1) {
+            const int base = (int)A.nf - 13 - 16 * (int)b;
+#pragma unroll
+            for (int f = 3; f < NB; f++) {
+                const int d = (f - 16) - base;
+                if (d >= 0 && d < 13) A.yhist_out[d * M256 + j_i] = old[f];
+            }
+#pragma unroll
+            for (int f = 0; f < NB; f++) {
+                const int d = f - base;
+                if (d >= 0 && d < 13 && f < nvalid) A.yhist_out[d * M256 + j_i] = nw[f];
+            }
+        }
+        __syncthreads();                                            // P consumed, R free
+
+        // ---- polyphase FIR + NCO pre-mix ----
+        float h[P];
+#pragma unroll
+        for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j_i) + n * M256];
+        const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j_i], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j_i];
+#pragma unroll
+        for (int f = 0; f < NB; f++) {
+            v2f ev = {0.f, 0.f}, od = {0.f, 0.f};
+#pragma unroll
+            for (int n = P - 1; n >= 0; n--) {
+                const int i = f - n;
+                const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
+                const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
+                if (n & 1) od = __builtin_elementwise_fma(sv, hv, od); else ev = __builtin_elementwise_fma(sv, hv, ev);
+            }
+            const float2 xa = cmul(make_float2(ev.x, ev.y), (f & 1) ? Wb : Wa), xb = cmul(make_float2(od.x, od.y), (f & 1) ? Wa : Wb);
+            R[f * FS_X + j_i] = cadd(xa, xb);
+        }
+#pragma unroll
+        for (int f = 3; f < NB; f++) old[f] = nw[f];                // next tile's window
+        __syncthreads();                                            // X complete
+
+        float2 v[16];
+        {
+            const int f = tid_i >> 4, b1 = tid_i & 15;
+#pragma unroll
+            for (int a = 0; a < 16; a++) v[a] = R[f * FS_X + 16 * a + b1];
+            fft16(v);
+#pragma unroll
+            for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], tw_s[16 * k1 + b1]);
+            __syncthreads();                                        // everyone has read X
+#pragma unroll
+            for (int k1 = 0; k1 < 16; k1++) R[f * FS_Z + k1 * RS_Z + b1] = v[k1];
+        }
+        __syncthreads();                                            // Z complete
+        {
+            const int f = tid_i >> 4, k1 = tid_i & 15;
+#pragma unroll
+            for (int b1 = 0; b1 < 16; b1++) v[b1] = R[f * FS_Z + k1 * RS_Z + b1];
+            fft16(v);
+            __syncthreads();                                        // everyone has read Z
+#pragma unroll
+            for (int k2 = 0; k2 < 16; k2++) R[(k1 + 16 * k2) * RS_Y + f] = v[k2];
+        }
+        __syncthreads();                                            // Y complete
+
+        // ---- tail: thread k owns channel k ----
+#pragma unroll
+        for (int f = 0; f < NB; f++) v[f] = R[tid_i * RS_Y + f];
+        const size_t row = (size_t)(owned ? tid_i - A.c0 : 0) * A.nf + (size_t)16 * b;
+        if (FM) {
+            if (b == first && w > 0) RA.yfirst[(size_t)w * M256 + tid_i] = v[0];
+            float2 lv = v[0];
+#pragma unroll
+            for (int f = 1; f < NB; f++) if (f < nvalid) lv = v[f];
+            if (owned) {
+                float m[NB];
+#pragma unroll
+                for (int f = 0; f < NB; f++) {
+                    const float2 rp = f ? v[f - 1] : prev, r = v[f];
+                    const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
+                    const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
+                    m[f] = fast_atan2f(im, re) * A.fm_ref;
+                }
+                float *o = (float *)A.out + row;
+                if ((A.nf % 4u) == 0 && nvalid == NB) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = m[f];
+                }
+            }
+            prev = lv; lastY = lv;
+        } else if (owned) {
+            float2 *o = (float2 *)A.out + row;
+            if ((A.nf % 2u) == 0 && nvalid == NB) {
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    *reinterpret_cast<float4 *>(o + 2 * q) = make_float4(v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y);
+            } else {
+#pragma unroll
+                for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = v[f];
+            }
+        }
+        __syncthreads();                                            // Y consumed, R free
+    }
+    if (FM) {
+        reinterpret_cast<float2 *>(A.ylast)[(size_t)w * M256 + tid] = lastY;
+        if (last == A.nb && owned) A.rp_out[tid - A.c0] = lastY;
+    }
+}
+
+// first freqdem sample of every run w >= 1: needs the last frame of run w-1
+__global__ __launch_bounds__(256) void k_run_fixup(const float2 *__restrict__ yfirst, const float2 *__restrict__ ylast,
+                                                   float *__restrict__ out, uint32_t nf, uint32_t S, uint32_t c0, uint32_t C,
+                                                   float ref)
+{
+    const uint32_t k = threadIdx.x, w = blockIdx.x + 1;
+    if (k < c0 || k >= c0 + C) return;
+    const float2 r = yfirst[(size_t)w * M256 + k], rp = ylast[(size_t)(w - 1) * M256 + k];
+    const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
+    const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
+    out[(size_t)(k - c0) * nf + (size_t)16 * S * w] = fast_atan2f(im, re) * ref;
 }
 
 }  // namespace
@@ -492,6 +782,10 @@ struct FusedPlan {
     unsigned *d_ticket = nullptr, *d_yflag = nullptr, *d_status = nullptr;
     u64 *d_agg = nullptr, *d_ylast = nullptr;
     void *d_premix = nullptr;    // per-channel output before mixing
+    u64 *d_trace = nullptr;
+    float2 *d_yfirst = nullptr;
+    uint32_t run_min_tiles = 8192;   // chunks with at least this many tiles use the run kernel
+    uint32_t resident_wgs = 512;     // workgroups of k_run256 the device holds at once
     TileArgs proto;
 };
 
@@ -501,7 +795,7 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
 {
     FusedPlan *p = new FusedPlan();
     p->cfg = cfg;
-    p->name = cfg.fm ? "k_tile256<FM>" : "k_tile256<CF32>";
+    p->name = cfg.fm ? "k_run256|k_tile256<FM>" : "k_run256|k_tile256<CF32>";
     p->max_nb = (cfg.max_nf + NB - 1) / NB;
     auto fail = [&](int r) { fused_destroy(p); return r; };
 #define ALLOC(ptr, bytes) do { hipError_t e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 1); if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__)); } while (0)
@@ -518,14 +812,18 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     ALLOC(p->d_yflag, sizeof(unsigned) * p->max_nb);
     ALLOC(p->d_agg, sizeof(u64) * 2 * p->max_nb);
     ALLOC(p->d_ylast, sizeof(u64) * (size_t)cfg.M * p->max_nb);
+    ALLOC(p->d_yfirst, sizeof(float2) * (size_t)cfg.M * (p->max_nb / 8 + 2));
+    if (const char *e = getenv("CSDR_RUN_MIN_TILES")) p->run_min_tiles = (uint32_t)atol(e);
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
+    if (getenv("CSDR_TRACE")) { ALLOC(p->d_trace, sizeof(u64) * 16 * p->max_nb); CSDR_HIP(hipMemset(p->d_trace, 0, sizeof(u64) * 16 * p->max_nb)); }
 #undef ALLOC
     CSDR_HIP(hipMemcpy(p->d_taps, cfg.taps, sizeof(float) * cfg.M * cfg.p, hipMemcpyHostToDevice));
     std::vector<float2> tw(cfg.M), wpre(2 * cfg.M);
-    for (uint32_t i = 0; i < cfg.M; i++) {
-        const double a = -2.0 * 3.14159265358979323846 * (double)i / (double)cfg.M;
-        tw[i] = make_float2((float)std::cos(a), (float)std::sin(a));
-    }
+    for (uint32_t k1 = 0; k1 < 16; k1++)
+        for (uint32_t b1 = 0; b1 < 16; b1++) {
+            const double a = -2.0 * 3.14159265358979323846 * (double)(b1 * k1) / (double)cfg.M;
+            tw[16 * k1 + b1] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
     // nco_crcf_mix_block_down multiplies by conj(cos + j sin) of theta = n*d_theta; for M = 256
     // the phase sequence has period 2M: row 0 = even frames (n = j), row 1 = odd (n = M + j)
     for (uint32_t i = 0; i < 2 * cfg.M; i++) {
@@ -543,7 +841,7 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     A = TileArgs{};
     A.taps = p->d_taps; A.tw = p->d_tw; A.wpre = p->d_wpre;
     A.ticket = p->d_ticket; A.agg = p->d_agg; A.ylast = p->d_ylast; A.yflag = p->d_yflag; A.status = p->d_status;
-    A.c0 = cfg.c0; A.C = cfg.C; A.fm_ref = cfg.fm_ref;
+    A.c0 = cfg.c0; A.C = cfg.C; A.fm_ref = cfg.fm_ref; A.trace = p->d_trace;
     const double beta = cfg.dc_block ? (double)cfg.dc.beta : 0.0;
     A.alpha = cfg.dc_block ? (float)(1.0 - beta) : 0.0f;    // alpha = 1 - beta with beta = f32(1 - 0.0005)
     A.beta = (float)beta;
@@ -551,6 +849,16 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     for (int k = 0; k < 16; k++) A.b16[k] = (float)std::pow(beta, 16.0 * k);
     for (int k = 0; k < 17; k++) A.b256[k] = (float)std::pow(beta, 256.0 * k);
     for (int k = 0; k < 16; k++) A.bj[k] = (float)std::pow(beta, (double)k);
+    {
+        int dev = 0, cus = 256, occ = 2;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (cfg.fm) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run256<true>, 256, 0);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run256<false>, 256, 0);
+        if (occ < 1) occ = 1;
+        p->resident_wgs = (uint32_t)(cus * occ);
+        if (const char *e = getenv("CSDR_RESIDENT_WGS")) p->resident_wgs = (uint32_t)atol(e);
+    }
     *out = p;
     return 0;
 }
@@ -581,11 +889,28 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     if (++p->epoch == 0) p->epoch = 1;
     A.epoch = p->epoch; A.nf = nf; A.nb = (nf + NB - 1) / NB;
     A.parity0 = (uint32_t)(p->frames_done & 1);
-    CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
-    if (timer && (r = timer->begin(s))) return r;
-    if (c.fm) hipLaunchKernelGGL(k_tile256<true>, dim3(A.nb), dim3(256), 0, s, A);
-    else hipLaunchKernelGGL(k_tile256<false>, dim3(A.nb), dim3(256), 0, s, A);
-    if (timer && (r = timer->end(s))) return r;
+    if (A.nb >= p->run_min_tiles) {
+        // large chunk: dependency-free runs of S tiles (S >= 8 keeps the warm-up reads <= 7/8 of a run)
+        RunArgs RA{};
+        RA.t = A; RA.yfirst = p->d_yfirst;
+        // one workgroup per resident slot (a single round, no tail): S = ceil(nb / resident), >= 8
+        RA.S = (A.nb + p->resident_wgs - 1) / p->resident_wgs; if (RA.S < 8) RA.S = 8;
+        RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;
+        const uint32_t nruns = (A.nb + RA.S - 1) / RA.S;
+        if (timer && (r = timer->begin(s))) return r;
+        if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), 0, s, RA);
+        else hipLaunchKernelGGL(k_run256<false>, dim3(nruns), dim3(256), 0, s, RA);
+        if (timer && (r = timer->end(s))) return r;
+        if (c.fm && nruns > 1)
+            hipLaunchKernelGGL(k_run_fixup, dim3(nruns - 1), dim3(256), 0, s, p->d_yfirst, (const float2 *)p->d_ylast,
+                               (float *)A.out, nf, RA.S, c.c0, c.C, c.fm_ref);
+    } else {
+        CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
+        if (timer && (r = timer->begin(s))) return r;
+        if (c.fm) hipLaunchKernelGGL(k_tile256<true>, dim3(A.nb), dim3(256), 0, s, A);
+        else hipLaunchKernelGGL(k_tile256<false>, dim3(A.nb), dim3(256), 0, s, A);
+        if (timer && (r = timer->end(s))) return r;
+    }
     CSDR_HIP(hipGetLastError());
     p->cur ^= 1;
     p->frames_done += nf;
@@ -597,6 +922,14 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
 
 const char *fused_name(const FusedPlan *p) { return p->name.c_str(); }
 
+int fused_trace(FusedPlan *p, unsigned long long *out, uint32_t ntiles)
+{
+    if (!p->d_trace) return 0;
+    if (ntiles > p->max_nb) ntiles = p->max_nb;
+    CSDR_HIP(hipMemcpy(out, p->d_trace, sizeof(u64) * 16 * ntiles, hipMemcpyDeviceToHost));
+    return (int)ntiles;
+}
+
 int fused_status(FusedPlan *p, unsigned *status)
 {
     CSDR_HIP(hipMemcpy(status, p->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -607,7 +940,7 @@ void fused_destroy(FusedPlan *p)
 {
     if (!p) return;
     void *ptrs[] = {p->d_taps, p->d_tw, p->d_wpre, p->d_yhist[0], p->d_yhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0],
-                    p->d_rp[1], p->d_ticket, p->d_yflag, p->d_status, p->d_agg, p->d_ylast, p->d_premix};
+                    p->d_rp[1], p->d_ticket, p->d_yflag, p->d_status, p->d_agg, p->d_ylast, p->d_premix, p->d_trace, p->d_yfirst};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }

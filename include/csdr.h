@@ -163,6 +163,11 @@ const char *csdr_chain_path(const csdr_chain *h);                  /* "fused-...
  * since the last call (synchronises the stream).  Returns the kernel's name. */
 const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *launches);
 
+/* Diagnostics: with CSDR_TRACE=1 in the environment at create time the fused kernel records 16
+ * s_memtime stamps per 16-frame tile; copies the stamps of the first `ntiles` tiles of the last
+ * launch into out[ntiles][16] and returns the number of tiles copied (0 when tracing is off). */
+int  csdr_chain_debug_trace(csdr_chain *h, unsigned long long *out, uint32_t ntiles);
+
 #ifdef __cplusplus
 }
 #endif

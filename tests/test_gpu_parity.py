@@ -338,3 +338,34 @@ def test_fused256_dc_state_matches_long_stream():
     assert rel_rms(one, want) < 2e-4
     assert rel_rms(one, want64) < 2e-6
     assert rel_rms(one, want64) < rel_rms(want, want64)
+
+
+def test_fused256_run_kernel_matches_tile_kernel_and_oracle(monkeypatch):
+    """Large chunks use the dependency-free run kernel (k_run256); force it on a small chunk
+    (CSDR_RUN_MIN_TILES) and compare with the look-back tile kernel and the oracle, including a
+    ragged tail and state carry into a second call."""
+    M = 256
+    nfs = [16 * 40 + 5, 16 * 9, 300]
+    x = synth_cf32(M * sum(nfs), M, seed=31, dc=0.05 + 0.02j)
+    for demod in ("none", "fm"):
+        monkeypatch.setenv("CSDR_RUN_MIN_TILES", "1")
+        run = cs.Chain(channels=M, demod=demod, kf=0.3, max_frames=max(nfs))
+        monkeypatch.setenv("CSDR_RUN_MIN_TILES", "1000000")
+        tile = cs.Chain(channels=M, demod=demod, kf=0.3, max_frames=max(nfs))
+        orc = O.Chain(M, demod=demod, kf=0.3)
+        pos = 0
+        for nf in nfs:
+            c = x[pos:pos + nf * M]
+            pos += nf * M
+            a, t, w = run.process(c), tile.process(c), orc.process(c)
+            if demod == "fm":
+                d = np.abs(wrap_pm(a.astype(np.float64) - t, 1.0 / 0.3))
+                dw = np.abs(wrap_pm(a.astype(np.float64) - w, 1.0 / 0.3))
+                tone = np.arange(M) % 4 == 1
+                print(f"run-vs-tile FM nf={nf}: tone max {d[tone].max():.3e} median {np.median(d):.3e}; vs oracle tone max {dw[tone].max():.3e}")
+                assert d[tone].max() < 5e-6 and np.median(d) < 5e-6
+                assert dw[tone].max() < 2e-5
+            else:
+                print(f"run-vs-tile DeNo nf={nf}: rel-rms {rel_rms(a, t):.3e}; vs oracle {rel_rms(a, w):.3e}")
+                assert rel_rms(a, t) < 1e-6
+                assert rel_rms(a, w) < 1e-5
