@@ -385,18 +385,24 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
     if (cfg->agc_threshold_db != 0.0f && (r = dev_alloc(&h->d_agc, C))) return fail(r);
     if (cfg->demod == CSDR_DEMOD_FM && ((r = dev_alloc(&h->d_rp[0], C)) || (r = dev_alloc(&h->d_rp[1], C)))) return fail(r);
 
-    // Path selection: fused kernels cover power-of-two M without AGC; everything else
-    // (and anything with the sequential AGC tail) runs the generic multi-kernel path.
-    h->use_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && fused_supported(M, h->p) &&
-                   cfg->agc_threshold_db == 0.0f;
+    // Path selection: the fused kernels cover M = 256 (DC blocker + pre-mix + PFB [+ freqdem]).
+    // With the AGC on, the fused kernel stops at the channel-major CF32 samples and the
+    // exactly-sequential per-channel AGC tail (one lane per channel) + freqdem + mix follow.
+    h->use_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && fused_supported(M, h->p);
     if (h->use_fused) {
+        const bool agc_on = cfg->agc_threshold_db != 0.0f;
         FusedConfig fc{};
         fc.M = M; fc.p = h->p; fc.C = C; fc.c0 = c0; fc.max_nf = h->max_nf;
-        fc.dc_block = cfg->dc_block != 0; fc.dc = h->dc; fc.fm = cfg->demod == CSDR_DEMOD_FM; fc.fm_ref = h->fm_ref;
-        fc.mix = cfg->mix != 0; fc.taps = h->taps.data(); fc.d_theta = h->d_theta;
+        fc.dc_block = cfg->dc_block != 0; fc.dc = h->dc;
+        fc.fm = cfg->demod == CSDR_DEMOD_FM && !agc_on; fc.fm_ref = h->fm_ref;
+        fc.mix = cfg->mix != 0 && !agc_on; fc.taps = h->taps.data(); fc.d_theta = h->d_theta;
         if ((r = fused_create(fc, &h->fused))) return fail(r);
-        h->path = std::string("fused-") + fused_name(h->fused);
+        h->path = std::string("fused-") + fused_name(h->fused) + (agc_on ? "+agc-tail" : "");
         h->timed_kernel = fused_name(h->fused);
+        if (agc_on && (cfg->demod == CSDR_DEMOD_FM || cfg->mix)) {
+            if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf))) return fail(r);
+            if (cfg->demod == CSDR_DEMOD_FM && cfg->mix && (r = dev_alloc(&h->d_B, (size_t)C * h->max_nf))) return fail(r);
+        }
     } else {
         h->path = "generic";
         h->timed_kernel = M > 1 ? "k_pfb_fir" : "k_dc_apply";
@@ -476,10 +482,23 @@ int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, vo
     const uint32_t nf = n_in / h->M;
     int r;
     if (h->use_fused) {
+        const bool agc_on = h->d_agc != nullptr, fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix != 0;
+        float2 *Z = (agc_on && (fm || mixo)) ? h->d_A : (float2 *)d_out;
         FusedCall fcall{};
-        fcall.d_in = (const float2 *)d_in; fcall.d_out = d_out; fcall.nf = nf; fcall.theta0 = h->theta;
+        fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
         h->theta += n_in * h->d_theta;
+        if (agc_on) {
+            if ((r = launch_agc(Z, h->C, nf, h->d_agc, h->agc, s))) return r;
+            if (fm) {
+                float *F = mixo ? (float *)h->d_B : (float *)d_out;
+                if ((r = launch_fm(Z, F, h->C, nf, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s))) return r;
+                h->rp_cur ^= 1;
+                if (mixo && (r = launch_mix(F, (float *)d_out, h->C, nf, s))) return r;
+            } else if (mixo) {
+                if ((r = launch_mix((const float *)Z, (float *)d_out, h->C, 2 * nf, s))) return r;
+            }
+        }
     } else {
         if ((r = chain_generic(h, (const float2 *)d_in, n_in, d_out, s))) return r;
     }

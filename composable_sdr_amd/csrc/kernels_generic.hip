@@ -325,29 +325,32 @@ int launch_agc_init(AgcState *st, uint32_t C, hipStream_t s)
 
 __device__ __forceinline__ float2 agc_step(float2 x, AgcState &q, const AgcParams &p)
 {
+    // agc_crcf_execute: y = x*g ; y2' <- (1-alpha) y2' + alpha |y|^2 ; g <- g * exp(-alpha/2 * ln y2') ;
+    // the dependent chain is what bounds this kernel, so the gain update uses the hardware
+    // log2/exp2 (1 ulp) instead of libm's expf/logf: g*2^(-alpha/2 * log2 y2') is the same function.
     float2 y = make_float2(x.x * q.g, x.y * q.g);
     const float y2 = __fadd_rn(__fmul_rn(y.x, y.x), __fmul_rn(y.y, y.y));
-    // (1.0 - alpha)*y2' + alpha*y2 : evaluated in f64 like the C expression
-    q.y2 = (float)((1.0 - (double)p.alpha) * (double)q.y2 + (double)__fmul_rn(p.alpha, y2));
-    if (q.y2 > 1e-6f) q.g *= expf(-0.5f * p.alpha * logf(q.y2));
-    if (q.g > 1e6f) q.g = 1e6f;
+    q.y2 = fmaf(1.0f - p.alpha, q.y2, p.alpha * y2);
+    const float upd = __builtin_amdgcn_exp2f((-0.5f * p.alpha) * __builtin_amdgcn_logf(q.y2));
+    q.g = (q.y2 > 1e-6f) ? q.g * upd : q.g;
+    q.g = fminf(q.g, 1e6f);
     const bool ex = q.g < p.g_thr;                    // rssi > threshold
-    switch (q.mode) {
-    case 1: q.mode = ex ? 2 : 1; break;               // ENABLED
-    case 2: q.mode = ex ? 3 : 4; break;               // RISE
-    case 3: q.mode = ex ? 3 : 4; break;               // SIGNALHI
-    case 4: q.mode = ex ? 3 : 5; q.timer = p.timeout; break;   // FALL
-    case 5:                                           // SIGNALLO
-        q.timer--;
-        if (q.timer == 0) q.mode = 6; else if (ex) q.mode = 3;
-        break;
-    case 6: q.mode = 1; break;                        // TIMEOUT
-    default: break;
-    }
-    if (q.mode != 3) y = make_float2(0.f, 0.f);       // reference mute rule (Liquid.chs:703-704)
+    // squelch state machine (agc_crcf_squelch_update_mode), modes 1..6
+    int m = q.mode;
+    const bool lo_to = (m == 5) && (q.timer == 1u);
+    q.timer = (m == 4) ? p.timeout : ((m == 5) ? q.timer - 1u : q.timer);
+    const int nxt_ex = (m == 1) ? 2 : ((m == 6) ? 1 : 3);                 // threshold exceeded
+    const int nxt_no = (m == 1) ? 1 : ((m == 4) ? 5 : ((m == 5) ? 5 : ((m == 6) ? 1 : 4)));
+    m = ex ? nxt_ex : nxt_no;
+    m = lo_to ? 6 : m;
+    q.mode = m;
+    if (m != 3) y = make_float2(0.f, 0.f);            // reference mute rule (Liquid.chs:703-704)
     return y;
 }
 
+// One lane per channel; each lane streams its row in blocks of 16 samples (128 B = one cache
+// line per lane and block), the next block's loads in flight while the current one runs through
+// the recurrence, so the loop is bound by the AGC's dependent chain and not by memory latency.
 __global__ __launch_bounds__(64) void k_agc(float2 *__restrict__ Z, uint32_t C, uint32_t nf,
                                             AgcState *__restrict__ st, AgcParams p)
 {
@@ -355,7 +358,32 @@ __global__ __launch_bounds__(64) void k_agc(float2 *__restrict__ Z, uint32_t C, 
     if (c >= C) return;
     AgcState q = st[c];
     float2 *row = Z + (uint64_t)c * nf;
-    for (uint32_t t = 0; t < nf; t++) row[t] = agc_step(row[t], q, p);
+    const bool vec = ((uint64_t)c * nf) % 2 == 0;            // 16-byte aligned row start
+    uint32_t t = 0;
+    if (vec && nf >= 16) {
+        float4 cur[8], nxt[8];
+        const float4 *r4 = reinterpret_cast<const float4 *>(row);
+#pragma unroll
+        for (int i = 0; i < 8; i++) cur[i] = r4[i];
+        for (; t + 16 <= nf; t += 16) {
+            const bool more = t + 32 <= nf;
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) nxt[i] = r4[(t + 16) / 2 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float2 a = agc_step(make_float2(cur[i].x, cur[i].y), q, p);
+                const float2 b = agc_step(make_float2(cur[i].z, cur[i].w), q, p);
+                reinterpret_cast<float4 *>(row)[t / 2 + i] = make_float4(a.x, a.y, b.x, b.y);
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) cur[i] = nxt[i];
+            }
+        }
+    }
+    for (; t < nf; t++) row[t] = agc_step(row[t], q, p);
     st[c] = q;
 }
 

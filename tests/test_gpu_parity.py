@@ -159,7 +159,7 @@ def test_chain_fm_matches_oracle(M):
         assert d[strong].max() < 2e-5
 
 
-@pytest.mark.parametrize("M", [8, 64])
+@pytest.mark.parametrize("M", [8, 64, 256])
 def test_chain_agc_fm_matches_oracle(M):
     kf = 0.3
     # threshold between tone channels (PFB gain ~M on a 0.5/sqrt(M/4) tone) and noise-only ones
