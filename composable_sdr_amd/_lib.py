@@ -57,6 +57,7 @@ SIGNATURES = {
     "csdr_chain_process": (_i32, [_vp, _vp, _u32, _vp, _pu32]),
     "csdr_chain_process_device": (_i32, [_vp, _vp, _u32, _vp, _pu32, _vp]),
     "csdr_chain_reset": (_i32, [_vp]),
+    "csdr_chain_seek_frames": (_i32, [_vp, C.c_uint64]),
     "csdr_chain_destroy": (_i32, [_vp]),
     "csdr_chain_out_elem_size": (_u32, [_vp]),
     "csdr_chain_get_taps": (_i32, [_vp, _vp, _u32]),

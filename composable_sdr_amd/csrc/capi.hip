@@ -543,6 +543,17 @@ int csdr_chain_reset(csdr_chain *h)
     return CSDR_OK;
 }
 
+int csdr_chain_seek_frames(csdr_chain *h, uint64_t frames)
+{
+    int r = csdr_chain_reset(h);
+    if (r) return r;
+    const uint64_t n = frames * (uint64_t)h->M;
+    h->theta = (uint32_t)(n * (uint64_t)h->d_theta);
+    if (h->tab_len) h->tab_pos = (uint32_t)(n % h->tab_len);
+    if (h->fused) fused_seek(h->fused, frames);
+    return CSDR_OK;
+}
+
 int csdr_chain_get_taps(const csdr_chain *h, float *taps, uint32_t n)
 {
     if (!h || !taps) return CSDR_ERR_INVALID;

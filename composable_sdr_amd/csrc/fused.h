@@ -26,6 +26,7 @@ int  fused_create(const FusedConfig &cfg, FusedPlan **out);
 int  fused_reset(FusedPlan *plan, hipStream_t s);
 int  fused_process(FusedPlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
 const char *fused_name(const FusedPlan *plan);
+void fused_seek(FusedPlan *plan, uint64_t frames);   // after fused_reset: global frame index of the next frame
 // sticky device-side error word (bit0/bit1: an inter-workgroup wait hit its spin limit); synchronises
 int  fused_status(FusedPlan *plan, unsigned *status);
 // CSDR_TRACE=1: per-tile s_memtime stamps (16 per tile) of the last launches; returns tiles copied

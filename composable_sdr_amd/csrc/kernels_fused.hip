@@ -921,6 +921,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
 }
 
 const char *fused_name(const FusedPlan *p) { return p->name.c_str(); }
+void fused_seek(FusedPlan *p, uint64_t frames) { p->frames_done = frames; }
 
 int fused_trace(FusedPlan *p, unsigned long long *out, uint32_t ntiles)
 {

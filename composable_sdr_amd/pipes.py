@@ -235,6 +235,10 @@ class Chain:
     def reset(self):
         check(lib().csdr_chain_reset(self.h))
 
+    def seek_frames(self, frames):
+        """reset, then continue as if `frames` frames of the stream had already gone by"""
+        check(lib().csdr_chain_seek_frames(self.h, int(frames)))
+
     def close(self):
         self._h.close()
 

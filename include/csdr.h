@@ -151,6 +151,10 @@ int  csdr_chain_process(csdr_chain *h, const float *in_cf32, uint32_t n_in, void
 int  csdr_chain_process_device(csdr_chain *h, const void *d_in_cf32, uint32_t n_in,
                                void *d_out, uint32_t *n_out, void *stream);
 int  csdr_chain_reset(csdr_chain *h);      /* back to the state right after create        */
+/* Reset, then place the stream position at frame `frames` (n = frames*channels samples in):
+ * the NCO pre-mix phase becomes what it would be there.  Used by time-striped multi-GPU runs,
+ * where a rank starts in the middle of the stream behind a warm-up prefix. */
+int  csdr_chain_seek_frames(csdr_chain *h, uint64_t frames);
 int  csdr_chain_destroy(csdr_chain *h);
 
 /* introspection used by the tests (mirrors what firpfbch_crcf_print / nco_crcf_print

@@ -369,3 +369,39 @@ def test_fused256_run_kernel_matches_tile_kernel_and_oracle(monkeypatch):
                 print(f"run-vs-tile DeNo nf={nf}: rel-rms {rel_rms(a, t):.3e}; vs oracle {rel_rms(a, w):.3e}")
                 assert rel_rms(a, t) < 1e-6
                 assert rel_rms(a, w) < 1e-5
+
+
+# --------------------------------------------------------------------------- sharding on the HIP chain
+@pytest.mark.parametrize("mode", ["time", "channel"])
+def test_sharded_two_ranks_on_one_gpu(mode):
+    """The partitions of composable_sdr_amd.sharded driven rank by rank on one GPU (the gloo
+    world-2 CPU test covers the collectives): stripes / channel shards reassemble the stream."""
+    from composable_sdr_amd.pipes import ChainConfig
+    from composable_sdr_amd.sharded import ShardedChain
+    M, nf = 256, 1200
+    x = synth_cf32(M * nf, M, seed=17)
+    cfg = ChainConfig(channels=M, demod="none", max_frames=512)
+    want = cs.Chain(cfg).process(x[:M * 512])
+    full = np.concatenate([cs.Chain(channels=M, max_frames=nf).process(x)], axis=1)
+    parts = [ShardedChain(cfg, mode=mode, rank=r, world=2).process_stream(x) for r in range(2)]
+    got = np.concatenate(parts, axis=1 if mode == "time" else 0)
+    assert got.shape == full.shape
+    print(mode, "sharded vs single rel-rms", rel_rms(got, full))
+    assert rel_rms(got, full) < (2e-6 if mode == "time" else 1e-7)
+    assert np.array_equal(want, full[:, :512]) or rel_rms(want, full[:, :512]) < 1e-6
+
+
+def test_seek_frames_sets_premix_phase():
+    M = 256
+    x = synth_cf32(M * 80, M, seed=23)
+    ref = cs.Chain(channels=M, dc_block=False, max_frames=80).process(x)
+    ch = cs.Chain(channels=M, dc_block=False, max_frames=80)
+    ch.seek_frames(33)                                  # odd frame: the pre-mix phasor row flips
+    got = ch.process(x[33 * M:])
+    # after the 13-frame FIR transient the outputs coincide with the un-seeked stream
+    assert rel_rms(got[:, 14:], ref[:, 33 + 14:]) < 1e-6
+    gen = cs.Chain(channels=20, dc_block=False, max_frames=80)   # generic path, non-periodic NCO
+    x20 = synth_cf32(20 * 80, 20, seed=24)
+    ref20 = cs.Chain(channels=20, dc_block=False, max_frames=80).process(x20)
+    gen.seek_frames(33)
+    assert rel_rms(gen.process(x20[33 * 20:])[:, 14:], ref20[:, 33 + 14:]) < 1e-6

@@ -1,0 +1,96 @@
+"""Host-side combinators (composable_sdr_amd/trans.py) against the semantics of
+/root/reference/src/ComposableSDR/Trans.hs and Types.hs (cited per test)."""
+import numpy as np
+
+from composable_sdr_amd.pipes import Pipe, compose
+from composable_sdr_amd.trans import addPipe, collect, compact, distribute_, mix, mux, takeNArr
+
+
+def _arr(a, b):
+    return np.arange(a, b, dtype=np.float32)
+
+
+def test_takeNArr_trims_the_last_array_and_stops():          # Trans.hs:33-56
+    src = [_arr(0, 4), _arr(4, 8), _arr(8, 12)]
+    out = list(takeNArr(6, src))
+    assert [len(a) for a in out] == [4, 2] and np.array_equal(np.concatenate(out), _arr(0, 6))
+    assert [len(a) for a in takeNArr(8, src)] == [4, 4]      # exact boundary: third array not emitted
+    assert list(takeNArr(0, src)) == []
+    assert [len(a) for a in takeNArr(100, src)] == [4, 4, 4]
+
+
+def test_compact_emits_exactly_n_and_flushes_remainder():    # Trans.hs:58-84
+    sink = collect()
+    f = compact(5, sink)
+    for a in (_arr(0, 3), _arr(3, 6), _arr(6, 7), _arr(7, 13)):
+        f.step(a)
+    f.done()
+    lens = [len(a) for a in sink.items]
+    # 3 (buffer) -> 6: emit 5 keep 1 -> 7: keep 2 -> 13: emit 5 keep 3 ; done: flush 3
+    assert lens == [5, 5, 3]
+    assert np.array_equal(np.concatenate(sink.items), _arr(0, 13))
+    # an input larger than 2n emits n and keeps the (>= n) rest until the next step / done
+    sink = collect()
+    f = compact(4, sink)
+    f.step(_arr(0, 11))
+    f.done()
+    assert [len(a) for a in sink.items] == [4, 7]
+    # empty remainder is still pushed downstream at end of stream (Trans.hs:66-68)
+    sink = collect()
+    f = compact(4, sink)
+    f.step(_arr(0, 4))
+    f.done()
+    assert [len(a) for a in sink.items] == [4, 0]
+
+
+def test_mix_is_left_fold_and_mux_keeps_per_channel_state():  # Trans.hs:119-129
+    chans = [np.float32([1e8, 1.0]), np.float32([-1e8, 1.0]), np.float32([1.0, 1.0])]
+    out = mix._process(None, chans)
+    assert np.array_equal(out, np.float32([1.0, 3.0]))        # ((1e8 + -1e8) + 1), not 1e8 + (-1e8 + 1)
+    starts = []
+
+    def counter():
+        st = {"n": 0}
+        starts.append(st)
+        return st
+
+    def proc(st, a):
+        st["n"] += len(a)
+        return a + st["n"]
+    p = Pipe(counter, proc, lambda st: st.update(done=True))
+    m = mux([p, p, p])                                        # replicate nch demod: same Pipe VALUE
+    r = m._start()
+    assert len(starts) == 3                                   # but one state per channel (Trans.hs:127)
+    o1 = m._process(r, [_arr(0, 2), _arr(0, 3), _arr(0, 1)])
+    o2 = m._process(r, [_arr(0, 2), _arr(0, 3), _arr(0, 1)])
+    assert [st["n"] for st in starts] == [4, 6, 2]
+    assert np.array_equal(o2[1], _arr(0, 3) + 6) and np.array_equal(o1[2], _arr(0, 1) + 1)
+    m._done(r)
+    assert all(st.get("done") for st in starts)
+
+
+def test_compose_order_and_addPipe_lifecycle():                # Types.hs:93-131
+    log = []
+    a = Pipe(lambda: log.append("startA") or "A", lambda r, x: x + 1, lambda r: log.append("doneA"))
+    b = Pipe(lambda: log.append("startB") or "B", lambda r, x: x * 2, lambda r: log.append("doneB"))
+    c = compose(a, b)                                         # a . b : b first, then a
+    r = c._start()
+    assert c._process(r, np.float32([1, 2])).tolist() == [3.0, 5.0]
+    c._done(r)
+    assert log == ["startA", "startB", "doneB", "doneA"]
+    assert (a @ b)._process((None, None), np.float32([1])).tolist() == [3.0]
+    sink = collect()
+    f = addPipe(b, sink)
+    f.step(np.float32([1, 2])).step(np.float32([3]))
+    f.done()
+    assert [x.tolist() for x in sink.items] == [[2.0, 4.0], [6.0]]
+
+
+def test_distribute_routes_channel_k_to_sink_k():              # Trans.hs:106-117, SoapySDR.hs:209-212
+    sinks = [collect() for _ in range(3)]
+    d = distribute_(sinks)
+    d.step([_arr(0, 2), _arr(10, 12), _arr(20, 22)])
+    d.step([_arr(2, 4)])                                      # a single (empty-chunk) element reaches sink 1 only
+    d.done()
+    assert np.array_equal(sinks[0].concat(), _arr(0, 4))
+    assert np.array_equal(sinks[1].concat(), _arr(10, 12)) and np.array_equal(sinks[2].concat(), _arr(20, 22))
