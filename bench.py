@@ -98,6 +98,7 @@ def main():
     out = torch.empty(M * nf * out_elem // 4, dtype=torch.float32, device=dev)
     chain = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, max_frames=nf, device=local,
                      flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
+    chain.seek_frames(rank * a.steps * nf)      # rank r's stripe of one long stream
     stream = torch.cuda.current_stream().cuda_stream
 
     def step(i):

@@ -9,4 +9,4 @@ from .pipes import (  # noqa: F401
     Pipe, compose, Chain, ChainConfig, dcBlocker, mixDown, mixUp, automaticGainControl,
     fmDemodulator, firpfbchChannelizer,
 )
-from .trans import compact, takeNArr, mix, mux, distribute_  # noqa: F401
+from .trans import compact, takeNArr, mix, mux, distribute_, addPipe  # noqa: F401

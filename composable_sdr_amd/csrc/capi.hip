@@ -397,7 +397,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
         fc.fm = cfg->demod == CSDR_DEMOD_FM && !agc_on; fc.fm_ref = h->fm_ref;
         fc.mix = cfg->mix != 0 && !agc_on; fc.taps = h->taps.data(); fc.d_theta = h->d_theta;
         if ((r = fused_create(fc, &h->fused))) return fail(r);
-        h->path = std::string("fused-") + fused_name(h->fused) + (agc_on ? "+agc-tail" : "");
+        h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (agc_on ? "+agc-tail" : "");
         h->timed_kernel = fused_name(h->fused);
         if (agc_on && (cfg->demod == CSDR_DEMOD_FM || cfg->mix)) {
             if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf))) return fail(r);
@@ -584,6 +584,7 @@ const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *la
     if (total_ms) *total_ms = h->timer.acc_ms;
     if (launches) *launches = h->timer.launches;
     h->timer.acc_ms = 0.0; h->timer.launches = 0;
+    if (h->fused) h->timed_kernel = fused_name(h->fused);      // the kernel the last call launched
     return h->timed_kernel.c_str();
 }
 

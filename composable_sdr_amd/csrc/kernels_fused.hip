@@ -795,7 +795,7 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
 {
     FusedPlan *p = new FusedPlan();
     p->cfg = cfg;
-    p->name = cfg.fm ? "k_run256|k_tile256<FM>" : "k_run256|k_tile256<CF32>";
+    p->name = cfg.fm ? "k_tile256<FM>" : "k_tile256<CF32>";
     p->max_nb = (cfg.max_nf + NB - 1) / NB;
     auto fail = [&](int r) { fused_destroy(p); return r; };
 #define ALLOC(ptr, bytes) do { hipError_t e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 1); if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__)); } while (0)
@@ -891,6 +891,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     A.parity0 = (uint32_t)(p->frames_done & 1);
     if (A.nb >= p->run_min_tiles) {
         // large chunk: dependency-free runs of S tiles (S >= 8 keeps the warm-up reads <= 7/8 of a run)
+        p->name = c.fm ? "k_run256<FM>" : "k_run256<CF32>";
         RunArgs RA{};
         RA.t = A; RA.yfirst = p->d_yfirst;
         // one workgroup per resident slot (a single round, no tail): S = ceil(nb / resident), >= 8
@@ -905,6 +906,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
             hipLaunchKernelGGL(k_run_fixup, dim3(nruns - 1), dim3(256), 0, s, p->d_yfirst, (const float2 *)p->d_ylast,
                                (float *)A.out, nf, RA.S, c.c0, c.C, c.fm_ref);
     } else {
+        p->name = c.fm ? "k_tile256<FM>" : "k_tile256<CF32>";
         CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
         if (timer && (r = timer->begin(s))) return r;
         if (c.fm) hipLaunchKernelGGL(k_tile256<true>, dim3(A.nb), dim3(256), 0, s, A);

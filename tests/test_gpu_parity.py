@@ -405,3 +405,35 @@ def test_seek_frames_sets_premix_phase():
     ref20 = cs.Chain(channels=20, dc_block=False, max_frames=80).process(x20)
     gen.seek_frames(33)
     assert rel_rms(gen.process(x20[33 * 20:])[:, 14:], ref20[:, 33 + 14:]) < 1e-6
+
+
+# --------------------------------------------------------------------------- file-in / file-out replay
+def test_sdr_process_example3_shape(tmp_path):
+    """README Example 3 scaled by 1/25: -n 640000 -c 20 --demod DeNo -> 20 files of n/20 samples
+    x 8 bytes, 'no samples are lost' (KAT4), contents equal to the oracle's."""
+    from composable_sdr_amd.app import sdr_process
+    M, n = 20, 640000
+    x = synth_cf32(n + 777, M, seed=3)                       # file longer than -n: takeNArr trims
+    src = tmp_path / "input.cf32"
+    x.tofile(src)
+    names = sdr_process(str(src), channels=M, demod="none", numsamples=n, outname=str(tmp_path / "output"), chunksize=1000)
+    assert len(names) == M and names[0].endswith("output_ch1.cf32") and names[-1].endswith("output_ch20.cf32")
+    want = O.Chain(M).process(x[:n])
+    for k, nm in enumerate(names):
+        got = np.fromfile(nm, dtype=np.complex64)
+        assert got.nbytes == n // M * 8 == 256000
+        # per-file error against the stream-wide scale (noise-only channels are 20 dB below the tones)
+        assert max_abs_err(got, want[k]) < 1e-4 * np.abs(want).max()
+        assert np.sqrt(np.mean(np.abs(got - want[k]) ** 2)) < 1e-5 * np.sqrt(np.mean(np.abs(want) ** 2))
+
+
+def test_sdr_process_fm_mix_single_output(tmp_path):
+    from composable_sdr_amd.app import sdr_process
+    M, n = 256, 256 * 4096 + 256 * 100
+    x = synth_cf32(n, M, seed=4)
+    src = tmp_path / "in.cf32"
+    x.tofile(src)
+    names = sdr_process(str(src), channels=M, demod="fm", kf=0.3, mix=True, numsamples=n, outname=str(tmp_path / "o"))
+    assert names == [str(tmp_path / "o.f32")]
+    got = np.fromfile(names[0], dtype=np.float32)
+    assert got.size == n // M                                 # one mixed stream of n/M samples

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Copies the judged artefacts of a tools/profile.sh run into profiles/ and updates
+profiles/traffic.json (per-launch HBM bytes of the dominant kernel from the PMC passes).
+
+    tools/collect_profile.py gpurun_out/prof_TAG rNN [M nf]
+
+FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 derived counters).  On gfx950 FETCH_SIZE reports
+half of the bytes of a wide (16 B/lane) coalesced stream (MI355X_MICROARCH.md, section HBM): the
+staging loads of k_run256/k_tile256 are exactly that pattern, so reads are doubled; WRITE_SIZE is
+taken as reported (uncalibrated)."""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+from collections import defaultdict
+
+src, tag = sys.argv[1], sys.argv[2]
+M = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+nf = int(sys.argv[4]) if len(sys.argv) > 4 else 262144
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+summary = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), src], capture_output=True, text=True).stdout
+bench_line = ""
+tl = os.path.join(src, "trace.log")
+if os.path.exists(tl):
+    for line in open(tl):
+        if line.startswith('{"metric"'):
+            bench_line = line.strip()
+with open(os.path.join(dst, f"{tag}_rocprofv3_summary.txt"), "w") as f:
+    f.write(f"# rocprofv3 --kernel-trace --stats / --pmc passes of: python3 bench.py --steps 5 --warmup 1 "
+            f"--no-cpu-baseline --no-agc-variant   (tools/profile.sh)\n# bench line of the traced run:\n# {bench_line}\n\n")
+    f.write(summary)
+for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+
+vals = defaultdict(dict)
+for sub in ("pmc3", "pmc4"):
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        acc = defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            acc[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
+        for (k, c), v in acc.items():
+            vals[k][c] = sum(v) / len(v)
+tj_path = os.path.join(dst, "traffic.json")
+tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+for k, c in vals.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c and ("k_run256" in k or "k_tile256" in k):
+        short = "k_run256" if "k_run256" in k else "k_tile256"
+        short += "<FM>" if "<true>" in k or "ILb1" in k else "<CF32>"
+        rd, wr = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024
+        tj[f"{short}|M={M}|nf={nf}"] = {
+            "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
+            "fetch_size_kib_raw": c["FETCH_SIZE"], "write_size_kib_raw": c["WRITE_SIZE"],
+            "note": "FETCH_SIZE x2 (gfx950 wide-load under-count), WRITE_SIZE as reported", "source": f"profiles/{tag}_rocprofv3_summary.txt"}
+json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
+print(open(os.path.join(dst, f"{tag}_rocprofv3_summary.txt")).read()[:1500])
+print(json.dumps(tj, indent=1))
