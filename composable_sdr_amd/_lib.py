@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libcsdr_hip.so")
+_SO = os.environ.get("CSDR_LIB") or os.path.join(_HERE, "libcsdr_hip.so")   # CSDR_LIB: A/B builds
 
 DEMOD_NONE, DEMOD_FM = 0, 1
 FLAG_TIME_KERNELS, FLAG_FORCE_GENERIC, FLAG_QUIET = 1, 2, 4

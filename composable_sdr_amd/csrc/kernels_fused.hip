@@ -153,6 +153,7 @@ struct TileArgs {
     unsigned *status;           // sticky error word (spin limit hit)
     u64 *trace;                 // optional [nb][16] s_memtime stamps of thread 0 (CSDR_TRACE=1)
     uint32_t epoch, nf, nb, c0, C, parity0;
+    uint32_t out_stride, out_t0;   // output row length (frames of the whole call) and this launch's first frame in it
     float alpha, beta, fm_ref;
     float wtile[LOOKBACK + 2];  // beta^(4096 k)
     float b16[16];              // beta^(16 r)
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
 #pragma unroll
     for (int f = 0; f < NB; f++) v[f] = R[tid * RS_Y + f];
     const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
-    const size_t row = (size_t)(owned ? tid - A.c0 : 0) * A.nf + (size_t)16 * b;
+    const size_t row = (size_t)(owned ? tid - A.c0 : 0) * A.out_stride + A.out_t0 + (size_t)16 * b;
 
     if (FM) {
         // publish my last valid frame for the next tile, then fetch the previous tile's
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
                 m[0] = fast_atan2f(im, re) * A.fm_ref;
             }
             float *o = (float *)A.out + row;
-            if ((A.nf % 4u) == 0 && nvalid == NB) {
+            if (((A.out_stride | A.out_t0) % 4u) == 0 && nvalid == NB) {
 #pragma unroll
                 for (int q = 0; q < 4; q++)
                     *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
         }
     } else if (owned) {
         float2 *o = (float2 *)A.out + row;
-        if ((A.nf % 2u) == 0 && nvalid == NB) {
+        if (((A.out_stride | A.out_t0) % 2u) == 0 && nvalid == NB) {
 #pragma unroll
             for (int q = 0; q < 8; q++)
                 *reinterpret_cast<float4 *>(o + 2 * q) = make_float4(v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y);
@@ -617,13 +618,18 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
         __syncthreads();
     }
 
+    {   // the window holds pre-mixed samples u = y * conj(nco): frame f of the previous tile has f's parity
+        const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
+#pragma unroll
+        for (int f = 3; f < NB; f++) old[f] = cmul(old[f], (f & 1) ? Wb : Wa);
+    }
     const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
     float2 prev = (w == 0 && owned) ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
-    float2 lastY = make_float2(0.f, 0.f);
+    const bool vec_out = ((A.out_stride | A.out_t0) % 4u) == 0;
 
-    tile_load(x4 + (size_t)first * 2048, (int)min(16u, A.nf - 16u * first), raw, tid);
+    tile_load(x4 + (size_t)first * 2048, 16, raw, tid);
     for (unsigned b = first; b < last; b++) {
-        const int nvalid = (int)min(16u, A.nf - 16u * b);
+        // every tile of a run is a full tile (the host hands ragged tails to k_tile256).
         // keep the per-phase LDS address arithmetic inside the iteration: hoisted out of the tile
         // loop it would pin >100 VGPRs and halve the occupancy
         int tid_i = tid;
@@ -632,56 +638,51 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
         const int col_off_i = 16 * (j_i >> 4) + 2 * (((j_i & 15) >> 1) ^ (j_i >> 5)) + (j_i & 1);
         // ---- stage + scan this tile, prefetch the next one ----
         stage_and_scan(raw, R, E, Tt, A, tid_i);
-        if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, (int)min(16u, A.nf - 16u * (b + 1)), raw, tid_i);
 #pragma unroll
         for (int f = 0; f < NB; f++) nw[f] = R[256 * f + col_off_i];
         const float kj = -A.alpha * A.bj[j_i & 15];
         const float br = A.b16[tid_i & 15], bf = A.b256[tid_i >> 4];
         float2 vb, ve;
         frame_carries(Tt, A, tid_i, vb, ve);
-        const float2 v0 = cfma(c, bf, vb);                          // v before my run's frame
-        E[tid_i] = cfma(v0, br, E[tid_i]);
-        if (b == A.nb - 1 && tid_i == 16 * ((nvalid - 1) & 15) + 15) A.vend_out[0] = cfma(v0, A.b256[1], Tt[nvalid - 1]);
+        E[tid_i] = cfma(cfma(c, bf, vb), br, E[tid_i]);
         c = cfma(c, A.b256[16], ve);
         __syncthreads();
+        // ---- finish the DC blocker and apply the NCO pre-mix (nco_crcf_mix_block_down) ----
+        {
+            const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j_i], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j_i];
 #pragma unroll
-        for (int f = 0; f < NB; f++) nw[f] = cfma(E[16 * f + (j_i >> 4)], kj, nw[f]);
-        if (b == A.nb - 1) {
-            const int base = (int)A.nf - 13 - 16 * (int)b;
+            for (int f = 0; f < NB; f++) nw[f] = cfma(E[16 * f + (j_i >> 4)], kj, nw[f]);
+            if (b + 1 == A.nb) {                                    // the stream's last 13 frames of y
 #pragma unroll
-            for (int f = 3; f < NB; f++) {
-                const int d = (f - 16) - base;
-                if (d >= 0 && d < 13) A.yhist_out[d * M256 + j_i] = old[f];
+                for (int f = 3; f < NB; f++) A.yhist_out[(f - 3) * M256 + j_i] = nw[f];
             }
 #pragma unroll
-            for (int f = 0; f < NB; f++) {
-                const int d = f - base;
-                if (d >= 0 && d < 13 && f < nvalid) A.yhist_out[d * M256 + j_i] = nw[f];
-            }
+            for (int f = 0; f < NB; f++) nw[f] = cmul(nw[f], (f & 1) ? Wb : Wa);
         }
         __syncthreads();                                            // P consumed, R free
 
-        // ---- polyphase FIR + NCO pre-mix ----
-        float h[P];
+        // ---- polyphase FIR on the pre-mixed window, oldest tap first ----
+        {
+            float h[P];
 #pragma unroll
-        for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j_i) + n * M256];
-        const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j_i], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j_i];
+            for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j_i) + n * M256];
 #pragma unroll
-        for (int f = 0; f < NB; f++) {
-            v2f ev = {0.f, 0.f}, od = {0.f, 0.f};
+            for (int f = 0; f < NB; f++) {
+                v2f acc = {0.f, 0.f};
 #pragma unroll
-            for (int n = P - 1; n >= 0; n--) {
-                const int i = f - n;
-                const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
-                const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
-                if (n & 1) od = __builtin_elementwise_fma(sv, hv, od); else ev = __builtin_elementwise_fma(sv, hv, ev);
+                for (int n = P - 1; n >= 0; n--) {
+                    const int i = f - n;
+                    const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
+                    const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
+                    acc = __builtin_elementwise_fma(sv, hv, acc);
+                }
+                R[f * FS_X + j_i] = make_float2(acc.x, acc.y);
             }
-            const float2 xa = cmul(make_float2(ev.x, ev.y), (f & 1) ? Wb : Wa), xb = cmul(make_float2(od.x, od.y), (f & 1) ? Wa : Wb);
-            R[f * FS_X + j_i] = cadd(xa, xb);
         }
 #pragma unroll
         for (int f = 3; f < NB; f++) old[f] = nw[f];                // next tile's window
         __syncthreads();                                            // X complete
+        if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, 16, raw, tid_i);
 
         float2 v[16];
         {
@@ -710,48 +711,46 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
         // ---- tail: thread k owns channel k ----
 #pragma unroll
         for (int f = 0; f < NB; f++) v[f] = R[tid_i * RS_Y + f];
-        const size_t row = (size_t)(owned ? tid_i - A.c0 : 0) * A.nf + (size_t)16 * b;
+        const size_t row = (size_t)(owned ? tid_i - A.c0 : 0) * A.out_stride + A.out_t0 + (size_t)16 * b;
         if (FM) {
             if (b == first && w > 0) RA.yfirst[(size_t)w * M256 + tid_i] = v[0];
-            float2 lv = v[0];
-#pragma unroll
-            for (int f = 1; f < NB; f++) if (f < nvalid) lv = v[f];
             if (owned) {
+                float *o = (float *)A.out + row;
                 float m[NB];
 #pragma unroll
                 for (int f = 0; f < NB; f++) {
                     const float2 rp = f ? v[f - 1] : prev, r = v[f];
-                    const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
-                    const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
+                    const float re = fmaf(rp.x, r.x, rp.y * r.y);
+                    const float im = fmaf(rp.x, r.y, -(rp.y * r.x));
                     m[f] = fast_atan2f(im, re) * A.fm_ref;
                 }
-                float *o = (float *)A.out + row;
-                if ((A.nf % 4u) == 0 && nvalid == NB) {
+                if (vec_out) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+                    for (int q = 0; q < 4; q++) *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
                 } else {
 #pragma unroll
-                    for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = m[f];
+                    for (int f = 0; f < NB; f++) o[f] = m[f];
                 }
             }
-            prev = lv; lastY = lv;
+            prev = v[NB - 1];
         } else if (owned) {
             float2 *o = (float2 *)A.out + row;
-            if ((A.nf % 2u) == 0 && nvalid == NB) {
+            if (vec_out) {
 #pragma unroll
                 for (int q = 0; q < 8; q++)
                     *reinterpret_cast<float4 *>(o + 2 * q) = make_float4(v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y);
             } else {
 #pragma unroll
-                for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = v[f];
+                for (int f = 0; f < NB; f++) o[f] = v[f];
             }
         }
         __syncthreads();                                            // Y consumed, R free
     }
-    if (FM) {
-        reinterpret_cast<float2 *>(A.ylast)[(size_t)w * M256 + tid] = lastY;
-        if (last == A.nb && owned) A.rp_out[tid - A.c0] = lastY;
+    // ---- stream state after the run that ends the launch ----
+    if (FM) reinterpret_cast<float2 *>(A.ylast)[(size_t)w * M256 + tid] = prev;
+    if (last == A.nb) {
+        if (tid == 0) A.vend_out[0] = c;
+        if (FM && owned) A.rp_out[tid - A.c0] = prev;
     }
 }
 
@@ -886,13 +885,15 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     A.yhist_in = p->d_yhist[p->cur]; A.yhist_out = p->d_yhist[p->cur ^ 1];
     A.vend_in = p->d_vend[p->cur];   A.vend_out = p->d_vend[p->cur ^ 1];
     A.rp_in = p->d_rp[p->cur];       A.rp_out = p->d_rp[p->cur ^ 1];
-    if (++p->epoch == 0) p->epoch = 1;
-    A.epoch = p->epoch; A.nf = nf; A.nb = (nf + NB - 1) / NB;
+    A.out_stride = nf; A.out_t0 = 0;
     A.parity0 = (uint32_t)(p->frames_done & 1);
-    if (A.nb >= p->run_min_tiles) {
-        // large chunk: dependency-free runs of S tiles (S >= 8 keeps the warm-up reads <= 7/8 of a run)
+    const uint32_t nb_full = nf / NB;
+    if (nb_full >= p->run_min_tiles) {
+        // large chunk: dependency-free runs of S full tiles; a ragged tail (< 16 frames) follows as
+        // a second launch of the tile kernel on the state the run kernel leaves behind
         p->name = c.fm ? "k_run256<FM>" : "k_run256<CF32>";
         RunArgs RA{};
+        A.nf = nb_full * NB; A.nb = nb_full;
         RA.t = A; RA.yfirst = p->d_yfirst;
         // one workgroup per resident slot (a single round, no tail): S = ceil(nb / resident), >= 8
         RA.S = (A.nb + p->resident_wgs - 1) / p->resident_wgs; if (RA.S < 8) RA.S = 8;
@@ -905,8 +906,25 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         if (c.fm && nruns > 1)
             hipLaunchKernelGGL(k_run_fixup, dim3(nruns - 1), dim3(256), 0, s, p->d_yfirst, (const float2 *)p->d_ylast,
                                (float *)A.out, nf, RA.S, c.c0, c.C, c.fm_ref);
+        const uint32_t rem = nf - nb_full * NB;
+        if (rem) {
+            p->cur ^= 1;                                         // the tail starts from the run kernel's state
+            TileArgs T = p->proto;
+            T.x = call.d_in + (size_t)nb_full * NB * c.M; T.out = A.out;
+            T.yhist_in = p->d_yhist[p->cur]; T.yhist_out = p->d_yhist[p->cur ^ 1];
+            T.vend_in = p->d_vend[p->cur];   T.vend_out = p->d_vend[p->cur ^ 1];
+            T.rp_in = p->d_rp[p->cur];       T.rp_out = p->d_rp[p->cur ^ 1];
+            if (++p->epoch == 0) p->epoch = 1;
+            T.epoch = p->epoch; T.nf = rem; T.nb = 1; T.out_stride = nf; T.out_t0 = nb_full * NB;
+            T.parity0 = (uint32_t)((p->frames_done + nb_full * NB) & 1);
+            CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
+            if (c.fm) hipLaunchKernelGGL(k_tile256<true>, dim3(1), dim3(256), 0, s, T);
+            else hipLaunchKernelGGL(k_tile256<false>, dim3(1), dim3(256), 0, s, T);
+        }
     } else {
         p->name = c.fm ? "k_tile256<FM>" : "k_tile256<CF32>";
+        if (++p->epoch == 0) p->epoch = 1;
+        A.epoch = p->epoch; A.nf = nf; A.nb = (nf + NB - 1) / NB;
         CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
         if (timer && (r = timer->begin(s))) return r;
         if (c.fm) hipLaunchKernelGGL(k_tile256<true>, dim3(A.nb), dim3(256), 0, s, A);
