@@ -105,6 +105,36 @@ __device__ __forceinline__ void fft16(float2 (&v)[16])
         }
 }
 
+
+// ---- packed-f32 complex helpers (v2f = {re, im}); written so that hipcc folds the swaps and sign
+// flips into op_sel / neg modifiers of v_pk_add_f32 / v_pk_fma_f32 instead of v_mov ----
+__device__ __forceinline__ v2f to_v(float2 a) { return (v2f){a.x, a.y}; }
+__device__ __forceinline__ float2 to_f2(v2f a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ v2f mulmj_v(v2f a) { return (v2f){a.y, -a.x}; }
+__device__ __forceinline__ v2f cmul_v(v2f a, v2f b)
+{
+    const v2f bx = {-b.y, b.x};
+    return __builtin_elementwise_fma((v2f){a.y, a.y}, bx, (v2f){a.x, a.x} * b);
+}
+__device__ __forceinline__ void bfly4_v(v2f &x0, v2f &x1, v2f &x2, v2f &x3)
+{
+    const v2f s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = mulmj_v(x1 - x3);
+    x0 = s02 + s13; x1 = d02 + d13; x2 = s02 - s13; x3 = d02 - d13;
+}
+// forward 16-point DFT, natural-order input; OUTPUT INDEX PERMUTED: v[4q + r] = X[q + 4r]
+__device__ __forceinline__ void fft16_v(v2f (&v)[16])
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int a = 0; a < 4; a++) bfly4_v(v[a], v[a + 4], v[a + 8], v[a + 12]);
+    v[5] = cmul_v(v[5], (v2f){C1, -S1});   v[9] = cmul_v(v[9], (v2f){R2, -R2});    v[13] = cmul_v(v[13], (v2f){S1, -C1});
+    v[6] = cmul_v(v[6], (v2f){R2, -R2});   v[10] = mulmj_v(v[10]);                 v[14] = cmul_v(v[14], (v2f){-R2, -R2});
+    v[7] = cmul_v(v[7], (v2f){S1, -C1});   v[11] = cmul_v(v[11], (v2f){-R2, -R2}); v[15] = cmul_v(v[15], (v2f){-C1, S1});
+#pragma unroll
+    for (int q = 0; q < 4; q++) bfly4_v(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+#define XIDX(i) (((i) >> 2) + 4 * ((i) & 3))   /* register slot i of fft16_v holds X[XIDX(i)] */
+
 // atan2f for the freqdem tail: odd minimax polynomial of degree 17 on [0,1] (fit error 6e-9,
 // f32 evaluation error <= 1.2e-7 rad) + octant folding.  Signed zeros follow IEEE atan2
 // (atan2(+-0, -0) = +-pi, atan2(+-0, +0) = +-0), which is what cargf(conjf(0)*r) relies on.
@@ -128,6 +158,35 @@ __device__ __forceinline__ float fast_atan2f(float y, float x)
     float r = p * a;
     r = (ay > ax) ? 1.57079632679489662f - r : r;
     r = (__float_as_uint(x) >> 31) ? 3.14159265358979324f - r : r;
+    return copysignf(r, y);
+}
+
+// ref * atan2f(y, x) for the run kernel's tail: degree-15 odd minimax polynomial (f32 evaluation error
+// <= 1.2e-7 rad), coefficients pre-scaled by ref; hp = ref*pi/2, pi = ref*pi.  Same signed-zero
+// behaviour as fast_atan2f; inputs are finite by construction (no Inf guard).
+struct PhaseK { float c[8]; float hp, pi; };
+__device__ __forceinline__ PhaseK phase_consts(float ref)
+{
+    PhaseK k;
+    const float c[8] = {9.999993443e-01f, -3.332985938e-01f, 1.994656026e-01f, -1.390860826e-01f,
+                        9.642146528e-02f, -5.591168255e-02f, 2.186254039e-02f, -4.054457881e-03f};
+#pragma unroll
+    for (int i = 0; i < 8; i++) k.c[i] = c[i] * ref;
+    k.hp = 1.57079632679489662f * ref; k.pi = 3.14159265358979324f * ref;
+    return k;
+}
+__device__ __forceinline__ float scaled_atan2f(float y, float x, const PhaseK &k)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const float z = a * a;
+    float p = k.c[7];
+#pragma unroll
+    for (int i = 6; i >= 0; i--) p = fmaf(p, z, k.c[i]);
+    float r = p * a;
+    r = (ay > ax) ? k.hp - r : r;
+    r = (__float_as_int(x) < 0) ? k.pi - r : r;
     return copysignf(r, y);
 }
 
@@ -396,35 +455,36 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
     STAMP(6);   // FIR done
 
     // ---------------- DFT pass 1: thread (f, b1) ----------------
-    float2 v[16];
-    {
-        const int f = tid >> 4, b1 = tid & 15;
+        v2f vv[16];
+        {
+            const int f = tid >> 4, b1 = tid & 15;
 #pragma unroll
-        for (int a = 0; a < 16; a++) v[a] = R[f * FS_X + 16 * a + b1];
-        fft16(v);
+            for (int a = 0; a < 16; a++) vv[a] = to_v(R[f * FS_X + 16 * a + b1]);
+            fft16_v(vv);
 #pragma unroll
-        for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], tw_s[16 * k1 + b1]);
-        __syncthreads();                                        // everyone has read X
+            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + b1]));
+            __syncthreads();                                        // everyone has read X
 #pragma unroll
-        for (int k1 = 0; k1 < 16; k1++) R[f * FS_Z + k1 * RS_Z + b1] = v[k1];
-    }
-    __syncthreads();                                            // Z complete
+            for (int i = 0; i < 16; i++) R[f * FS_Z + XIDX(i) * RS_Z + b1] = to_f2(vv[i]);
+        }
+        __syncthreads();                                            // Z complete
     STAMP(7);   // pass 1 done
 
     // ---------------- DFT pass 2: thread (f, k1) ----------------
-    {
-        const int f = tid >> 4, k1 = tid & 15;
+        {
+            const int f = tid >> 4, k1 = tid & 15;
 #pragma unroll
-        for (int b1 = 0; b1 < 16; b1++) v[b1] = R[f * FS_Z + k1 * RS_Z + b1];
-        fft16(v);
-        __syncthreads();                                        // everyone has read Z
+            for (int b1 = 0; b1 < 16; b1++) vv[b1] = to_v(R[f * FS_Z + k1 * RS_Z + b1]);
+            fft16_v(vv);
+            __syncthreads();                                        // everyone has read Z
 #pragma unroll
-        for (int k2 = 0; k2 < 16; k2++) R[(k1 + 16 * k2) * RS_Y + f] = v[k2];
-    }
-    __syncthreads();                                            // Y complete
+            for (int i = 0; i < 16; i++) R[(k1 + 16 * XIDX(i)) * RS_Y + f] = to_f2(vv[i]);
+        }
+        __syncthreads();                                            // Y complete
     STAMP(8);   // pass 2 done
 
     // ---------------- tail: thread k owns channel k ----------------
+    float2 v[16];
 #pragma unroll
     for (int f = 0; f < NB; f++) v[f] = R[tid * RS_Y + f];
     const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
@@ -626,6 +686,7 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
     const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
     float2 prev = (w == 0 && owned) ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
     const bool vec_out = ((A.out_stride | A.out_t0) % 4u) == 0;
+    const PhaseK pk = phase_consts(A.fm_ref);
 
     tile_load(x4 + (size_t)first * 2048, 16, raw, tid);
     for (unsigned b = first; b < last; b++) {
@@ -636,8 +697,10 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
         asm volatile("" : "+v"(tid_i));
         const int j_i = tid_i;
         const int col_off_i = 16 * (j_i >> 4) + 2 * (((j_i & 15) >> 1) ^ (j_i >> 5)) + (j_i & 1);
+        STAMP(0);
         // ---- stage + scan this tile, prefetch the next one ----
         stage_and_scan(raw, R, E, Tt, A, tid_i);
+        STAMP(1);
 #pragma unroll
         for (int f = 0; f < NB; f++) nw[f] = R[256 * f + col_off_i];
         const float kj = -A.alpha * A.bj[j_i & 15];
@@ -647,6 +710,7 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
         E[tid_i] = cfma(cfma(c, bf, vb), br, E[tid_i]);
         c = cfma(c, A.b256[16], ve);
         __syncthreads();
+        STAMP(2);
         // ---- finish the DC blocker and apply the NCO pre-mix (nco_crcf_mix_block_down) ----
         {
             const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j_i], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j_i];
@@ -660,6 +724,7 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
             for (int f = 0; f < NB; f++) nw[f] = cmul(nw[f], (f & 1) ? Wb : Wa);
         }
         __syncthreads();                                            // P consumed, R free
+        STAMP(3);
 
         // ---- polyphase FIR on the pre-mixed window, oldest tap first ----
         {
@@ -682,33 +747,37 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
 #pragma unroll
         for (int f = 3; f < NB; f++) old[f] = nw[f];                // next tile's window
         __syncthreads();                                            // X complete
+        STAMP(4);
         if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, 16, raw, tid_i);
 
-        float2 v[16];
+        v2f vv[16];
         {
             const int f = tid_i >> 4, b1 = tid_i & 15;
 #pragma unroll
-            for (int a = 0; a < 16; a++) v[a] = R[f * FS_X + 16 * a + b1];
-            fft16(v);
+            for (int a = 0; a < 16; a++) vv[a] = to_v(R[f * FS_X + 16 * a + b1]);
+            fft16_v(vv);
 #pragma unroll
-            for (int k1 = 1; k1 < 16; k1++) v[k1] = cmul(v[k1], tw_s[16 * k1 + b1]);
+            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + b1]));
             __syncthreads();                                        // everyone has read X
 #pragma unroll
-            for (int k1 = 0; k1 < 16; k1++) R[f * FS_Z + k1 * RS_Z + b1] = v[k1];
+            for (int i = 0; i < 16; i++) R[f * FS_Z + XIDX(i) * RS_Z + b1] = to_f2(vv[i]);
         }
         __syncthreads();                                            // Z complete
+        STAMP(5);
         {
             const int f = tid_i >> 4, k1 = tid_i & 15;
 #pragma unroll
-            for (int b1 = 0; b1 < 16; b1++) v[b1] = R[f * FS_Z + k1 * RS_Z + b1];
-            fft16(v);
+            for (int b1 = 0; b1 < 16; b1++) vv[b1] = to_v(R[f * FS_Z + k1 * RS_Z + b1]);
+            fft16_v(vv);
             __syncthreads();                                        // everyone has read Z
 #pragma unroll
-            for (int k2 = 0; k2 < 16; k2++) R[(k1 + 16 * k2) * RS_Y + f] = v[k2];
+            for (int i = 0; i < 16; i++) R[(k1 + 16 * XIDX(i)) * RS_Y + f] = to_f2(vv[i]);
         }
         __syncthreads();                                            // Y complete
+        STAMP(6);
 
         // ---- tail: thread k owns channel k ----
+        float2 v[16];
 #pragma unroll
         for (int f = 0; f < NB; f++) v[f] = R[tid_i * RS_Y + f];
         const size_t row = (size_t)(owned ? tid_i - A.c0 : 0) * A.out_stride + A.out_t0 + (size_t)16 * b;
@@ -722,7 +791,7 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
                     const float2 rp = f ? v[f - 1] : prev, r = v[f];
                     const float re = fmaf(rp.x, r.x, rp.y * r.y);
                     const float im = fmaf(rp.x, r.y, -(rp.y * r.x));
-                    m[f] = fast_atan2f(im, re) * A.fm_ref;
+                    m[f] = scaled_atan2f(im, re, pk);
                 }
                 if (vec_out) {
 #pragma unroll
@@ -744,7 +813,9 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
                 for (int f = 0; f < NB; f++) o[f] = v[f];
             }
         }
+        STAMP(7);
         __syncthreads();                                            // Y consumed, R free
+        STAMP(8);
     }
     // ---- stream state after the run that ends the launch ----
     if (FM) reinterpret_cast<float2 *>(A.ylast)[(size_t)w * M256 + tid] = prev;
