@@ -60,6 +60,7 @@ DcParams make_dc(float alpha)
     d.beta = -d.a1;
     for (int i = 0; i < 9; i++) d.beta_pow_thr[i] = (float)std::pow((double)d.beta, (double)(DC_PER_THREAD << i));
     d.beta_blk = std::pow((double)d.beta, (double)DC_BLOCK);
+    d.log2_beta = (float)std::log2((double)d.beta);
     return d;
 }
 

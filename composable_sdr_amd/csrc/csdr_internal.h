@@ -43,6 +43,7 @@ struct DcParams {
     float beta;            // 1-alpha as f32 = -a1
     float beta_pow_thr[9]; // beta^(DC_PER_THREAD * 2^i), i=0..8
     double beta_blk;       // beta^DC_BLOCK (f64)
+    float log2_beta;
 };
 
 struct NcoParams {

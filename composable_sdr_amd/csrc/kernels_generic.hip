@@ -126,9 +126,19 @@ __global__ __launch_bounds__(DC_THREADS) void k_dc_apply(const float2 *__restric
     const int q = threadIdx.x;
     const uint32_t base = blockIdx.x * DC_BLOCK + q * DC_PER_THREAD;
     float2 xs[DC_PER_THREAD];
+    const bool full = base + DC_PER_THREAD <= n;            // 64-byte aligned run of 8 samples
+    if (full) {
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + base);
 #pragma unroll
-    for (int i = 0; i < DC_PER_THREAD; i++)
-        xs[i] = (base + i < n) ? x[base + i] : make_float2(0.f, 0.f);
+        for (int i = 0; i < DC_PER_THREAD / 2; i++) {
+            const float4 t = x4[i];
+            xs[2 * i] = make_float2(t.x, t.y); xs[2 * i + 1] = make_float2(t.z, t.w);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < DC_PER_THREAD; i++)
+            xs[i] = (base + i < n) ? x[base + i] : make_float2(0.f, 0.f);
+    }
 
     float2 v1 = make_float2(0.f, 0.f);
     if (do_dc) {
@@ -139,13 +149,13 @@ __global__ __launch_bounds__(DC_THREADS) void k_dc_apply(const float2 *__restric
         (void)incl;
         float2 excl = (q > 0) ? sh[q - 1] : make_float2(0.f, 0.f);
         // carry decayed to my first sample: beta^(DC_PER_THREAD*q)
-        float w = (float)pow((double)dc.beta, (double)(DC_PER_THREAD * q));
+        const float w = exp2f((float)(DC_PER_THREAD * q) * dc.log2_beta);
         const float2 c = carries[blockIdx.x];
         v1 = cmadd(c, w, excl);
     }
+    float2 os[DC_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < DC_PER_THREAD; i++) {
-        if (base + i >= n) break;
         float2 o = xs[i];
         if (do_dc) {
             // iirfilt_crcf_execute_norm: v0 = x - a1*v1 ; y = v0 - v1
@@ -156,7 +166,15 @@ __global__ __launch_bounds__(DC_THREADS) void k_dc_apply(const float2 *__restric
             if (base + i == n - 1) state_out[0] = v0;
         }
         if (do_mix) o = nco_rotate(o, base + i, nco, tab);
-        y[base + i] = o;
+        os[i] = o;
+    }
+    if (full) {
+        float4 *y4 = reinterpret_cast<float4 *>(y + base);
+#pragma unroll
+        for (int i = 0; i < DC_PER_THREAD / 2; i++) y4[i] = make_float4(os[2 * i].x, os[2 * i].y, os[2 * i + 1].x, os[2 * i + 1].y);
+    } else {
+#pragma unroll
+        for (int i = 0; i < DC_PER_THREAD; i++) if (base + i < n) y[base + i] = os[i];
     }
 }
 
@@ -180,30 +198,57 @@ int launch_dc_mix(const float2 *x, float2 *y, uint32_t n, bool do_dc, const DcPa
 // ---------------------------------------------------------------------------
 // Polyphase branch filters (firpfbch_crcf analyzer_push + dotprod; Liquid.chs:843).
 // ---------------------------------------------------------------------------
+// One thread = one polyphase branch j x FIR_F consecutive frames: the p+FIR_F-1 window samples
+// are loaded once (coalesced along j) and slide through registers.
+constexpr int FIR_F = 8;
+constexpr int FIR_PMAX = 32;
 __global__ __launch_bounds__(256) void k_pfb_fir(const float2 *__restrict__ u, const float *__restrict__ taps,
-                                                 float2 *__restrict__ X, uint32_t M, uint32_t p, uint64_t total)
+                                                 float2 *__restrict__ X, uint32_t M, uint32_t p, uint32_t nf)
 {
     const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total) return;
     const uint32_t j = (uint32_t)(gid % M);
-    const int64_t t = (int64_t)(gid / M);
-    float2 acc = make_float2(0.f, 0.f);
-    // oldest sample first, as dotprod_crcf walks the window
-    for (int nn = (int)p - 1; nn >= 0; nn--) {
-        const float h = taps[(M - 1 - j) + (uint32_t)nn * M];
-        const float2 v = u[(t - nn) * (int64_t)M + j];
-        acc.x = fmaf(h, v.x, acc.x);
-        acc.y = fmaf(h, v.y, acc.y);
+    const int64_t t0 = (int64_t)(gid / M) * FIR_F;
+    if (t0 >= (int64_t)nf) return;
+    if (p == 14) {
+        float h[14];
+#pragma unroll
+        for (int n = 0; n < 14; n++) h[n] = taps[(M - 1 - j) + (uint32_t)n * M];
+        float2 w[13 + FIR_F];
+#pragma unroll
+        for (int i = 0; i < 13 + FIR_F; i++) {
+            const int64_t t = t0 - 13 + i;
+            w[i] = (t < (int64_t)nf) ? u[t * (int64_t)M + j] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int f = 0; f < FIR_F; f++) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int n = 13; n >= 0; n--) {                      // oldest sample first
+                acc.x = fmaf(h[n], w[13 + f - n].x, acc.x);
+                acc.y = fmaf(h[n], w[13 + f - n].y, acc.y);
+            }
+            if (t0 + f < (int64_t)nf) X[(t0 + f) * (int64_t)M + j] = acc;
+        }
+    } else {
+        for (int f = 0; f < FIR_F && t0 + f < (int64_t)nf; f++) {
+            float2 acc = make_float2(0.f, 0.f);
+            for (int nn = (int)p - 1; nn >= 0; nn--) {
+                const float h = taps[(M - 1 - j) + (uint32_t)nn * M];
+                const float2 v = u[(t0 + f - nn) * (int64_t)M + j];
+                acc.x = fmaf(h, v.x, acc.x);
+                acc.y = fmaf(h, v.y, acc.y);
+            }
+            X[(t0 + f) * (int64_t)M + j] = acc;
+        }
     }
-    X[gid] = acc;
 }
 
 int launch_pfb_fir(const float2 *u, const float *taps, float2 *X, uint32_t M, uint32_t p, uint32_t nf,
                    hipStream_t s)
 {
-    const uint64_t total = (uint64_t)M * nf;
-    if (!total) return 0;
-    hipLaunchKernelGGL(k_pfb_fir, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, u, taps, X, M, p, total);
+    if (!nf) return 0;
+    const uint64_t total = (uint64_t)M * ((nf + FIR_F - 1) / FIR_F);
+    hipLaunchKernelGGL(k_pfb_fir, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, u, taps, X, M, p, nf);
     CSDR_HIP(hipGetLastError());
     return 0;
 }
