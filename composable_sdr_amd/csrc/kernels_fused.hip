@@ -854,7 +854,7 @@ struct FusedPlan {
     void *d_premix = nullptr;    // per-channel output before mixing
     u64 *d_trace = nullptr;
     float2 *d_yfirst = nullptr;
-    uint32_t run_min_tiles = 8192;   // chunks with at least this many tiles use the run kernel
+    uint32_t run_min_tiles = 2048;   // chunks with at least this many tiles use the run kernel (measured crossover)
     uint32_t resident_wgs = 512;     // workgroups of k_run256 the device holds at once
     TileArgs proto;
 };
@@ -882,7 +882,7 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     ALLOC(p->d_yflag, sizeof(unsigned) * p->max_nb);
     ALLOC(p->d_agg, sizeof(u64) * 2 * p->max_nb);
     ALLOC(p->d_ylast, sizeof(u64) * (size_t)cfg.M * p->max_nb);
-    ALLOC(p->d_yfirst, sizeof(float2) * (size_t)cfg.M * (p->max_nb / 8 + 2));
+    ALLOC(p->d_yfirst, sizeof(float2) * (size_t)cfg.M * (p->max_nb / 8 + 2));   // S >= 8 tiles per run
     if (const char *e = getenv("CSDR_RUN_MIN_TILES")) p->run_min_tiles = (uint32_t)atol(e);
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
     if (getenv("CSDR_TRACE")) { ALLOC(p->d_trace, sizeof(u64) * 16 * p->max_nb); CSDR_HIP(hipMemset(p->d_trace, 0, sizeof(u64) * 16 * p->max_nb)); }

@@ -437,3 +437,26 @@ def test_sdr_process_fm_mix_single_output(tmp_path):
     assert names == [str(tmp_path / "o.f32")]
     got = np.fromfile(names[0], dtype=np.float32)
     assert got.size == n // M                                 # one mixed stream of n/M samples
+
+
+# --------------------------------------------------------------------------- BASELINE.json configs 4 and 5 shapes
+def test_config4_shape_1024ch_fm_matches_oracle():
+    M = 1024
+    got, want, path = _chain_case(M, [24, 9], demod="fm", kf=0.3)
+    _, r, _ = _chain_case(M, [24, 9], demod="none")
+    r = np.abs(r.reshape(want.shape))
+    d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / 0.3))
+    rmin = np.minimum(r, np.concatenate([np.zeros((M, 1)), r[:, :-1]], axis=1))
+    print(f"cfg4 shape M=1024 FM [{path}] median {np.median(d):.3e} weighted max {(d * rmin / r.max()).max():.3e}")
+    assert (d * rmin / r.max()).max() < 2 * (1 / (2 * np.pi * 0.3)) * 1e-4 and np.median(d) < 5e-5
+
+
+def test_config5_shape_4096ch_mix_matches_oracle():
+    M = 4096
+    got, want, path = _chain_case(M, [10, 6], mix=True)
+    assert got.shape == want.shape == (16,)
+    full, wfull, _ = _chain_case(M, [10, 6])
+    print(f"cfg5 shape M=4096 [{path}] DeNo rel-rms {rel_rms(full, wfull):.3e}; mix abs err {np.abs(got - want).max():.3e} of {np.abs(want).max():.3f}")
+    assert rel_rms(full, wfull) < 1e-5
+    # 4096-term left fold of values up to ~70: bounded by the unmixed tolerance times sqrt(M)
+    assert np.abs(got - want).max() < 1e-4 * np.abs(wfull).max() * np.sqrt(M)
