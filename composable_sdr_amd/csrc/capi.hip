@@ -104,6 +104,7 @@ struct csdr_chain {
     // host-API staging
     float2 *d_in_stage = nullptr; void *d_out_stage = nullptr;
     FusedPlan *fused = nullptr;
+    SmallPlan *small = nullptr;
     KernelTimer timer;
     std::string timed_kernel;
 };
@@ -327,6 +328,7 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
         CSDR_HIP(hipMemsetAsync(h->d_rp[1], 0, sizeof(float2) * h->C, s));
     }
     if (h->fused) { int r = fused_reset(h->fused, s); if (r) return r; }
+    if (h->small) { int r = small_reset(h->small, s); if (r) return r; }
     return 0;
 }
 
@@ -389,7 +391,8 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
     // Path selection: the fused kernels cover M = 256 (DC blocker + pre-mix + PFB [+ freqdem]).
     // With the AGC on, the fused kernel stops at the channel-major CF32 samples and the
     // exactly-sequential per-channel AGC tail (one lane per channel) + freqdem + mix follow.
-    h->use_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && fused_supported(M, h->p);
+    const bool want_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC);
+    h->use_fused = want_fused && (fused_supported(M, h->p) || small_supported(M, h->p));
     if (h->use_fused) {
         const bool agc_on = cfg->agc_threshold_db != 0.0f;
         FusedConfig fc{};
@@ -397,9 +400,15 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
         fc.dc_block = cfg->dc_block != 0; fc.dc = h->dc;
         fc.fm = cfg->demod == CSDR_DEMOD_FM && !agc_on; fc.fm_ref = h->fm_ref;
         fc.mix = cfg->mix != 0 && !agc_on; fc.taps = h->taps.data(); fc.d_theta = h->d_theta;
-        if ((r = fused_create(fc, &h->fused))) return fail(r);
-        h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (agc_on ? "+agc-tail" : "");
-        h->timed_kernel = fused_name(h->fused);
+        if (small_supported(M, h->p)) {
+            if ((r = small_create(fc, &h->small))) return fail(r);
+            h->path = std::string("fused-") + small_name(h->small) + (agc_on ? "+agc-tail" : "");
+            h->timed_kernel = small_name(h->small);
+        } else {
+            if ((r = fused_create(fc, &h->fused))) return fail(r);
+            h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (agc_on ? "+agc-tail" : "");
+            h->timed_kernel = fused_name(h->fused);
+        }
         if (agc_on && (cfg->demod == CSDR_DEMOD_FM || cfg->mix)) {
             if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf))) return fail(r);
             if (cfg->demod == CSDR_DEMOD_FM && cfg->mix && (r = dev_alloc(&h->d_B, (size_t)C * h->max_nf))) return fail(r);
@@ -487,7 +496,8 @@ int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, vo
         float2 *Z = (agc_on && (fm || mixo)) ? h->d_A : (float2 *)d_out;
         FusedCall fcall{};
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
-        if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
+        if (h->small) { if ((r = small_process(h->small, fcall, s, &h->timer))) return r; }
+        else if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
         h->theta += n_in * h->d_theta;
         if (agc_on) {
             if ((r = launch_agc(Z, h->C, nf, h->d_agc, h->agc, s))) return r;
@@ -552,6 +562,7 @@ int csdr_chain_seek_frames(csdr_chain *h, uint64_t frames)
     h->theta = (uint32_t)(n * (uint64_t)h->d_theta);
     if (h->tab_len) h->tab_pos = (uint32_t)(n % h->tab_len);
     if (h->fused) fused_seek(h->fused, frames);
+    if (h->small) small_seek(h->small, frames);
     return CSDR_OK;
 }
 
@@ -595,6 +606,7 @@ int csdr_chain_destroy(csdr_chain *h)
     DevGuard guard(h->device);
     (void)hipDeviceSynchronize();
     if (h->fused) fused_destroy(h->fused);
+    if (h->small) small_destroy(h->small);
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
                     h->d_agc, h->d_rp[0], h->d_rp[1], h->d_in_stage, h->d_out_stage};

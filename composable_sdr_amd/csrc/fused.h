@@ -33,4 +33,15 @@ int  fused_status(FusedPlan *plan, unsigned *status);
 int  fused_trace(FusedPlan *plan, unsigned long long *out, uint32_t ntiles);
 void fused_destroy(FusedPlan *plan);
 
+
+// M = 64 run kernel (kernels_fused_small.hip): same call interface
+struct SmallPlan;
+bool small_supported(uint32_t M, uint32_t p);
+int  small_create(const FusedConfig &cfg, SmallPlan **out);
+int  small_reset(SmallPlan *plan, hipStream_t s);
+int  small_process(SmallPlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
+void small_seek(SmallPlan *plan, uint64_t frames);
+const char *small_name(const SmallPlan *plan);
+void small_destroy(SmallPlan *plan);
+
 }  // namespace csdr

@@ -1,0 +1,304 @@
+// Device helpers shared by the fused kernels (kernels_fused.hip: M = 256; kernels_fused_small.hip:
+// M = 64).  Everything here is M-agnostic: a TILE is 4096 consecutive input samples, a DC "row" is
+// 256 samples (16 runs of 16), whatever the channel count.  Product code.
+#pragma once
+#include "fused.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace csdr {
+namespace {
+
+constexpr int M256 = 256;
+constexpr int P = 14;            // taps per branch (2m, m = 7)
+constexpr int NB = 16;           // frames per tile
+constexpr int FS_X = 272;        // float2 stride between frames, FIR -> pass-1 layout
+constexpr int FS_Z = 289;        // float2 stride between frames, pass-1 -> pass-2 layout
+constexpr int RS_Z = 18;         // float2 stride between k1 rows inside a frame (16 + 2 pad)
+constexpr int RS_Y = 17;         // float2 stride between channel rows, pass-2 -> tail layout
+constexpr int LDS_F2 = 16 * FS_Z;   // 4624 float2 = 36992 B (largest layout)
+constexpr int E_OFF = 4096;      // float2 offset of the two 256-entry run-carry tables
+constexpr int LOOKBACK = 10;     // tiles; beta^(4096*10) ~ 1.3e-9 for alpha = 0.0005
+constexpr unsigned SPIN_LIMIT = 1u << 24;
+
+typedef unsigned long long u64;
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 mulmj(float2 a) { return make_float2(a.y, -a.x); }   // * -j
+__device__ __forceinline__ float2 cfma(float2 a, float s, float2 b)                    // a*s + b
+{
+    return make_float2(fmaf(a.x, s, b.x), fmaf(a.y, s, b.y));
+}
+
+// forward radix-4 butterfly (W4 = -j)
+__device__ __forceinline__ void bfly4(float2 &x0, float2 &x1, float2 &x2, float2 &x3)
+{
+    const float2 s02 = cadd(x0, x2), d02 = csub(x0, x2);
+    const float2 s13 = cadd(x1, x3), d13 = mulmj(csub(x1, x3));
+    x0 = cadd(s02, s13);
+    x1 = cadd(d02, d13);
+    x2 = csub(s02, s13);
+    x3 = csub(d02, d13);
+}
+
+// In-register forward 16-point DFT, natural order in and out.
+__device__ __forceinline__ void fft16(float2 (&v)[16])
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int a = 0; a < 4; a++) bfly4(v[a], v[a + 4], v[a + 8], v[a + 12]);
+    v[1 + 4] = cmul(v[1 + 4], make_float2(C1, -S1));            // W16^1
+    v[1 + 8] = cmul(v[1 + 8], make_float2(R2, -R2));            // W16^2
+    v[1 + 12] = cmul(v[1 + 12], make_float2(S1, -C1));          // W16^3
+    v[2 + 4] = cmul(v[2 + 4], make_float2(R2, -R2));            // W16^2
+    v[2 + 8] = mulmj(v[2 + 8]);                                 // W16^4 = -j
+    v[2 + 12] = cmul(v[2 + 12], make_float2(-R2, -R2));         // W16^6
+    v[3 + 4] = cmul(v[3 + 4], make_float2(S1, -C1));            // W16^3
+    v[3 + 8] = cmul(v[3 + 8], make_float2(-R2, -R2));           // W16^6
+    v[3 + 12] = cmul(v[3 + 12], make_float2(-C1, S1));          // W16^9
+#pragma unroll
+    for (int q = 0; q < 4; q++) bfly4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int r = q + 1; r < 4; r++) {
+            const float2 t = v[4 * q + r];
+            v[4 * q + r] = v[4 * r + q];
+            v[4 * r + q] = t;
+        }
+}
+
+
+// ---- packed-f32 complex helpers (v2f = {re, im}); written so that hipcc folds the swaps and sign
+// flips into op_sel / neg modifiers of v_pk_add_f32 / v_pk_fma_f32 instead of v_mov ----
+__device__ __forceinline__ v2f to_v(float2 a) { return (v2f){a.x, a.y}; }
+__device__ __forceinline__ float2 to_f2(v2f a) { return make_float2(a.x, a.y); }
+__device__ __forceinline__ v2f mulmj_v(v2f a) { return (v2f){a.y, -a.x}; }
+__device__ __forceinline__ v2f cmul_v(v2f a, v2f b)
+{
+    const v2f bx = {-b.y, b.x};
+    return __builtin_elementwise_fma((v2f){a.y, a.y}, bx, (v2f){a.x, a.x} * b);
+}
+__device__ __forceinline__ void bfly4_v(v2f &x0, v2f &x1, v2f &x2, v2f &x3)
+{
+    const v2f s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = mulmj_v(x1 - x3);
+    x0 = s02 + s13; x1 = d02 + d13; x2 = s02 - s13; x3 = d02 - d13;
+}
+// forward 16-point DFT, natural-order input; OUTPUT INDEX PERMUTED: v[4q + r] = X[q + 4r]
+__device__ __forceinline__ void fft16_v(v2f (&v)[16])
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int a = 0; a < 4; a++) bfly4_v(v[a], v[a + 4], v[a + 8], v[a + 12]);
+    v[5] = cmul_v(v[5], (v2f){C1, -S1});   v[9] = cmul_v(v[9], (v2f){R2, -R2});    v[13] = cmul_v(v[13], (v2f){S1, -C1});
+    v[6] = cmul_v(v[6], (v2f){R2, -R2});   v[10] = mulmj_v(v[10]);                 v[14] = cmul_v(v[14], (v2f){-R2, -R2});
+    v[7] = cmul_v(v[7], (v2f){S1, -C1});   v[11] = cmul_v(v[11], (v2f){-R2, -R2}); v[15] = cmul_v(v[15], (v2f){-C1, S1});
+#pragma unroll
+    for (int q = 0; q < 4; q++) bfly4_v(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+#define XIDX(i) (((i) >> 2) + 4 * ((i) & 3))   /* register slot i of fft16_v holds X[XIDX(i)] */
+
+// atan2f for the freqdem tail: odd minimax polynomial of degree 17 on [0,1] (fit error 6e-9,
+// f32 evaluation error <= 1.2e-7 rad) + octant folding.  Signed zeros follow IEEE atan2
+// (atan2(+-0, -0) = +-pi, atan2(+-0, +0) = +-0), which is what cargf(conjf(0)*r) relies on.
+__device__ __forceinline__ float fast_atan2f(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float a = mn * __builtin_amdgcn_rcpf(mx);
+    a = (mx == 0.0f) ? 0.0f : a;
+    a = (mx == INFINITY) ? ((mn == INFINITY) ? 1.0f : 0.0f) : a;
+    const float z = a * a;
+    float p = 2.456645248e-03f;
+    p = fmaf(p, z, -1.440101303e-02f);
+    p = fmaf(p, z, 3.978060186e-02f);
+    p = fmaf(p, z, -7.234797627e-02f);
+    p = fmaf(p, z, 1.049891263e-01f);
+    p = fmaf(p, z, -1.416121870e-01f);
+    p = fmaf(p, z, 1.998590529e-01f);
+    p = fmaf(p, z, -3.333259821e-01f);
+    p = fmaf(p, z, 9.999998808e-01f);
+    float r = p * a;
+    r = (ay > ax) ? 1.57079632679489662f - r : r;
+    r = (__float_as_uint(x) >> 31) ? 3.14159265358979324f - r : r;
+    return copysignf(r, y);
+}
+
+// ref * atan2f(y, x) for the run kernel's tail: degree-15 odd minimax polynomial (f32 evaluation error
+// <= 1.2e-7 rad), coefficients pre-scaled by ref; hp = ref*pi/2, pi = ref*pi.  Same signed-zero
+// behaviour as fast_atan2f; inputs are finite by construction (no Inf guard).
+struct PhaseK { float c[8]; float hp, pi; };
+__device__ __forceinline__ PhaseK phase_consts(float ref)
+{
+    PhaseK k;
+    const float c[8] = {9.999993443e-01f, -3.332985938e-01f, 1.994656026e-01f, -1.390860826e-01f,
+                        9.642146528e-02f, -5.591168255e-02f, 2.186254039e-02f, -4.054457881e-03f};
+#pragma unroll
+    for (int i = 0; i < 8; i++) k.c[i] = c[i] * ref;
+    k.hp = 1.57079632679489662f * ref; k.pi = 3.14159265358979324f * ref;
+    return k;
+}
+__device__ __forceinline__ float scaled_atan2f(float y, float x, const PhaseK &k)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const float z = a * a;
+    float p = k.c[7];
+#pragma unroll
+    for (int i = 6; i >= 0; i--) p = fmaf(p, z, k.c[i]);
+    float r = p * a;
+    r = (ay > ax) ? k.hp - r : r;
+    r = (__float_as_int(x) < 0) ? k.pi - r : r;
+    return copysignf(r, y);
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ __forceinline__ float2 dpp2(float2 v) { return make_float2(dpp<CTRL>(v.x), dpp<CTRL>(v.y)); }
+
+struct TileArgs {
+    const float2 *x;            // new input, nf*256 samples
+    void *out;                  // [C][nf] F32 (FM) or CF32
+    const float *taps;          // [P][256] prototype taps h[i + n*256]
+    const float2 *tw;           // pass-1 twiddles, tw[16*k1 + b1] = W256^(b1*k1)
+    const float2 *wpre;         // [2][256]: conj(nco phasor) of column j for even / odd global frames
+    const float2 *yhist_in; float2 *yhist_out;   // [13][256] DC-blocked samples before the call / after it
+    const float2 *vend_in;  float2 *vend_out;    // DC blocker state v1
+    const float2 *rp_in;    float2 *rp_out;      // [C] freqdem r'
+    unsigned *ticket;           // zeroed before every launch
+    u64 *agg;                   // [nb][2] {epoch, bits} granules: tile aggregates
+    u64 *ylast;                 // [nb][256] last Y frame of each tile
+    unsigned *yflag;            // [nb]
+    unsigned *status;           // sticky error word (spin limit hit)
+    u64 *trace;                 // optional [nb][16] s_memtime stamps of thread 0 (CSDR_TRACE=1)
+    uint32_t epoch, nf, nb, c0, C, parity0;
+    uint32_t out_stride, out_t0;   // output row length (frames of the whole call) and this launch's first frame in it
+    float alpha, beta, fm_ref;
+    float wtile[LOOKBACK + 2];  // beta^(4096 k)
+    float b16[16];              // beta^(16 r)
+    float b256[17];             // beta^(256 f)
+    float bj[16];               // beta^i
+};
+
+// Raw tile -> registers: 8 x 16 bytes per thread, addressed so that the LDS image below is
+// XOR-swizzled at 16-byte granularity (both the run-major b128 accesses and the column-major
+// b64 accesses are then bank-conflict free).
+__device__ __forceinline__ void tile_load(const float4 *__restrict__ src, int valid_runs, float4 (&raw)[8], int tid)
+{
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int slot = 64 * (it * 4 + wave) + lane;          // 16-byte slot in LDS
+        const int q = slot >> 3;                               // run (16 samples)
+        const int i = (slot & 7) ^ ((q >> 1) & 7);             // which 16-byte piece of the run
+        raw[it] = (q < valid_runs) ? src[8 * q + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// Registers -> LDS, then the zero-state DC scan of the tile.  On return R holds
+// z[n] = x[n] - alpha*s[n-1] (s = scan inside the 16-sample run), E[q] the carry into run q from
+// earlier runs of its frame, T[f] the frame totals.  Ends with a barrier.
+__device__ __forceinline__ float2 stage_and_scan(const float4 (&raw)[8], float2 *R, float2 *E, float2 *T,
+                                               const TileArgs &A, int tid)
+{
+    float4 *R4 = reinterpret_cast<float4 *>(R);
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int it = 0; it < 8; it++) R4[64 * (it * 4 + wave) + lane] = raw[it];
+    __syncthreads();
+
+    const int q = tid, sw = (q >> 1) & 7;
+    float2 s = make_float2(0.f, 0.f);
+    const float na = -A.alpha, be = A.beta;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float4 v = R4[8 * q + (i ^ sw)];
+        float2 x0 = make_float2(v.x, v.y), x1 = make_float2(v.z, v.w);
+        const float2 z0 = cfma(s, na, x0);
+        s = cfma(s, be, x0);
+        const float2 z1 = cfma(s, na, x1);
+        s = cfma(s, be, x1);
+        R4[8 * q + (i ^ sw)] = make_float4(z0.x, z0.y, z1.x, z1.y);
+    }
+    // inclusive decayed scan of the run totals across the 16 runs of a frame (one DPP row)
+    float2 t;
+    t = dpp2<0x111>(s); s = cfma(t, A.b16[1], s);
+    t = dpp2<0x112>(s); s = cfma(t, A.b16[2], s);
+    t = dpp2<0x114>(s); s = cfma(t, A.b16[4], s);
+    t = dpp2<0x118>(s); s = cfma(t, A.b16[8], s);
+    const float2 e = dpp2<0x111>(s);                           // v at my run's start (zero row carry)
+    if (E) E[q] = e;
+    if ((q & 15) == 15) T[q >> 4] = s;                         // row total
+    __syncthreads();
+    return e;
+}
+
+// Zero-state v before frame f of a tile, from its 16 frame totals: every 16-lane row runs the
+// same decayed DPP scan over T[0..15] and picks the entry of the frame before its own.
+__device__ __forceinline__ float2 frame_carry_zero_state(const float2 *T, const TileArgs &A, int tid)
+{
+    float2 s = T[tid & 15];
+    float2 t;
+    t = dpp2<0x111>(s); s = cfma(t, A.b256[1], s);
+    t = dpp2<0x112>(s); s = cfma(t, A.b256[2], s);
+    t = dpp2<0x114>(s); s = cfma(t, A.b256[4], s);
+    t = dpp2<0x118>(s); s = cfma(t, A.b256[8], s);
+    // lane r now holds v after frame r; I need v after frame (f-1), f = tid >> 4
+    const int f = (tid >> 4) & 15;
+    const int srcl = (tid & 48) | ((f - 1) & 15);
+    float2 r = make_float2(__shfl(s.x, srcl), __shfl(s.y, srcl));
+    return f ? r : make_float2(0.f, 0.f);
+}
+
+
+constexpr int WU = 6;
+
+struct RunArgs {
+    TileArgs t;
+    float2 *yfirst;             // [nruns][256] first Y frame of every run
+    uint32_t S;                 // tiles per run
+    float l2beta;               // log2(beta)
+};
+
+__device__ __forceinline__ float2 wg_sum(float2 v, float2 *red, int tid)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { v.x += __shfl_xor(v.x, d); v.y += __shfl_xor(v.y, d); }
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    const float2 r = cadd(cadd(red[0], red[1]), cadd(red[2], red[3]));
+    __syncthreads();
+    return r;
+}
+
+// v after frame 15 of a tile (zero state) from its frame totals; every lane gets the value
+__device__ __forceinline__ void frame_carries(const float2 *T, const TileArgs &A, int tid, float2 &before_mine, float2 &after_tile)
+{
+    float2 s = T[tid & 15];
+    float2 t;
+    t = dpp2<0x111>(s); s = cfma(t, A.b256[1], s);
+    t = dpp2<0x112>(s); s = cfma(t, A.b256[2], s);
+    t = dpp2<0x114>(s); s = cfma(t, A.b256[4], s);
+    t = dpp2<0x118>(s); s = cfma(t, A.b256[8], s);
+    const int f = (tid >> 4) & 15;
+    const int srcl = (tid & 48) | ((f - 1) & 15);
+    const float2 r = make_float2(__shfl(s.x, srcl), __shfl(s.y, srcl));
+    before_mine = f ? r : make_float2(0.f, 0.f);
+    const int endl = (tid & 48) | 15;
+    after_tile = make_float2(__shfl(s.x, endl), __shfl(s.y, endl));
+}
+
+
+}  // namespace
+}  // namespace csdr
