@@ -39,19 +39,20 @@ def parse():
     ap.add_argument("--demod", default="fm", choices=["fm", "none"])
     ap.add_argument("--kf", type=float, default=0.3)
     ap.add_argument("--agc", type=float, default=0.0, help="squelch threshold dB (0 = AGC off)")
+    ap.add_argument("--mix", action="store_true", help="--mix: sum the channels (configs[4] shape)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agc-variant", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def cpu_baseline(M, demod, kf, agc, x_host, seconds):
+def cpu_baseline(M, demod, kf, agc, x_host, seconds, mix=False):
     """The oracle (CPU restatement, 1 thread like the reference's non-threaded RTS) timed on a
     bounded sample of the same workload: reference-sized chunks (4096 frames) of the same
     synthetic stream, repeated until ~`seconds` of CPU work."""
     import numpy as np
     import oracle_lib as O
-    chain = O.Chain(M, dc_block=True, agc_db=agc, demod=demod, kf=kf)
+    chain = O.Chain(M, dc_block=True, agc_db=agc, demod=demod, kf=kf, mix=mix)
     chunk = 4096 * M
     nchunks = x_host.size // chunk
     done, t0 = 0, time.perf_counter()
@@ -96,7 +97,7 @@ def main():
     # rank r's stripe is a different stretch of the stream (different seed offset)
     xs = [synth_cf32_torch(nx, M, dev, seed=20260101 + 7919 * (2 * rank + i)) for i in range(2)]
     out = torch.empty(M * nf * out_elem // 4, dtype=torch.float32, device=dev)
-    chain = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, max_frames=nf, device=local,
+    chain = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local,
                      flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
     chain.seek_frames(rank * a.steps * nf)      # rank r's stripe of one long stream
     stream = torch.cuda.current_stream().cuda_stream
@@ -132,7 +133,7 @@ def main():
 
     total_samples = float(nx) * a.steps * world
     value = total_samples / dt / 1e6
-    alg_bytes_per_sample = 8 + out_elem                 # read CF32 once + write W
+    alg_bytes_per_sample = 8 + (out_elem / M if a.mix else out_elem)   # read CF32 once + write W
     kavg_ms = kms / max(klaunches, 1)
     achieved = (nx * alg_bytes_per_sample) / (kavg_ms * 1e-3) / 1e9 if klaunches else None
     traffic = None
@@ -151,7 +152,7 @@ def main():
         "config": {"workload": f"cfg3: {M}-ch firpfbch(m=7,As=80)+dcBlocker+freqdem(kf={a.kf}) on synthetic CF32, "
                                f"AGC {'off (-a 0)' if a.agc == 0 else a.agc}, {nf} frames/step "
                                f"({nx * 8 / 2**20:.0f} MiB in, {M * nf * out_elem / 2**20:.0f} MiB out), HBM-resident",
-                   "channels": M, "frames_per_step": nf, "demod": a.demod, "kf": a.kf, "agc_db": a.agc,
+                   "channels": M, "frames_per_step": nf, "demod": a.demod, "kf": a.kf, "agc_db": a.agc, "mix": bool(a.mix),
                    "path": chain.path, "sharding": "time stripes, 1 per rank" if world > 1 else "none"},
         "hbm_roofline_frac_whole_step": round(value * 1e6 * alg_bytes_per_sample / 1e9 / (HBM_PEAK_GBS * world), 4),
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
@@ -160,7 +161,7 @@ def main():
                      "alg_bytes_per_sample": alg_bytes_per_sample, "samples_per_launch": nx},
     }
 
-    if world == 1 and not a.no_agc_variant and a.agc == 0.0:
+    if world == 1 and not a.no_agc_variant and a.agc == 0.0 and M == 256 and not a.mix:
         # cfg3 with the AGC on: exactly-sequential per-channel AGC tail
         nf2 = min(nf, 65536)
         ch2 = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=10.0, max_frames=nf2, device=local, flags=_lib.FLAG_QUIET)
@@ -180,7 +181,7 @@ def main():
 
     if world == 1 and not a.no_cpu_baseline:
         x_host = xs[0][: 4096 * M * 4].cpu().numpy().view(np.complex64).reshape(-1)
-        res["cpu_baseline"] = cpu_baseline(M, a.demod, a.kf, a.agc, x_host, a.cpu_seconds)
+        res["cpu_baseline"] = cpu_baseline(M, a.demod, a.kf, a.agc, x_host, a.cpu_seconds, a.mix)
     print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -458,9 +458,17 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
         CSDR_HIP(hipMemcpyAsync(h->d_hist_tmp, h->d_u + nx, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
         CSDR_HIP(hipMemcpyAsync(h->d_u, h->d_hist_tmp, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
         if ((r = launch_dft(h->d_A, h->d_B, h->d_tw, M, nf, s))) return r;
-        if ((r = launch_transpose(h->d_B, Z, M, nf, h->c0, C, s))) return r;
         h->theta += nx * h->d_theta;
         if (h->tab_len) h->tab_pos = (uint32_t)(((uint64_t)h->tab_pos + nx) % h->tab_len);
+        if (!agc && (fm || mixo)) {
+            // frame-major tails: no transpose in front of freqdem / mix
+            if (mixo) r = launch_mix_frames(h->d_B, d_out, fm, M, nf, h->c0, C, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s);
+            else r = launch_transpose_fm(h->d_B, (float *)d_out, M, nf, h->c0, C, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s);
+            if (r) return r;
+            if (fm) h->rp_cur ^= 1;
+            return 0;
+        }
+        if ((r = launch_transpose(h->d_B, Z, M, nf, h->c0, C, s))) return r;
     } else {
         if ((r = h->timer.begin(s))) return r;
         if ((r = launch_dc_mix(d_in, Z, nx, h->cfg.dc_block != 0, h->dc, h->d_dcstate, h->d_scratch, false, nco, nullptr, s))) return r;

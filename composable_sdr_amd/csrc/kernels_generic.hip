@@ -302,6 +302,103 @@ __global__ __launch_bounds__(256) void k_dft_direct(const float2 *__restrict__ X
     Y[gid] = make_float2(sr, si);
 }
 
+
+// ---------------------------------------------------------------------------
+// Forward DFT for N = 1024 (16*16*4) and N = 4096 (16*16*16): three register passes
+// (radix 16, 16, R3) with two LDS exchanges per 4096-point tile (4 frames or 1 frame).
+// ---------------------------------------------------------------------------
+typedef float v2fg __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2fg g_mulmj(v2fg a) { return (v2fg){a.y, -a.x}; }
+__device__ __forceinline__ v2fg g_cmul(v2fg a, v2fg b)
+{
+    const v2fg bx = {-b.y, b.x};
+    return __builtin_elementwise_fma((v2fg){a.y, a.y}, bx, (v2fg){a.x, a.x} * b);
+}
+__device__ __forceinline__ void g_bfly4(v2fg &x0, v2fg &x1, v2fg &x2, v2fg &x3)
+{
+    const v2fg s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = g_mulmj(x1 - x3);
+    x0 = s02 + s13; x1 = d02 + d13; x2 = s02 - s13; x3 = d02 - d13;
+}
+// natural-order input, output slot i holds X[(i >> 2) + 4 * (i & 3)]
+__device__ __forceinline__ void g_fft16(v2fg (&v)[16])
+{
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int a = 0; a < 4; a++) g_bfly4(v[a], v[a + 4], v[a + 8], v[a + 12]);
+    v[5] = g_cmul(v[5], (v2fg){C1, -S1});   v[9] = g_cmul(v[9], (v2fg){R2, -R2});    v[13] = g_cmul(v[13], (v2fg){S1, -C1});
+    v[6] = g_cmul(v[6], (v2fg){R2, -R2});   v[10] = g_mulmj(v[10]);                  v[14] = g_cmul(v[14], (v2fg){-R2, -R2});
+    v[7] = g_cmul(v[7], (v2fg){S1, -C1});   v[11] = g_cmul(v[11], (v2fg){-R2, -R2}); v[15] = g_cmul(v[15], (v2fg){-C1, S1});
+#pragma unroll
+    for (int q = 0; q < 4; q++) g_bfly4(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+#define GXIDX(i) (((i) >> 2) + 4 * ((i) & 3))
+
+template <int R3>   // N = 256 * R3
+__global__ __launch_bounds__(256) void k_fft_r16(const float2 *__restrict__ X, float2 *__restrict__ Y,
+                                                 const float2 *__restrict__ tw, uint32_t nf)
+{
+    constexpr int N = 256 * R3, F = 4096 / N;             // frames per tile
+    constexpr int AS = 17 * R3;                           // padded stride between k1 rows of the pass-1 image
+    __shared__ float2 bufA[F * 16 * AS];
+    __shared__ float2 bufB[4096];
+    const int t = threadIdx.x;
+    const uint64_t f0 = (uint64_t)blockIdx.x * F;
+    v2fg v[16];
+    // ---- pass 1: radix 16 over n1 (stride N/16) for (frame, m) ----
+    {
+        const int fr = t / (N / 16), m = t % (N / 16);
+        const bool ok = f0 + fr < nf;
+        const float2 *src = X + (f0 + fr) * N + m;
+#pragma unroll
+        for (int n1 = 0; n1 < 16; n1++) { const float2 x = ok ? src[(N / 16) * n1] : make_float2(0.f, 0.f); v[n1] = (v2fg){x.x, x.y}; }
+        g_fft16(v);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int k1 = GXIDX(i);
+            if (k1) { const float2 w = tw[m * k1]; v[i] = g_cmul(v[i], (v2fg){w.x, w.y}); }
+            bufA[fr * 16 * AS + k1 * AS + m] = make_float2(v[i].x, v[i].y);
+        }
+    }
+    __syncthreads();
+    // ---- pass 2: radix 16 over n2 for (frame, k1, n3) ----
+    {
+        const int n3 = t % R3, k1 = (t / R3) % 16, fr = t / (16 * R3);
+#pragma unroll
+        for (int n2 = 0; n2 < 16; n2++) { const float2 x = bufA[fr * 16 * AS + k1 * AS + R3 * n2 + n3]; v[n2] = (v2fg){x.x, x.y}; }
+        g_fft16(v);
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int k2 = GXIDX(i);
+            if (k2 && n3) { const float2 w = tw[16 * n3 * k2]; v[i] = g_cmul(v[i], (v2fg){w.x, w.y}); }
+            bufB[fr * N + (k1 + 16 * k2) * R3 + n3] = make_float2(v[i].x, v[i].y);
+        }
+    }
+    __syncthreads();
+    // ---- pass 3: radix R3 over n3 for (frame, k1 + 16 k2), straight to global ----
+    if (R3 == 16) {
+        const bool ok = f0 < nf;
+#pragma unroll
+        for (int n3 = 0; n3 < 16; n3++) { const float2 x = bufB[t * 16 + n3]; v[n3] = (v2fg){x.x, x.y}; }
+        g_fft16(v);
+        if (ok) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) Y[f0 * N + t + 256 * GXIDX(i)] = make_float2(v[i].x, v[i].y);
+        }
+    } else {
+#pragma unroll
+        for (int fr = 0; fr < F; fr++) {
+            v2fg a[4];
+#pragma unroll
+            for (int n3 = 0; n3 < 4; n3++) { const float2 x = bufB[fr * N + t * 4 + n3]; a[n3] = (v2fg){x.x, x.y}; }
+            g_bfly4(a[0], a[1], a[2], a[3]);
+            if (f0 + fr < nf) {
+#pragma unroll
+                for (int k3 = 0; k3 < 4; k3++) Y[(f0 + fr) * N + t + 256 * k3] = make_float2(a[k3].x, a[k3].y);
+            }
+        }
+    }
+}
+
 int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s)
 {
     if (!nf) return 0;
@@ -309,7 +406,11 @@ int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_
         CSDR_HIP(hipMemcpyAsync(Y, X, sizeof(float2) * nf, hipMemcpyDeviceToDevice, s));
         return 0;
     }
-    if ((M & (M - 1)) == 0 && M <= 8192) {
+    if (M == 1024) {
+        hipLaunchKernelGGL(k_fft_r16<4>, dim3((nf + 3) / 4), dim3(256), 0, s, X, Y, tw, nf);
+    } else if (M == 4096) {
+        hipLaunchKernelGGL(k_fft_r16<16>, dim3(nf), dim3(256), 0, s, X, Y, tw, nf);
+    } else if ((M & (M - 1)) == 0 && M <= 8192) {
         uint32_t lg = 0; while ((1u << lg) < M) lg++;
         unsigned th = M / 2 < 64 ? 64 : (M / 2 > 256 ? 256 : M / 2);
         hipLaunchKernelGGL(k_fft_pow2, dim3(nf), dim3(th), M * sizeof(float2), s, X, Y, tw, M, lg);
@@ -465,6 +566,92 @@ int launch_fm(const float2 *Z, float *F, uint32_t C, uint32_t nf, float ref, con
     const uint64_t total = (uint64_t)C * nf;
     if (!total) return 0;
     hipLaunchKernelGGL(k_fm, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, Z, F, nf, total, ref, rp_in, rp_out);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------
+// Frame-major tails (generic path, M > 1 without AGC): freqdem only needs the same channel of
+// the previous frame, which is the previous ROW of Y[nf][M] -- no transpose needed before it.
+//   k_transpose_fm : F[c][t] = arg(conj(Y[t-1][c0+c]) Y[t][c0+c]) * ref, 32x32 tiles through LDS
+//   k_mix_frames   : out[t] = sum_c (FM ? m[t][c] : Y[t][c0+c]), one workgroup per frame
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float fm_sample(float2 rp, float2 r, float ref)
+{
+    const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
+    const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
+    return atan2f(im, re) * ref;
+}
+
+__global__ __launch_bounds__(256) void k_transpose_fm(const float2 *__restrict__ Y, float *__restrict__ F, uint32_t M,
+                                                      uint32_t nf, uint32_t c0, uint32_t C, float ref,
+                                                      const float2 *__restrict__ rp_in, float2 *__restrict__ rp_out)
+{
+    __shared__ float tile[32][33];
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const uint32_t cb = blockIdx.x * 32, tb = blockIdx.y * 32;
+    for (uint32_t r = ty; r < 32; r += 8) {
+        const uint32_t t = tb + r, c = cb + tx;
+        if (t < nf && c < C) {
+            const float2 cur = Y[(uint64_t)t * M + c0 + c];
+            const float2 prv = t ? Y[(uint64_t)(t - 1) * M + c0 + c] : rp_in[c];
+            tile[r][tx] = fm_sample(prv, cur, ref);
+            if (t == nf - 1) rp_out[c] = cur;
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < 32; r += 8) {
+        const uint32_t c = cb + r, t = tb + tx;
+        if (t < nf && c < C) F[(uint64_t)c * nf + t] = tile[tx][r];
+    }
+}
+
+template <bool FM>
+__global__ __launch_bounds__(256) void k_mix_frames(const float2 *__restrict__ Y, void *__restrict__ out, uint32_t M,
+                                                    uint32_t nf, uint32_t c0, uint32_t C, float ref,
+                                                    const float2 *__restrict__ rp_in, float2 *__restrict__ rp_out)
+{
+    __shared__ float2 red[256];
+    const uint32_t t = blockIdx.x;
+    const float2 *row = Y + (uint64_t)t * M + c0;
+    const float2 *prow = t ? Y + (uint64_t)(t - 1) * M + c0 : nullptr;
+    // thread i folds channels i, i+256, ... in ascending order; then an ordered tree over threads
+    float2 acc = make_float2(0.f, 0.f);
+    for (uint32_t c = threadIdx.x; c < C; c += 256) {
+        const float2 cur = row[c];
+        if (FM) {
+            const float2 prv = t ? prow[c] : rp_in[c];
+            acc.x += fm_sample(prv, cur, ref);
+            if (t == nf - 1) rp_out[c] = cur;
+        } else { acc.x += cur.x; acc.y += cur.y; }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) { red[threadIdx.x].x += red[threadIdx.x + d].x; red[threadIdx.x].y += red[threadIdx.x + d].y; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (FM) ((float *)out)[t] = red[0].x; else ((float2 *)out)[t] = red[0];
+    }
+}
+
+int launch_transpose_fm(const float2 *Y, float *F, uint32_t M, uint32_t nf, uint32_t c0, uint32_t C, float ref,
+                        const float2 *rp_in, float2 *rp_out, hipStream_t s)
+{
+    if (!nf || !C) return 0;
+    hipLaunchKernelGGL(k_transpose_fm, dim3((C + 31) / 32, (nf + 31) / 32), dim3(256), 0, s, Y, F, M, nf, c0, C, ref, rp_in, rp_out);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_mix_frames(const float2 *Y, void *out, bool fm, uint32_t M, uint32_t nf, uint32_t c0, uint32_t C, float ref,
+                      const float2 *rp_in, float2 *rp_out, hipStream_t s)
+{
+    if (!nf || !C) return 0;
+    if (fm) hipLaunchKernelGGL(k_mix_frames<true>, dim3(nf), dim3(256), 0, s, Y, out, M, nf, c0, C, ref, rp_in, rp_out);
+    else hipLaunchKernelGGL(k_mix_frames<false>, dim3(nf), dim3(256), 0, s, Y, out, M, nf, c0, C, ref, rp_in, rp_out);
     CSDR_HIP(hipGetLastError());
     return 0;
 }
