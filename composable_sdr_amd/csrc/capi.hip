@@ -105,6 +105,7 @@ struct csdr_chain {
     float2 *d_in_stage = nullptr; void *d_out_stage = nullptr;
     FusedPlan *fused = nullptr;
     SmallPlan *small = nullptr;
+    DcTilePlan *dctile = nullptr;   // generic path with the DC blocker: single-pass scan kernel
     KernelTimer timer;
     std::string timed_kernel;
 };
@@ -329,6 +330,7 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
     }
     if (h->fused) { int r = fused_reset(h->fused, s); if (r) return r; }
     if (h->small) { int r = small_reset(h->small, s); if (r) return r; }
+    if (h->dctile) { int r = dctile_reset(h->dctile, s); if (r) return r; }
     return 0;
 }
 
@@ -420,6 +422,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
             if ((r = dev_alloc(&h->d_u, (size_t)(h->p - 1) * M + h->max_nx)) || (r = dev_alloc(&h->d_hist_tmp, (size_t)(h->p - 1) * M))) return fail(r);
         }
         if ((r = dev_alloc(&h->d_A, h->max_nx)) || (r = dev_alloc(&h->d_B, h->max_nx))) return fail(r);
+        if (M > 1 && cfg->dc_block && (r = dctile_create(h->dc, h->max_nx, &h->dctile))) return fail(r);
     }
     if ((r = chain_init_state(h, nullptr))) return fail(r);
     CSDR_HIP(hipDeviceSynchronize());
@@ -450,7 +453,9 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
         const size_t hist = (size_t)(h->p - 1) * M;
         nco.theta0 = h->theta; nco.d_theta = h->d_theta; nco.tab_len = h->tab_len; nco.tab_pos = h->tab_pos; nco.up = 0;
         float2 *u_new = h->d_u + hist;
-        if ((r = launch_dc_mix(d_in, u_new, nx, h->cfg.dc_block != 0, h->dc, h->d_dcstate, h->d_scratch, true, nco, h->d_nco_tab, s))) return r;
+        if (h->dctile) r = dctile_process(h->dctile, d_in, u_new, nx, true, nco, h->d_nco_tab, s);
+        else r = launch_dc_mix(d_in, u_new, nx, h->cfg.dc_block != 0, h->dc, h->d_dcstate, h->d_scratch, true, nco, h->d_nco_tab, s);
+        if (r) return r;
         if ((r = h->timer.begin(s))) return r;
         if ((r = launch_pfb_fir(u_new, h->d_taps, h->d_A, M, h->p, nf, s))) return r;
         if ((r = h->timer.end(s))) return r;
@@ -615,6 +620,7 @@ int csdr_chain_destroy(csdr_chain *h)
     (void)hipDeviceSynchronize();
     if (h->fused) fused_destroy(h->fused);
     if (h->small) small_destroy(h->small);
+    if (h->dctile) dctile_destroy(h->dctile);
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
                     h->d_agc, h->d_rp[0], h->d_rp[1], h->d_in_stage, h->d_out_stage};

@@ -44,4 +44,13 @@ void small_seek(SmallPlan *plan, uint64_t frames);
 const char *small_name(const SmallPlan *plan);
 void small_destroy(SmallPlan *plan);
 
+
+// single-pass DC blocker + NCO mix for whole chunks of the generic path (kernels_dc_tile.hip)
+struct DcTilePlan;
+int  dctile_create(const DcParams &dc, uint64_t max_samples, DcTilePlan **out);
+int  dctile_reset(DcTilePlan *plan, hipStream_t s);
+int  dctile_process(DcTilePlan *plan, const float2 *x, float2 *y, uint32_t n, bool do_mix, const NcoParams &nco,
+                    const float2 *nco_tab, hipStream_t s);
+void dctile_destroy(DcTilePlan *plan);
+
 }  // namespace csdr

@@ -1,0 +1,231 @@
+// Single-pass DC blocker + NCO mix for the generic (any M) path: one workgroup per 4096-sample
+// tile, zero-state scan in LDS (shared with the fused kernels), tile carries by decoupled
+// look-back over the previous 10 published tile aggregates (ticket order => deadlock-free; see
+// kernels_fused.hip), one coalesced 16 B/lane read and write per sample.
+// Replaces iirfilt_crcf_execute_block + nco_crcf_mix_block_down (Liquid.chs:575-589, 846-847)
+// for whole chunks; the 3-kernel scan in kernels_generic.hip remains for the standalone Pipes.
+#include "fused_common.h"
+
+namespace csdr {
+
+namespace {
+
+struct DcTileArgs {
+    const float2 *x; float2 *y;
+    uint32_t n;                 // samples
+    uint32_t nb;                // tiles
+    const float2 *vend_in; float2 *vend_out;
+    unsigned *ticket; u64 *agg; unsigned *status;
+    uint32_t epoch;
+    NcoParams nco; const float2 *nco_tab; int do_mix;
+    float alpha, beta;
+    float wtile[LOOKBACK + 2], b16[16], b256[17], bj[16];
+};
+
+__global__ __launch_bounds__(256) void k_dc_tile(DcTileArgs D)
+{
+    __shared__ __attribute__((aligned(16))) float2 R[4096];
+    __shared__ float2 Tt[16];
+    __shared__ float2 carry_s;
+    __shared__ unsigned tile_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) tile_s = atomicAdd(D.ticket, 1u);
+    __syncthreads();
+    const unsigned b = tile_s;
+    if (b >= D.nb) return;
+    const uint32_t n0 = b * 4096u, nleft = D.n - n0;
+    const int valid_runs = (int)min(256u, (nleft + 15) / 16);
+    // TileArgs view for the shared helpers (alpha/beta/b16/b256 only)
+    TileArgs A{};
+    A.alpha = D.alpha; A.beta = D.beta;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { A.b16[i] = D.b16[i]; A.bj[i] = D.bj[i]; }
+#pragma unroll
+    for (int i = 0; i < 17; i++) A.b256[i] = D.b256[i];
+
+    float4 raw[8];
+    if (nleft >= 4096u) tile_load(reinterpret_cast<const float4 *>(D.x) + (size_t)b * 2048, 256, raw, tid);
+    else {
+        // ragged last tile: per-sample guard (n need not be a multiple of 16)
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
+            const int i = (slot & 7) ^ ((q >> 1) & 7);
+            const uint32_t s0 = 16u * q + 2u * i;
+            const float2 a = s0 < nleft ? D.x[n0 + s0] : make_float2(0.f, 0.f);
+            const float2 c = s0 + 1 < nleft ? D.x[n0 + s0 + 1] : make_float2(0.f, 0.f);
+            raw[it] = make_float4(a.x, a.y, c.x, c.y);
+        }
+    }
+    (void)valid_runs;
+    const float2 e = stage_and_scan(raw, R, nullptr, Tt, A, tid);
+    float2 vb, ve;
+    frame_carries(Tt, A, tid, vb, ve);
+
+    if (tid < 64) {
+        if (tid == 0) {
+            __hip_atomic_store(&D.agg[2 * (size_t)b], ((u64)D.epoch << 32) | __float_as_uint(ve.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&D.agg[2 * (size_t)b + 1], ((u64)D.epoch << 32) | __float_as_uint(ve.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const int k = tid;
+        float2 cb = make_float2(0.f, 0.f);
+        const bool need = (k >= 1 && k <= LOOKBACK && (int)b - k >= 0);
+        u64 g0 = 0, g1 = 0;
+        unsigned spins = 0;
+        bool ok = !need;
+        while (true) {
+            if (need && !ok) {
+                g0 = __hip_atomic_load(&D.agg[2 * (size_t)(b - k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g1 = __hip_atomic_load(&D.agg[2 * (size_t)(b - k) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(g0 >> 32) == D.epoch && (unsigned)(g1 >> 32) == D.epoch;
+            }
+            if (__all(ok)) break;
+            if (++spins > SPIN_LIMIT) { if (k == 0) atomicOr(D.status, 4u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (need) cb = make_float2(__uint_as_float((unsigned)g0) * D.wtile[k - 1], __uint_as_float((unsigned)g1) * D.wtile[k - 1]);
+        if (k == 0 && b <= LOOKBACK) { const float2 v = D.vend_in[0]; cb = make_float2(v.x * D.wtile[b], v.y * D.wtile[b]); }
+        cb = cadd(cb, dpp2<0x111>(cb)); cb = cadd(cb, dpp2<0x112>(cb));
+        cb = cadd(cb, dpp2<0x114>(cb)); cb = cadd(cb, dpp2<0x118>(cb));
+        if (k == 15) carry_s = cb;
+    }
+    __syncthreads();
+    const float2 c = carry_s;
+    const float br = D.b16[tid & 15], bf = D.b256[tid >> 4];
+    const float2 Pq = cfma(cfma(c, bf, vb), br, e);                  // v before my run
+    if (b == D.nb - 1) {
+        // state after the last sample: v before the first padded sample.  Its run owner rebuilds it.
+        const uint32_t last_run = (nleft - 1) / 16, within = (nleft - 1) % 16;
+        if ((uint32_t)tid == last_run) {
+            float4 *R4 = reinterpret_cast<float4 *>(R);
+            const int sw = (tid >> 1) & 7;
+            float2 v = Pq, s = make_float2(0.f, 0.f);
+            for (uint32_t i = 0; i <= within; i++) {
+                const float4 zz = R4[8 * tid + ((int)(i >> 1) ^ sw)];
+                const float2 z = (i & 1) ? make_float2(zz.z, zz.w) : make_float2(zz.x, zz.y);
+                const float2 x = make_float2(z.x + D.alpha * s.x, z.y + D.alpha * s.y);   // undo z = x - alpha*s_prev
+                s = cfma(s, D.beta, x);
+                v = cfma(v, D.beta, x);
+            }
+            D.vend_out[0] = v;
+        }
+    }
+    // ---- finish: y = z - alpha*beta^i*P, NCO mix, coalesced store in the tile-load pattern ----
+    {
+        float4 *R4 = reinterpret_cast<float4 *>(R);
+        const int q = tid, sw = (q >> 1) & 7;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 z = R4[8 * q + (i ^ sw)];
+            const float k0 = -D.alpha * D.bj[2 * i], k1 = -D.alpha * D.bj[2 * i + 1];
+            float2 y0 = make_float2(fmaf(Pq.x, k0, z.x), fmaf(Pq.y, k0, z.y));
+            float2 y1 = make_float2(fmaf(Pq.x, k1, z.z), fmaf(Pq.y, k1, z.w));
+            R4[8 * q + (i ^ sw)] = make_float4(y0.x, y0.y, y1.x, y1.y);
+        }
+    }
+    __syncthreads();
+    {
+        const float4 *R4 = reinterpret_cast<const float4 *>(R);
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
+            const int i = (slot & 7) ^ ((q >> 1) & 7);
+            const uint32_t s0 = 16u * q + 2u * i;
+            if (s0 >= nleft) continue;
+            float4 yv = R4[slot];
+            float2 y0 = make_float2(yv.x, yv.y), y1 = make_float2(yv.z, yv.w);
+            if (D.do_mix) {
+                const uint32_t idx = n0 + s0;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    float c_, s_;
+                    if (D.nco.tab_len) { const float2 cs = D.nco_tab[(D.nco.tab_pos + idx + h) % D.nco.tab_len]; c_ = cs.x; s_ = cs.y; }
+                    else {
+                        const uint32_t theta = D.nco.theta0 + (idx + h) * D.nco.d_theta;
+                        const float ph = (float)(6.283185307179586 * (double)(float)theta / 4294967296.0);
+                        sincosf(ph, &s_, &c_);
+                    }
+                    if (!D.nco.up) s_ = -s_;
+                    float2 &yy = h ? y1 : y0;
+                    yy = make_float2(yy.x * c_ - yy.y * s_, yy.x * s_ + yy.y * c_);
+                }
+            }
+            if (s0 + 1 < nleft) reinterpret_cast<float4 *>(D.y)[(size_t)b * 2048 + 8 * q + i] = make_float4(y0.x, y0.y, y1.x, y1.y);
+            else D.y[n0 + s0] = y0;
+        }
+    }
+}
+
+}  // namespace
+
+struct DcTilePlan {
+    uint32_t max_nb = 0, epoch = 0;
+    unsigned *d_ticket = nullptr, *d_status = nullptr;
+    u64 *d_agg = nullptr;
+    float2 *d_vend[2] = {nullptr, nullptr};
+    int cur = 0;
+    DcTileArgs proto;
+};
+
+void dctile_destroy(DcTilePlan *p)
+{
+    if (!p) return;
+    void *ptrs[] = {p->d_ticket, p->d_status, p->d_agg, p->d_vend[0], p->d_vend[1]};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    delete p;
+}
+
+int dctile_create(const DcParams &dc, uint64_t max_samples, DcTilePlan **out)
+{
+    DcTilePlan *p = new DcTilePlan();
+    p->max_nb = (uint32_t)((max_samples + 4095) / 4096);
+    auto fail = [&](int r) { dctile_destroy(p); return r; };
+#define ALLOC(ptr, bytes) do { hipError_t e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 1); if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__)); } while (0)
+    ALLOC(p->d_ticket, sizeof(unsigned)); ALLOC(p->d_status, sizeof(unsigned));
+    ALLOC(p->d_agg, sizeof(u64) * 2 * p->max_nb);
+    ALLOC(p->d_vend[0], sizeof(float2)); ALLOC(p->d_vend[1], sizeof(float2));
+#undef ALLOC
+    CSDR_HIP(hipMemset(p->d_status, 0, sizeof(unsigned)));
+    CSDR_HIP(hipMemset(p->d_agg, 0, sizeof(u64) * 2 * p->max_nb));
+    CSDR_HIP(hipMemset(p->d_vend[0], 0, sizeof(float2)));
+    CSDR_HIP(hipMemset(p->d_vend[1], 0, sizeof(float2)));
+    DcTileArgs &D = p->proto;
+    D = DcTileArgs{};
+    const double beta = (double)dc.beta;
+    D.alpha = (float)(1.0 - beta); D.beta = (float)beta;
+    for (int k = 0; k < LOOKBACK + 2; k++) D.wtile[k] = (float)std::pow(beta, 4096.0 * k);
+    for (int k = 0; k < 16; k++) D.b16[k] = (float)std::pow(beta, 16.0 * k);
+    for (int k = 0; k < 17; k++) D.b256[k] = (float)std::pow(beta, 256.0 * k);
+    for (int k = 0; k < 16; k++) D.bj[k] = (float)std::pow(beta, (double)k);
+    D.ticket = p->d_ticket; D.agg = p->d_agg; D.status = p->d_status;
+    *out = p;
+    return 0;
+}
+
+int dctile_reset(DcTilePlan *p, hipStream_t s)
+{
+    p->cur = 0;
+    CSDR_HIP(hipMemsetAsync(p->d_vend[0], 0, sizeof(float2), s));
+    CSDR_HIP(hipMemsetAsync(p->d_vend[1], 0, sizeof(float2), s));
+    return 0;
+}
+
+int dctile_process(DcTilePlan *p, const float2 *x, float2 *y, uint32_t n, bool do_mix, const NcoParams &nco,
+                   const float2 *nco_tab, hipStream_t s)
+{
+    if (!n) return 0;
+    DcTileArgs D = p->proto;
+    D.x = x; D.y = y; D.n = n; D.nb = (n + 4095) / 4096;
+    D.vend_in = p->d_vend[p->cur]; D.vend_out = p->d_vend[p->cur ^ 1];
+    if (++p->epoch == 0) p->epoch = 1;
+    D.epoch = p->epoch; D.nco = nco; D.nco_tab = nco_tab; D.do_mix = do_mix ? 1 : 0;
+    CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_dc_tile, dim3(D.nb), dim3(256), 0, s, D);
+    CSDR_HIP(hipGetLastError());
+    p->cur ^= 1;
+    return 0;
+}
+
+}  // namespace csdr
