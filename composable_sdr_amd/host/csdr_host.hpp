@@ -1,0 +1,164 @@
+// C++ host side above the C ABI: the reference's block protocol and stream combinators
+// (GHC is not available in this image, and the reference is compiled code, so the host-side
+// mirror that ships is C++; composable_sdr_amd/*.py is the same thing for the tests).
+//
+//   Pipe<A,B>      Types.hs:51-55     { start, process, done } around one native handle
+//   compose        Types.hs:93-99     process2 >=> process1, done2 before done1
+//   Fold<A>        streamly Fold      step / done
+//   addPipe        Types.hs:117-131   downstream start first, then create; done: destroy, then downstream
+//   takeNArr       Trans.hs:33-56     pass arrays until n samples, trimming the last one
+//   compact        Trans.hs:58-84     emit exactly n, keep the rest, flush the remainder at done
+//   distribute_    Trans.hs:106-117   element k of the list to fold k (zip semantics)
+//   mix            Trans.hs:119-122   left fold of element-wise +
+//   fileSink       Sink.hs:29-34      raw chunk writer
+//   readFromFile   Source.chs:259-271 raw CF32 chunks of <= n samples
+#pragma once
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/csdr.h"
+
+namespace csdrhost {
+
+using cf32 = std::complex<float>;
+template <class T> using Array = std::vector<T>;
+
+struct CsdrError : std::runtime_error {
+    int code;
+    CsdrError(int c, const std::string &m) : std::runtime_error("csdr error " + std::to_string(c) + ": " + m), code(c) {}
+};
+inline void check(int code) { if (code != 0) throw CsdrError(code, csdr_last_error()); }   // Common.hs:32-33 `try`
+
+// ---- Pipe -------------------------------------------------------------------------------
+template <class A, class B> struct Pipe {
+    std::function<std::shared_ptr<void>()> start;
+    std::function<B(void *, const A &)> process;
+    std::function<void(void *)> done;
+};
+
+template <class A, class B, class C> Pipe<A, C> compose(Pipe<B, C> p1, Pipe<A, B> p2)
+{
+    struct R { std::shared_ptr<void> r1, r2; };
+    Pipe<A, C> p;
+    p.start = [=]() { auto r = std::make_shared<R>(); r->r1 = p1.start(); r->r2 = p2.start(); return std::static_pointer_cast<void>(r); };
+    p.process = [=](void *r, const A &a) { auto *rr = static_cast<R *>(r); return p1.process(rr->r1.get(), p2.process(rr->r2.get(), a)); };
+    p.done = [=](void *r) { auto *rr = static_cast<R *>(r); p2.done(rr->r2.get()); p1.done(rr->r1.get()); };
+    return p;
+}
+
+// ---- Fold -------------------------------------------------------------------------------
+template <class A> struct Fold {
+    virtual ~Fold() = default;
+    virtual void step(const A &a) = 0;
+    virtual void done() = 0;
+};
+
+template <class A, class B> struct AddPipe : Fold<A> {
+    Pipe<A, B> pipe; std::shared_ptr<Fold<B>> down; std::shared_ptr<void> r;
+    AddPipe(Pipe<A, B> p, std::shared_ptr<Fold<B>> d) : pipe(std::move(p)), down(std::move(d)), r(pipe.start()) {}
+    void step(const A &a) override { down->step(pipe.process(r.get(), a)); }
+    void done() override { pipe.done(r.get()); down->done(); }
+};
+template <class A, class B> std::shared_ptr<Fold<A>> addPipe(Pipe<A, B> p, std::shared_ptr<Fold<B>> d)
+{
+    return std::make_shared<AddPipe<A, B>>(std::move(p), std::move(d));
+}
+
+template <class T> struct Compact : Fold<Array<T>> {
+    size_t n; std::shared_ptr<Fold<Array<T>>> down; Array<T> buf;
+    Compact(size_t n_, std::shared_ptr<Fold<Array<T>>> d) : n(n_), down(std::move(d)) {}
+    void step(const Array<T> &a) override {
+        buf.insert(buf.end(), a.begin(), a.end());
+        if (buf.size() >= n) {                              // emit EXACTLY n, keep the rest (even if >= n)
+            Array<T> head(buf.begin(), buf.begin() + n);
+            buf.erase(buf.begin(), buf.begin() + n);
+            down->step(head);
+        }
+    }
+    void done() override { down->step(buf); buf.clear(); down->done(); }   // remainder pushed even when empty
+};
+template <class T> std::shared_ptr<Fold<Array<T>>> compact(size_t n, std::shared_ptr<Fold<Array<T>>> d)
+{
+    return std::make_shared<Compact<T>>(n, std::move(d));
+}
+
+template <class T> struct Distribute : Fold<std::vector<Array<T>>> {
+    std::vector<std::shared_ptr<Fold<Array<T>>>> folds;
+    explicit Distribute(std::vector<std::shared_ptr<Fold<Array<T>>>> f) : folds(std::move(f)) {}
+    void step(const std::vector<Array<T>> &as) override { for (size_t k = 0; k < folds.size() && k < as.size(); k++) folds[k]->step(as[k]); }
+    void done() override { for (auto &f : folds) f->done(); }
+};
+
+template <class T> Array<T> mix(const std::vector<Array<T>> &chans)
+{
+    Array<T> acc = chans.at(0);
+    for (size_t k = 1; k < chans.size(); k++) {
+        if (chans[k].size() < acc.size()) acc.resize(chans[k].size());       // zipWith truncates
+        for (size_t i = 0; i < acc.size(); i++) acc[i] = acc[i] + chans[k][i];
+    }
+    return acc;
+}
+
+// takeNArr as a push-side limiter: returns false once the stream is finished
+struct TakeN {
+    size_t n, seen = 0;
+    explicit TakeN(size_t n_) : n(n_) {}
+    template <class T> bool feed(Array<T> &a) {
+        if (seen == n) return false;
+        if (n - seen < a.size()) a.resize(n - seen);
+        seen += a.size();
+        return true;
+    }
+};
+
+template <class T> struct FileSink : Fold<Array<T>> {
+    FILE *f;
+    explicit FileSink(const std::string &path) : f(std::fopen(path.c_str(), "wb")) { if (!f) throw std::runtime_error("cannot open " + path); }
+    ~FileSink() override { if (f) std::fclose(f); }
+    void step(const Array<T> &a) override { if (!a.empty() && std::fwrite(a.data(), sizeof(T), a.size(), f) != a.size()) throw std::runtime_error("short write"); }
+    void done() override { if (f) { std::fclose(f); f = nullptr; } }
+};
+
+// ---- the fused chain as a Pipe (replaces mix . mux (replicate nch demod) . firpfbchChannelizer nc) ----
+struct ChainOpts {
+    uint32_t channels = 1; bool dc_block = true; float agc = 0.f; bool fm = false; float kf = 0.3f; bool mix = false;
+    uint32_t max_frames = 4096; uint32_t flags = CSDR_FLAG_QUIET;
+};
+
+template <class Out> Pipe<Array<cf32>, std::vector<Array<Out>>> fusedChain(const ChainOpts &o)
+{
+    Pipe<Array<cf32>, std::vector<Array<Out>>> p;
+    p.start = [o]() {
+        csdr_chain_cfg cfg;
+        csdr_chain_cfg_default(&cfg, o.channels);
+        cfg.channels = o.channels; cfg.dc_block = o.dc_block; cfg.agc_threshold_db = o.agc;
+        cfg.demod = o.fm ? CSDR_DEMOD_FM : CSDR_DEMOD_NONE; cfg.kf = o.kf; cfg.mix = o.mix; cfg.max_frames = o.max_frames; cfg.flags = o.flags;
+        csdr_chain *h = nullptr;
+        check(csdr_chain_create(&cfg, &h));
+        return std::shared_ptr<void>(h, [](void *q) { csdr_chain_destroy(static_cast<csdr_chain *>(q)); });
+    };
+    p.process = [o](void *r, const Array<cf32> &a) {
+        auto *h = static_cast<csdr_chain *>(r);
+        const uint32_t M = o.channels;
+        if (a.empty()) return std::vector<Array<Out>>{Array<Out>{}};          // nx = 0 -> [empty] (Liquid.chs:856-862)
+        const uint32_t usable = (uint32_t)(a.size() / M * M), nf = usable / M;
+        const bool mixed = o.mix && M > 1;
+        Array<Out> flat((size_t)(mixed ? nf : (size_t)M * nf));
+        uint32_t n_out = 0;
+        check(csdr_chain_process(h, reinterpret_cast<const float *>(a.data()), usable, flat.data(), &n_out));
+        std::vector<Array<Out>> outs;
+        if (mixed || M == 1) { outs.push_back(std::move(flat)); return outs; }
+        for (uint32_t k = 0; k < M; k++) outs.emplace_back(flat.begin() + (size_t)k * nf, flat.begin() + (size_t)(k + 1) * nf);
+        return outs;
+    };
+    p.done = [](void *) {};
+    return p;
+}
+
+}  // namespace csdrhost

@@ -1,0 +1,65 @@
+// soapy-sdr's file-input mode (apps/SoapySDR.hs:181-283) on the C-ABI chain:
+//   soapy_sdr_file --filename in.cf32 -n N -c M [--demod DeNo|DeNBFM kf] [-a dB] [-m] [-o output] [--chunksize 1024]
+// readFromFile -> takeNArr -> compact(4*M*1024) -> fused chain (dcBlocker + PFB + demod [+mix]) -> fileSinks
+// named <out>.cf32 / <out>_ch<k>.cf32 (DeNo, SoapySDR.hs:240) or raw .f32 for FM (the reference wraps
+// the same samples in WAV/AU through libsndfile).
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "csdr_host.hpp"
+
+using namespace csdrhost;
+
+template <class Out> static int run(const std::string &in, const ChainOpts &o, size_t n, const std::string &out, size_t chunk, const char *ext)
+{
+    const uint32_t M = o.channels;
+    const bool mixed = o.mix && M > 1;
+    std::vector<std::shared_ptr<Fold<Array<Out>>>> sinks;
+    if (mixed || M == 1) sinks.push_back(std::make_shared<FileSink<Out>>(out + ext));
+    else for (uint32_t k = 1; k <= M; k++) sinks.push_back(std::make_shared<FileSink<Out>>(out + "_ch" + std::to_string(k) + ext));
+    auto fold = compact<cf32>((size_t)4 * M * 1024, addPipe(fusedChain<Out>(o), std::static_pointer_cast<Fold<std::vector<Array<Out>>>>(
+                                                                                    std::make_shared<Distribute<Out>>(sinks))));
+    FILE *f = std::fopen(in.c_str(), "rb");
+    if (!f) { std::cerr << "Unable to open source: " << in << "\n"; return 1; }
+    TakeN take(n);
+    Array<cf32> a(chunk);
+    while (true) {
+        a.resize(chunk);
+        const size_t got = std::fread(a.data(), sizeof(cf32), chunk, f);
+        if (!got) break;
+        a.resize(got);
+        if (!take.feed(a)) break;
+        fold->step(a);
+    }
+    std::fclose(f);
+    fold->done();
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    std::string in, out = "output", demod = "DeNo";
+    ChainOpts o; o.flags = 0;
+    size_t n = 1024, chunk = 1024;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { std::cerr << "missing value for " << a << "\n"; std::exit(2); } return argv[++i]; };
+        if (a == "--filename") in = next();
+        else if (a == "-n" || a == "--numsamples") n = std::strtoull(next(), nullptr, 10);
+        else if (a == "-c" || a == "--channels") o.channels = (uint32_t)std::atoi(next());
+        else if (a == "-a" || a == "--agc") o.agc = (float)std::atof(next());
+        else if (a == "-m" || a == "--mix") o.mix = true;
+        else if (a == "-o" || a == "--output") out = next();
+        else if (a == "--chunksize") chunk = std::strtoull(next(), nullptr, 10);
+        else if (a == "--demod") { demod = next(); if (demod == "DeNBFM") { o.fm = true; o.kf = (float)std::atof(next()); } }
+        else { std::cerr << "unknown option " << a << "\n"; return 2; }
+    }
+    if (in.empty()) { std::cerr << "--filename is required (SoapySDR live sources are out of scope)\n"; return 2; }
+    try {
+        return o.fm ? run<float>(in, o, n, out, chunk, ".f32") : run<cf32>(in, o, n, out, chunk, ".cf32");
+    } catch (const std::exception &e) {
+        std::cerr << e.what() << "\n";
+        return 1;
+    }
+}

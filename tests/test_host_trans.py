@@ -94,3 +94,13 @@ def test_distribute_routes_channel_k_to_sink_k():              # Trans.hs:106-11
     d.done()
     assert np.array_equal(sinks[0].concat(), _arr(0, 4))
     assert np.array_equal(sinks[1].concat(), _arr(10, 12)) and np.array_equal(sinks[2].concat(), _arr(20, 22))
+
+
+def test_cpp_host_combinators_build_and_pass():
+    """The C++ mirror (composable_sdr_amd/host/csdr_host.hpp) runs its own semantic checks."""
+    import os
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "composable_sdr_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s", "test_host"])
+    out = subprocess.run([os.path.join(host, "test_host")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "host combinators ok" in out.stdout, out.stderr
