@@ -7,10 +7,10 @@
 with the DSP behind `compact` done by the fused C-ABI chain.  Sinks are the reference's raw
 `fileSink`s (Sink.hs:29-34): `<out>.cf32` / `<out>_ch<k>.cf32` for DeNo (SoapySDR.hs:240), and raw
 `.f32` for FM (the reference wraps FM audio in WAV/AU through libsndfile, which is out of scope;
-the sample values and their order are the same).  Resampler / --offset front-end: next round (f2)."""
+the sample values and their order are the same).  `--offset` is the reference's mixDown/mixUp in front; the msresamp resampler (`-b`) is not built (f2)."""
 import numpy as np
 
-from .pipes import Chain, ChainConfig
+from .pipes import Chain, ChainConfig, mixDown, mixUp
 from .trans import Fold, compact, takeNArr
 
 
@@ -66,7 +66,7 @@ class _FusedFold(Fold):
 
 
 def sdr_process(filename, channels=1, demod="none", kf=0.3, agc=0.0, mix=False, numsamples=1024,
-                outname="output", chunksize=1024, m=4):
+                outname="output", chunksize=1024, m=4, offset=0.0, samplerate=2.56e6):
     """soapy-sdr --filename F -c channels --demod ... -a agc [-m] -n numsamples -o outname
     (bandwidth 0, offset 0).  Returns the list of files written."""
     nch = channels
@@ -75,7 +75,17 @@ def sdr_process(filename, channels=1, demod="none", kf=0.3, agc=0.0, mix=False, 
     names = [outname + ext] if (mixed or nch == 1) else [f"{outname}_ch{k}{ext}" for k in range(1, nch + 1)]
     chain = Chain(ChainConfig(channels=nch, demod=demod, kf=kf, agc=agc, mix=mixed, max_frames=m * 1024))
     fold = compact(m * nch * 1024, _FusedFold(chain, [fileSink(n) for n in names], mixed))
-    for a in takeNArr(numsamples, readFromFile(chunksize, filename)):
+    # --offset: f = 2*pi*offset/fs; mixDown f if f > 0, mixUp (-f) if f < 0 (SoapySDR.hs:200-205),
+    # applied per source chunk BEFORE takeNArr (SoapySDR.hs:206-207)
+    f = np.float32(2 * np.pi * offset / samplerate)
+    front = None if f == 0 else (mixDown(float(f), max_samples=chunksize) if f > 0 else mixUp(float(-f), max_samples=chunksize))
+    r = front._start() if front else None
+    src = readFromFile(chunksize, filename)
+    if front:
+        src = (front._process(r, a) for a in src)
+    for a in takeNArr(numsamples, src):
         fold.step(a)
     fold.done()
+    if front:
+        front._done(r)
     return names

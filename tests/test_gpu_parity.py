@@ -483,3 +483,17 @@ def test_cpp_soapy_sdr_file_matches_python_replay(tmp_path):
         a = np.fromfile(tmp_path / f"py_ch{k}.f32", dtype=np.float32)
         b = np.fromfile(tmp_path / f"cc_ch{k}.f32", dtype=np.float32)
         assert a.size == n // M and np.array_equal(a, b)
+
+
+def test_sdr_process_offset_front_end(tmp_path):
+    """--offset = mixDown/mixUp per source chunk in front of takeNArr (SoapySDR.hs:200-207)."""
+    from composable_sdr_amd.app import sdr_process
+    n, fs, off = 40000, 2.56e6, 100e3
+    x = synth_cf32(n, 1, seed=9)
+    src = tmp_path / "i.cf32"
+    x.tofile(src)
+    names = sdr_process(str(src), channels=1, demod="none", numsamples=n, outname=str(tmp_path / "o"), offset=off, samplerate=fs)
+    got = np.fromfile(names[0], dtype=np.complex64)
+    f = np.float32(2 * np.pi * off / fs)
+    want = O.DcBlock().execute(O.Nco(f).mix_down(x))
+    assert got.size == n and rel_rms(got, want) < 1e-5
