@@ -136,7 +136,7 @@ __device__ __forceinline__ float fast_atan2f(float y, float x)
 // <= 1.2e-7 rad), coefficients pre-scaled by ref; hp = ref*pi/2, pi = ref*pi.  Same signed-zero
 // behaviour as fast_atan2f; inputs are finite by construction (no Inf guard).
 struct PhaseK { float c[8]; float hp, pi; };
-__device__ __forceinline__ PhaseK phase_consts(float ref)
+__host__ __device__ __forceinline__ PhaseK phase_consts(float ref)
 {
     PhaseK k;
     const float c[8] = {9.999993443e-01f, -3.332985938e-01f, 1.994656026e-01f, -1.390860826e-01f,
@@ -266,6 +266,7 @@ constexpr int WU = 6;
 
 struct RunArgs {
     TileArgs t;
+    PhaseK pk;                  // ref-scaled atan polynomial: uniform, so it lives in SGPRs
     float2 *yfirst;             // [nruns][256] first Y frame of every run
     uint32_t S;                 // tiles per run
     float l2beta;               // log2(beta)

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
 // The first freqdem output of every run but the first is finished by k_run_fixup.
 // ---------------------------------------------------------------------------------------------
 template <bool FM>
-__global__ __launch_bounds__(256) void k_run256(RunArgs RA)
+__global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs: 3 workgroups per CU
 {
     const TileArgs &A = RA.t;
     __shared__ __attribute__((aligned(16))) float2 R[LDS_F2];
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_run256(RunArgs RA)
     const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
     float2 prev = (w == 0 && owned) ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
     const bool vec_out = ((A.out_stride | A.out_t0) % 4u) == 0;
-    const PhaseK pk = phase_consts(A.fm_ref);
+    const PhaseK &pk = RA.pk;
 
     tile_load(x4 + (size_t)first * 2048, 256, raw, tid);
     for (unsigned b = first; b < last; b++) {
@@ -676,7 +676,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         p->name = c.fm ? "k_run256<FM>" : "k_run256<CF32>";
         RunArgs RA{};
         A.nf = nb_full * NB; A.nb = nb_full;
-        RA.t = A; RA.yfirst = p->d_yfirst;
+        RA.t = A; RA.yfirst = p->d_yfirst; RA.pk = phase_consts(c.fm_ref);
         // one workgroup per resident slot (a single round, no tail): S = ceil(nb / resident), >= 8
         RA.S = (A.nb + p->resident_wgs - 1) / p->resident_wgs; if (RA.S < 8) RA.S = 8;
         RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;

@@ -47,7 +47,7 @@ __device__ __forceinline__ int u_index(int n)
 }
 
 template <bool FM>
-__global__ __launch_bounds__(256) void k_run64(SmallArgs SA)
+__global__ __launch_bounds__(256, 3) void k_run64(SmallArgs SA)
 {
     const TileArgs &A = SA.t;
     __shared__ __attribute__((aligned(16))) float2 R[RS_F2];
