@@ -268,7 +268,8 @@ struct RunArgs {
     TileArgs t;
     PhaseK pk;                  // ref-scaled atan polynomial: uniform, so it lives in SGPRs
     float2 *yfirst;             // [nruns][256] first Y frame of every run
-    uint32_t S;                 // tiles per run
+    uint32_t S;                 // nominal tiles per run (fix-up indexing uses run_first)
+    uint32_t nruns;             // runs are balanced: run w covers tiles [w*nb/nruns, (w+1)*nb/nruns)
     float l2beta;               // log2(beta)
 };
 

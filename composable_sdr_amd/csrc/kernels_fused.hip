@@ -326,7 +326,8 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 
     const int tid = threadIdx.x, j = tid;
     const unsigned w = blockIdx.x;
-    const unsigned first = w * RA.S, last = min(first + RA.S, A.nb);     // tiles [first, last)
+    const unsigned first = (unsigned)((unsigned long long)w * A.nb / RA.nruns);
+    const unsigned last = (unsigned)((unsigned long long)(w + 1) * A.nb / RA.nruns);     // tiles [first, last)
     tw_s[tid] = A.tw[tid];
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
     float2 *E = R + E_OFF;
@@ -538,15 +539,16 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 
 // first freqdem sample of every run w >= 1: needs the last frame of run w-1
 __global__ __launch_bounds__(256) void k_run_fixup(const float2 *__restrict__ yfirst, const float2 *__restrict__ ylast,
-                                                   float *__restrict__ out, uint32_t nf, uint32_t S, uint32_t c0, uint32_t C,
-                                                   float ref)
+                                                   float *__restrict__ out, uint32_t nf, uint32_t nb, uint32_t nruns, uint32_t c0,
+                                                   uint32_t C, float ref)
 {
     const uint32_t k = threadIdx.x, w = blockIdx.x + 1;
     if (k < c0 || k >= c0 + C) return;
     const float2 r = yfirst[(size_t)w * M256 + k], rp = ylast[(size_t)(w - 1) * M256 + k];
     const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
     const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
-    out[(size_t)(k - c0) * nf + (size_t)16 * S * w] = fast_atan2f(im, re) * ref;
+    const size_t first = (size_t)((unsigned long long)w * nb / nruns);
+    out[(size_t)(k - c0) * nf + 16 * first] = fast_atan2f(im, re) * ref;
 }
 
 }  // namespace
@@ -677,17 +679,20 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         RunArgs RA{};
         A.nf = nb_full * NB; A.nb = nb_full;
         RA.t = A; RA.yfirst = p->d_yfirst; RA.pk = phase_consts(c.fm_ref);
-        // one workgroup per resident slot (a single round, no tail): S = ceil(nb / resident), >= 8
-        RA.S = (A.nb + p->resident_wgs - 1) / p->resident_wgs; if (RA.S < 8) RA.S = 8;
+        // one run per resident workgroup slot (a single round), runs balanced to within one tile,
+        // at least 8 tiles per run so that the warm-up reads stay below 7/8 of a run
+        uint32_t nruns = p->resident_wgs;
+        if (nruns > A.nb / 8) nruns = A.nb / 8;
+        if (nruns < 1) nruns = 1;
+        RA.nruns = nruns; RA.S = (A.nb + nruns - 1) / nruns;
         RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;
-        const uint32_t nruns = (A.nb + RA.S - 1) / RA.S;
         if (timer && (r = timer->begin(s))) return r;
         if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), 0, s, RA);
         else hipLaunchKernelGGL(k_run256<false>, dim3(nruns), dim3(256), 0, s, RA);
         if (timer && (r = timer->end(s))) return r;
         if (c.fm && nruns > 1)
             hipLaunchKernelGGL(k_run_fixup, dim3(nruns - 1), dim3(256), 0, s, p->d_yfirst, (const float2 *)p->d_ylast,
-                               (float *)A.out, nf, RA.S, c.c0, c.C, c.fm_ref);
+                               (float *)A.out, nf, A.nb, nruns, c.c0, c.C, c.fm_ref);
         const uint32_t rem = nf - nb_full * NB;
         if (rem) {
             p->cur ^= 1;                                         // the tail starts from the run kernel's state
