@@ -77,14 +77,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # under torchrun even N=1 goes through RCCL
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libcsdr_hip has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if use_dist:
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     import composable_sdr_amd as cs
     from composable_sdr_amd import _lib
@@ -106,7 +109,7 @@ def main():
         chain.process_device(xs[i & 1].data_ptr(), nx, out.data_ptr(), stream)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -120,15 +123,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kname, kms, klaunches = chain.kernel_time()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
         return
 
     total_samples = float(nx) * a.steps * world
@@ -183,7 +185,7 @@ def main():
         x_host = xs[0][: 4096 * M * 4].cpu().numpy().view(np.complex64).reshape(-1)
         res["cpu_baseline"] = cpu_baseline(M, a.demod, a.kf, a.agc, x_host, a.cpu_seconds, a.mix)
     print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
