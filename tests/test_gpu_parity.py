@@ -497,3 +497,88 @@ def test_sdr_process_offset_front_end(tmp_path):
     f = np.float32(2 * np.pi * off / fs)
     want = O.DcBlock().execute(O.Nco(f).mix_down(x))
     assert got.size == n and rel_rms(got, want) < 1e-5
+
+
+# --------------------------------------------------------------------------- BASELINE.json full sizes: size-independent properties
+def _torch_chain(M, nf, demod, **kw):
+    import torch
+    ch = cs.Chain(channels=M, demod=demod, max_frames=nf, **kw)
+    return ch, torch
+
+
+def test_full_size_cfg3_linearity_and_kernel_agreement(monkeypatch):
+    """configs[2] size (256 ch, 262 144 frames = 67 M samples per chunk), device-resident:
+    (1) the two fused kernels (dependency-free runs vs look-back tiles) agree on the whole chunk,
+    (2) DeNo is linear: chain(x1 + 2 x2) = chain(x1) + 2 chain(x2),
+    (3) a tone at a channel centre lands in that channel only (>= 75 dB), gain ~ M."""
+    import torch
+    from synth import channel_centre, synth_cf32_torch
+    M, nf = 256, 262144
+    dev = torch.device("cuda", 0)
+    x1 = synth_cf32_torch(M * nf, M, dev, seed=1)
+    x2 = synth_cf32_torch(M * nf, M, dev, seed=2)
+
+    def run(x, demod, run_min):
+        monkeypatch.setenv("CSDR_RUN_MIN_TILES", str(run_min))
+        ch = cs.Chain(channels=M, demod=demod, max_frames=nf)
+        out = torch.empty(M * nf * (1 if demod == "fm" else 2), dtype=torch.float32, device=dev)
+        ch.process_device(x.data_ptr(), M * nf, out.data_ptr(), 0)
+        torch.cuda.synchronize()
+        ch.close()
+        return out
+
+    a = run(x1, "fm", 1)                    # k_run256
+    b = run(x1, "fm", 10 ** 9)              # k_tile256
+    d = torch.remainder(a - b + 0.5 / 0.3, 1 / 0.3) - 0.5 / 0.3
+    dd = d.abs().view(M, nf)
+    tone = torch.arange(M, device=dev) % 4 == 1
+    print("full-size run-vs-tile FM: tone-channel max", float(dd[tone].max()), "median all", float(dd.median()))
+    assert float(dd[tone].max()) < 5e-6 and float(dd.median()) < 5e-6
+    del a, b, d, dd
+
+    y1 = run(x1, "none", 1)
+    y2 = run(x2, "none", 1)
+    y12 = run(x1 + 2 * x2, "none", 1)
+    err = (y12 - (y1 + 2 * y2)).abs().max()
+    scale = y12.abs().max()
+    print("full-size linearity: max err", float(err), "of", float(scale))
+    assert float(err) < 2e-5 * float(scale)
+    del y1, y2, y12
+
+    k = 37
+    n = torch.arange(M * nf, device=dev, dtype=torch.float64)
+    ph = torch.remainder(channel_centre(k, M) * n, 2 * np.pi).to(torch.float32)
+    tone_x = torch.stack([torch.cos(ph), torch.sin(ph)], dim=1).contiguous()
+    del n, ph
+    yt = run(tone_x, "none", 1).view(M, nf, 2)
+    p = torch.sqrt((yt[:, 100:, :] ** 2).sum(-1)).mean(1)
+    others = torch.cat([p[:k], p[k + 1:]])
+    iso = 20 * torch.log10(p[k] / (others.max() + 1e-30))
+    print("full-size tone: channel", int(p.argmax()), "isolation dB", float(iso), "gain/M", float(p[k]) / M)
+    assert int(p.argmax()) == k and float(iso) > 75 and abs(float(p[k]) / M - 1) < 0.02
+
+
+def test_full_size_cfg2_64ch_chunk_invariance():
+    """configs[1] size (64 ch, 1 048 576 frames): one chunk == 16 chunks (state carry), DeNo."""
+    import torch
+    from synth import synth_cf32_torch
+    M, nf = 64, 1048576
+    dev = torch.device("cuda", 0)
+    x = synth_cf32_torch(M * nf, M, dev, seed=3)
+    one = torch.empty(M * nf * 2, dtype=torch.float32, device=dev)
+    ch = cs.Chain(channels=M, max_frames=nf)
+    assert "k_run64" in ch.path
+    ch.process_device(x.data_ptr(), M * nf, one.data_ptr(), 0)
+    torch.cuda.synchronize()
+    ch.close()
+    parts = torch.empty(16, M, nf // 16, 2, dtype=torch.float32, device=dev)
+    ch = cs.Chain(channels=M, max_frames=nf // 16)
+    for i in range(16):
+        ch.process_device(x.data_ptr() + i * (M * nf // 16) * 8, M * nf // 16, parts[i].data_ptr(), 0)
+    torch.cuda.synchronize()
+    ch.close()
+    many = parts.permute(1, 0, 2, 3).reshape(M, nf, 2)
+    err = (many - one.view(M, nf, 2)).abs().max()
+    scale = one.abs().max()
+    print("cfg2 full size one-vs-16 chunks: max err", float(err), "of", float(scale))
+    assert float(err) < 1e-5 * float(scale)
