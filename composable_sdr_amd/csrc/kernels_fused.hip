@@ -495,35 +495,50 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         const size_t row = (size_t)(owned ? tid_i - A.c0 : 0) * A.out_stride + A.out_t0 + (size_t)16 * b;
         if (FM) {
             if (b == first && w > 0) RA.yfirst[(size_t)w * M256 + tid_i] = v[0];
-            if (owned) {
-                float *o = (float *)A.out + row;
-                float m[NB];
+            float m[NB];
 #pragma unroll
-                for (int f = 0; f < NB; f++) {
-                    const float2 rp = f ? v[f - 1] : prev, r = v[f];
-                    const float re = fmaf(rp.x, r.x, rp.y * r.y);
-                    const float im = fmaf(rp.x, r.y, -(rp.y * r.x));
-                    m[f] = scaled_atan2f(im, re, pk);
-                }
-                if (vec_out) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < NB; f++) o[f] = m[f];
-                }
+            for (int f = 0; f < NB; f++) {
+                const float2 rp = f ? v[f - 1] : prev, r = v[f];
+                const float re = fmaf(rp.x, r.x, rp.y * r.y);
+                const float im = fmaf(rp.x, r.y, -(rp.y * r.x));
+                m[f] = scaled_atan2f(im, re, pk);
             }
             prev = v[NB - 1];
+            if (vec_out) {
+                // transpose the 16 demodulated samples per channel through LDS so that 4 consecutive lanes
+                // write the 4 x 16-byte pieces of one channel row (a wave instruction = 16 x 64 B segments)
+                __syncthreads();                                    // Y consumed by everyone
+                float4 *M4 = reinterpret_cast<float4 *>(R);
+#pragma unroll
+                for (int q = 0; q < 4; q++) M4[tid_i * 5 + q] = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+                __syncthreads();
+                float *obase = (float *)A.out + A.out_t0 + (size_t)16 * b;
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int item = tid_i + 256 * it, rowk = item >> 2, piece = item & 3;
+                    if ((uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
+                        *reinterpret_cast<float4 *>(obase + (size_t)(rowk - A.c0) * A.out_stride + 4 * piece) = M4[rowk * 5 + piece];
+                }
+            } else if (owned) {
+                float *o = (float *)A.out + row;
+#pragma unroll
+                for (int f = 0; f < NB; f++) o[f] = m[f];
+            }
+        } else if (vec_out) {
+            // CF32 rows leave as whole 128-byte lines: 8 consecutive lanes write the 8 x 16-byte pieces of
+            // one channel row (a wave instruction = 8 full lines), instead of 64 lanes x 16 B of 64 rows
+            float2 *obase = (float2 *)A.out + A.out_t0 + (size_t)16 * b;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int item = tid_i + 256 * it, rowk = item >> 3, piece = item & 7;
+                const float2 a0 = R[rowk * RS_Y + 2 * piece], a1 = R[rowk * RS_Y + 2 * piece + 1];
+                if ((uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
+                    *reinterpret_cast<float4 *>(obase + (size_t)(rowk - A.c0) * A.out_stride + 2 * piece) = make_float4(a0.x, a0.y, a1.x, a1.y);
+            }
         } else if (owned) {
             float2 *o = (float2 *)A.out + row;
-            if (vec_out) {
 #pragma unroll
-                for (int q = 0; q < 8; q++)
-                    *reinterpret_cast<float4 *>(o + 2 * q) = make_float4(v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y);
-            } else {
-#pragma unroll
-                for (int f = 0; f < NB; f++) o[f] = v[f];
-            }
+            for (int f = 0; f < NB; f++) o[f] = v[f];
         }
         STAMP(7);
         __syncthreads();                                            // Y consumed, R free
