@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("CSDR_LIB") or os.path.join(_HERE, "libcsdr_hip.so")   # CSDR_LIB: A/B builds
 
 DEMOD_NONE, DEMOD_FM = 0, 1
-FLAG_TIME_KERNELS, FLAG_FORCE_GENERIC, FLAG_QUIET = 1, 2, 4
+FLAG_TIME_KERNELS, FLAG_FORCE_GENERIC, FLAG_QUIET, FLAG_AGC_SEQUENTIAL = 1, 2, 4, 8
 
 ERR_INVALID, ERR_HIP, ERR_NODEV, ERR_SIZE, ERR_NOMEM = -1, -2, -3, -4, -5
 
@@ -64,6 +64,7 @@ SIGNATURES = {
     "csdr_chain_get_nco": (_i32, [_vp, _pu32, _pu32]),
     "csdr_chain_path": (C.c_char_p, [_vp]),
     "csdr_chain_debug_trace": (_i32, [_vp, _vp, _u32]),
+    "csdr_chain_debug_agc": (_i32, [_vp, _vp, _vp]),
     "csdr_chain_kernel_time": (C.c_char_p, [_vp, C.POINTER(C.c_double), _pu32]),
 }
 

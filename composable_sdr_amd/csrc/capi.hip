@@ -106,6 +106,7 @@ struct csdr_chain {
     FusedPlan *fused = nullptr;
     SmallPlan *small = nullptr;
     DcTilePlan *dctile = nullptr;   // generic path with the DC blocker: single-pass scan kernel
+    AgcTailPlan *agc_tail = nullptr; // AGC on: time-parallel verified tail (unless CSDR_FLAG_AGC_SEQUENTIAL)
     KernelTimer timer;
     std::string timed_kernel;
 };
@@ -404,16 +405,17 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
         fc.mix = cfg->mix != 0 && !agc_on; fc.taps = h->taps.data(); fc.d_theta = h->d_theta;
         if (small_supported(M, h->p)) {
             if ((r = small_create(fc, &h->small))) return fail(r);
-            h->path = std::string("fused-") + small_name(h->small) + (agc_on ? "+agc-tail" : "");
+            h->path = std::string("fused-") + small_name(h->small) + (agc_on ? "+agc" : "");
             h->timed_kernel = small_name(h->small);
         } else {
             if ((r = fused_create(fc, &h->fused))) return fail(r);
-            h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (agc_on ? "+agc-tail" : "");
+            h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (agc_on ? "+agc" : "");
             h->timed_kernel = fused_name(h->fused);
         }
-        if (agc_on && (cfg->demod == CSDR_DEMOD_FM || cfg->mix)) {
+        if (agc_on) {
+            // d_A: channel-major CF32 from the channelizer; d_B: per-channel tail output in front of --mix
             if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf))) return fail(r);
-            if (cfg->demod == CSDR_DEMOD_FM && cfg->mix && (r = dev_alloc(&h->d_B, (size_t)C * h->max_nf))) return fail(r);
+            if (cfg->mix && (r = dev_alloc(&h->d_B, (size_t)C * h->max_nf))) return fail(r);
         }
     } else {
         h->path = "generic";
@@ -423,6 +425,10 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
         }
         if ((r = dev_alloc(&h->d_A, h->max_nx)) || (r = dev_alloc(&h->d_B, h->max_nx))) return fail(r);
         if (M > 1 && cfg->dc_block && (r = dctile_create(h->dc, h->max_nx, &h->dctile))) return fail(r);
+    }
+    if (h->d_agc && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL)) {
+        if ((r = agc_tail_create(C, h->max_nf, &h->agc_tail))) return fail(r);
+        h->path += h->use_fused ? "-spec" : "+agc-spec";
     }
     if ((r = chain_init_state(h, nullptr))) return fail(r);
     CSDR_HIP(hipDeviceSynchronize());
@@ -441,13 +447,26 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
 
 uint32_t csdr_chain_out_elem_size(const csdr_chain *h) { return h && h->cfg.demod == CSDR_DEMOD_FM ? 4u : 8u; }
 
+// AGC on: Z[C][nf] (channel-major CF32 in d_A) -> AGC + squelch [+ freqdem] [+ mix] -> d_out
+static int chain_agc_tail(csdr_chain *h, const float2 *Z, uint32_t nf, void *d_out, hipStream_t s)
+{
+    const bool fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix && h->M > 1;
+    void *T = mixo ? (void *)h->d_B : d_out;
+    int r = agc_tail_process(h->agc_tail, Z, T, fm, nf, h->d_agc, h->agc, h->fm_ref,
+                             fm ? h->d_rp[h->rp_cur] : nullptr, fm ? h->d_rp[h->rp_cur ^ 1] : nullptr, s);
+    if (r) return r;
+    if (fm) h->rp_cur ^= 1;
+    if (mixo) return launch_mix((const float *)T, (float *)d_out, h->C, fm ? nf : 2 * nf, s);
+    return 0;
+}
+
 static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d_out, hipStream_t s)
 {
     const uint32_t M = h->M, nf = nx / M, C = h->C;
     const bool fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix && M > 1, agc = h->d_agc != nullptr;
     int r;
     // where the channel-major CF32 lands
-    float2 *Z = (!fm && !mixo) ? (float2 *)d_out : h->d_A;
+    float2 *Z = (!fm && !mixo && !(agc && h->agc_tail)) ? (float2 *)d_out : h->d_A;
     NcoParams nco{};
     if (M > 1) {
         const size_t hist = (size_t)(h->p - 1) * M;
@@ -479,6 +498,7 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
         if ((r = launch_dc_mix(d_in, Z, nx, h->cfg.dc_block != 0, h->dc, h->d_dcstate, h->d_scratch, false, nco, nullptr, s))) return r;
         if ((r = h->timer.end(s))) return r;
     }
+    if (agc && h->agc_tail) return chain_agc_tail(h, Z, nf, d_out, s);
     if (agc && (r = launch_agc(Z, C, nf, h->d_agc, h->agc, s))) return r;
     if (fm) {
         float *F = mixo ? (float *)h->d_B : (float *)d_out;
@@ -506,13 +526,15 @@ int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, vo
     int r;
     if (h->use_fused) {
         const bool agc_on = h->d_agc != nullptr, fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix != 0;
-        float2 *Z = (agc_on && (fm || mixo)) ? h->d_A : (float2 *)d_out;
+        float2 *Z = (agc_on && (fm || mixo || h->agc_tail)) ? h->d_A : (float2 *)d_out;
         FusedCall fcall{};
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         if (h->small) { if ((r = small_process(h->small, fcall, s, &h->timer))) return r; }
         else if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
         h->theta += n_in * h->d_theta;
-        if (agc_on) {
+        if (agc_on && h->agc_tail) {
+            if ((r = chain_agc_tail(h, Z, nf, d_out, s))) return r;
+        } else if (agc_on) {
             if ((r = launch_agc(Z, h->C, nf, h->d_agc, h->agc, s))) return r;
             if (fm) {
                 float *F = mixo ? (float *)h->d_B : (float *)d_out;
@@ -600,6 +622,16 @@ int csdr_chain_debug_trace(csdr_chain *h, unsigned long long *out, uint32_t ntil
     (void)hipDeviceSynchronize();
     return fused_trace(h->fused, out, ntiles);
 }
+int csdr_chain_debug_agc(csdr_chain *h, uint32_t *checked, uint32_t *redone)
+{
+    if (!h) return CSDR_ERR_INVALID;
+    if (checked) *checked = 0;
+    if (redone) *redone = 0;
+    if (!h->agc_tail) return 0;
+    DevGuard guard(h->device);
+    (void)hipDeviceSynchronize();
+    return agc_tail_stats(h->agc_tail, checked, redone);
+}
 const char *csdr_chain_path(const csdr_chain *h) { return h ? h->path.c_str() : ""; }
 
 const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *launches)
@@ -621,6 +653,7 @@ int csdr_chain_destroy(csdr_chain *h)
     if (h->fused) fused_destroy(h->fused);
     if (h->small) small_destroy(h->small);
     if (h->dctile) dctile_destroy(h->dctile);
+    if (h->agc_tail) agc_tail_destroy(h->agc_tail);
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
                     h->d_agc, h->d_rp[0], h->d_rp[1], h->d_in_stage, h->d_out_stage};

@@ -92,6 +92,15 @@ int launch_transpose_fm(const float2 *Y, float *F, uint32_t M, uint32_t nf, uint
 int launch_mix_frames(const float2 *Y, void *out, bool fm, uint32_t M, uint32_t nf, uint32_t c0, uint32_t C, float ref,
                       const float2 *rp_in, float2 *rp_out, hipStream_t s);
 
+// ---- time-parallel exact AGC [+ freqdem] tail (kernels_agc_tail.hip) ----
+struct AgcTailPlan;
+int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out);
+void agc_tail_destroy(AgcTailPlan *p);
+// Z[C][nf] -> out[C][nf] (CF32, or F32 when fm); st (and rp_in -> rp_out when fm) carry the per-channel state
+int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32_t nf, AgcState *st, const AgcParams &prm,
+                     float fm_ref, const float2 *rp_in, float2 *rp_out, hipStream_t s);
+int agc_tail_stats(AgcTailPlan *p, unsigned *checked, unsigned *redone);
+
 // ---- hipEvent bracket around the dominant kernel (CSDR_FLAG_TIME_KERNELS) ----
 struct KernelTimer {
     std::vector<hipEvent_t> ev;          // pairs

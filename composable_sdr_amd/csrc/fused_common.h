@@ -77,32 +77,84 @@ __device__ __forceinline__ void fft16(float2 (&v)[16])
 }
 
 
-// ---- packed-f32 complex helpers (v2f = {re, im}); written so that hipcc folds the swaps and sign
-// flips into op_sel / neg modifiers of v_pk_add_f32 / v_pk_fma_f32 instead of v_mov ----
+// ---- packed-f32 complex helpers (v2f = {re, im}) ----
+// hipcc folds a broadcast ({a.x, a.x}) or a whole-vector negation into VOP3P modifiers but not a swap of the
+// two halves, so a complex multiply costs it 4 instructions (v_xor + v_mov + pk_mul + pk_fma) and a *(-j) two
+// v_movs.  The helpers below spell the instruction with op_sel / neg_lo / neg_hi by hand: 2 per complex
+// multiply, 0 extra per +-j rotation.  gfx950 interlocks dependent packed ops in hardware
+// (tools/probes/pk_hazard_probe.hip), so no wait states are needed inside a block.
 __device__ __forceinline__ v2f to_v(float2 a) { return (v2f){a.x, a.y}; }
 __device__ __forceinline__ float2 to_f2(v2f a) { return make_float2(a.x, a.y); }
-__device__ __forceinline__ v2f mulmj_v(v2f a) { return (v2f){a.y, -a.x}; }
-__device__ __forceinline__ v2f cmul_v(v2f a, v2f b)
+__device__ __forceinline__ v2f cmul_v(v2f a, v2f w)                    // a * w
 {
-    const v2f bx = {-b.y, b.x};
-    return __builtin_elementwise_fma((v2f){a.y, a.y}, bx, (v2f){a.x, a.x} * b);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(t), "=&v"(r) : "v"(a), "v"(w));
+    return r;
+}
+__device__ __forceinline__ void cmul2_v(v2f &a0, v2f w0, v2f &a1, v2f w1)   // two independent products, interleaved
+{
+    v2f t0, t1, r0, r1;
+    asm("v_pk_mul_f32 %0, %4, %5 op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %1, %6, %7 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %2, %4, %5, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+        "v_pk_fma_f32 %3, %6, %7, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(t0), "=&v"(t1), "=&v"(r0), "=&v"(r1) : "v"(a0), "v"(w0), "v"(a1), "v"(w1));
+    a0 = r0; a1 = r1;
+}
+// a * (SL*P[I0] + j*SH*P[I1]) for a uniform constant pair P held in SGPRs; NL1 = (SL<0), NH1 = (SH<0),
+// NL2 = (SH>0), NH2 = (SL<0)
+#define CSDR_CMULK(NAME, I0, NL1, I1, NH1, NL2, NH2)                                                              \
+    __device__ __forceinline__ v2f NAME(v2f a, v2f P)                                                            \
+    {                                                                                                            \
+        v2f t, r;                                                                                                \
+        asm("v_pk_mul_f32 %0, %2, %3 op_sel:[0," #I0 "] op_sel_hi:[0," #I1 "] neg_lo:[0," #NL1 "] neg_hi:[0," #NH1 "]\n\t" \
+            "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[1," #I1 ",0] op_sel_hi:[1," #I0 ",1] neg_lo:[0," #NL2 ",0] neg_hi:[0," #NH2 ",0]" \
+            : "=&v"(t), "=&v"(r) : "v"(a), "s"(P));                                                              \
+        return r;                                                                                                \
+    }
+CSDR_CMULK(cmul_w1, 0, 0, 1, 1, 0, 0)      // P = (C1, S1): * (C1 - j S1) = W16^1
+CSDR_CMULK(cmul_w3, 1, 0, 0, 1, 0, 0)      //               * (S1 - j C1) = W16^3
+CSDR_CMULK(cmul_w9, 0, 1, 1, 0, 1, 1)      //               * (-C1 + j S1) = W16^9
+CSDR_CMULK(cmul_w2, 0, 0, 0, 1, 0, 0)      // P = (R2, *):  * (R2 - j R2) = W16^2
+CSDR_CMULK(cmul_w6, 0, 1, 0, 1, 0, 1)      //               * (-R2 - j R2) = W16^6
+#undef CSDR_CMULK
+__device__ __forceinline__ v2f add_mj(v2f x, v2f d)                     // x + (-j) d = x + (d.y, -d.x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(d));
+    return r;
+}
+__device__ __forceinline__ v2f sub_mj(v2f x, v2f d)                     // x - (-j) d = x + (-d.y, d.x)
+{
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(x), "v"(d));
+    return r;
 }
 __device__ __forceinline__ void bfly4_v(v2f &x0, v2f &x1, v2f &x2, v2f &x3)
 {
-    const v2f s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = mulmj_v(x1 - x3);
-    x0 = s02 + s13; x1 = d02 + d13; x2 = s02 - s13; x3 = d02 - d13;
+    const v2f s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d = x1 - x3;
+    x0 = s02 + s13; x2 = s02 - s13; x1 = add_mj(d02, d); x3 = sub_mj(d02, d);
+}
+__device__ __forceinline__ void bfly4_v_mj2(v2f &x0, v2f &x1, v2f &x2, v2f &x3)      // same with x2 standing for (-j) x2
+{
+    const v2f s02 = add_mj(x0, x2), d02 = sub_mj(x0, x2), s13 = x1 + x3, d = x1 - x3;
+    x0 = s02 + s13; x2 = s02 - s13; x1 = add_mj(d02, d); x3 = sub_mj(d02, d);
 }
 // forward 16-point DFT, natural-order input; OUTPUT INDEX PERMUTED: v[4q + r] = X[q + 4r]
 __device__ __forceinline__ void fft16_v(v2f (&v)[16])
 {
-    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+    const v2f P = {0.92387953251128674f, 0.38268343236508977f}, Q = {0.70710678118654752f, 0.70710678118654752f};
 #pragma unroll
     for (int a = 0; a < 4; a++) bfly4_v(v[a], v[a + 4], v[a + 8], v[a + 12]);
-    v[5] = cmul_v(v[5], (v2f){C1, -S1});   v[9] = cmul_v(v[9], (v2f){R2, -R2});    v[13] = cmul_v(v[13], (v2f){S1, -C1});
-    v[6] = cmul_v(v[6], (v2f){R2, -R2});   v[10] = mulmj_v(v[10]);                 v[14] = cmul_v(v[14], (v2f){-R2, -R2});
-    v[7] = cmul_v(v[7], (v2f){S1, -C1});   v[11] = cmul_v(v[11], (v2f){-R2, -R2}); v[15] = cmul_v(v[15], (v2f){-C1, S1});
-#pragma unroll
-    for (int q = 0; q < 4; q++) bfly4_v(v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    v[5] = cmul_w1(v[5], P);   v[9] = cmul_w2(v[9], Q);    v[13] = cmul_w3(v[13], P);
+    v[6] = cmul_w2(v[6], Q);   /* v[10] *= -j: folded */   v[14] = cmul_w6(v[14], Q);
+    v[7] = cmul_w3(v[7], P);   v[11] = cmul_w6(v[11], Q);  v[15] = cmul_w9(v[15], P);
+    bfly4_v(v[0], v[1], v[2], v[3]);
+    bfly4_v(v[4], v[5], v[6], v[7]);
+    bfly4_v_mj2(v[8], v[9], v[10], v[11]);
+    bfly4_v(v[12], v[13], v[14], v[15]);
 }
 #define XIDX(i) (((i) >> 2) + 4 * ((i) & 3))   /* register slot i of fft16_v holds X[XIDX(i)] */
 
@@ -264,13 +316,31 @@ __device__ __forceinline__ float2 frame_carry_zero_state(const float2 *T, const 
 
 constexpr int WU = 6;
 
+// How a launch's tiles are split into runs.  Runs are grouped in "slots": slot s holds rps consecutive runs that
+// share tiles[s] tiles evenly, starting at tile base[s].  One slot with rps = nruns is the plain balanced
+// split; the run kernels use one slot per co-resident workgroup of a CU (blockIdx / #CUs) so that the share of
+// a run can follow the issue priority its workgroup gets (oldest first) and all runs end together.
+struct RunSplit {
+    uint32_t rps, nslots;
+    uint32_t base[8], tiles[8];
+};
+__host__ __device__ __forceinline__ void run_range(const RunSplit &sp, uint32_t w, uint32_t &first, uint32_t &last)
+{
+    const uint32_t s = w / sp.rps, i = w - s * sp.rps;
+    first = sp.base[s] + (uint32_t)((unsigned long long)i * sp.tiles[s] / sp.rps);
+    last = sp.base[s] + (uint32_t)((unsigned long long)(i + 1) * sp.tiles[s] / sp.rps);
+}
+
 struct RunArgs {
     TileArgs t;
+    RunSplit split;
     PhaseK pk;                  // ref-scaled atan polynomial: uniform, so it lives in SGPRs
     float2 *yfirst;             // [nruns][256] first Y frame of every run
     uint32_t S;                 // nominal tiles per run (fix-up indexing uses run_first)
     uint32_t nruns;             // runs are balanced: run w covers tiles [w*nb/nruns, (w+1)*nb/nruns)
     float l2beta;               // log2(beta)
+    uint32_t prio_div;          // > 0: rotate the wave priority per tile; CU slot of a run = blockIdx / prio_div
+    uint32_t trace_light;       // CSDR_TRACE=2: only per-run s_memrealtime stamps (entry / warm-up / halo / end)
 };
 
 __device__ __forceinline__ float2 wg_sum(float2 v, float2 *red, int tid)

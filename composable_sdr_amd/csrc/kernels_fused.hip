@@ -31,11 +31,17 @@
 // firpfbch_crcf_analyzer_execute + the Haskell transpose (Liquid.chs:575-589, 828-862) and
 // M x freqdem_demodulate_block (Liquid.chs:324-328).
 #include "fused_common.h"
+#ifndef CSDR_ABLATE
+#define CSDR_ABLATE 0
+#endif
+#include <cstring>
 
 namespace csdr {
 
 namespace {
 
+#define RSTAMP(i) do { if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LSTAMP(i) do { if (A.trace && tid == 0) A.trace[(size_t)first * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define STAMP(i) do { if (A.trace && tid == 0) A.trace[(size_t)b * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <bool FM>
@@ -184,19 +190,27 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
 #pragma unroll
         for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j) + n * M256];
         const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
+        const v2f Wav = to_v(Wa), Wbv = to_v(Wb);
 #pragma unroll
-        for (int f = 0; f < NB; f++) {
-            // complex x real multiply-accumulate as one packed f32 FMA per tap
-            v2f ev = {0.f, 0.f}, od = {0.f, 0.f};
+        for (int f = 0; f < NB; f += 2) {
+            // complex x real multiply-accumulate as one packed f32 FMA per tap; two frames at a time so that
+            // consecutive FMAs are independent
+            v2f ev[2] = {{0.f, 0.f}, {0.f, 0.f}}, od[2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int n = P - 1; n >= 0; n--) {
-                const int i = f - n;
-                const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
-                const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
-                if (n & 1) od = __builtin_elementwise_fma(sv, hv, od); else ev = __builtin_elementwise_fma(sv, hv, ev);
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int i = f + q - n;
+                    const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
+                    const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
+                    if (n & 1) od[q] = __builtin_elementwise_fma(sv, hv, od[q]); else ev[q] = __builtin_elementwise_fma(sv, hv, ev[q]);
+                }
             }
-            const float2 xa = cmul(make_float2(ev.x, ev.y), (f & 1) ? Wb : Wa), xb = cmul(make_float2(od.x, od.y), (f & 1) ? Wa : Wb);
-            R[f * FS_X + j] = cadd(xa, xb);
+            // frame f is even within the tile: its even taps see Wa, its odd taps Wb; frame f+1 the other way
+            cmul2_v(ev[0], Wav, od[0], Wbv);
+            cmul2_v(ev[1], Wbv, od[1], Wav);
+            R[f * FS_X + j] = to_f2(ev[0] + od[0]);
+            R[(f + 1) * FS_X + j] = to_f2(ev[1] + od[1]);
         }
     }
     __syncthreads();                                            // X complete
@@ -326,9 +340,10 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 
     const int tid = threadIdx.x, j = tid;
     const unsigned w = blockIdx.x;
-    const unsigned first = (unsigned)((unsigned long long)w * A.nb / RA.nruns);
-    const unsigned last = (unsigned)((unsigned long long)(w + 1) * A.nb / RA.nruns);     // tiles [first, last)
+    unsigned first, last;                                                            // tiles [first, last)
+    run_range(RA.split, w, first, last);
     tw_s[tid] = A.tw[tid];
+    LSTAMP(11);
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
     float2 *E = R + E_OFF;
     const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
@@ -372,6 +387,7 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
             acc = cfma(acc, A.b256[16], p);
         }
         float2 ch = wg_sum(acc, red, tid);                          // also orders tw_s
+        LSTAMP(12);
         if (h0 == 0) ch = cfma(A.vend_in[0], exp2f((float)(4096u * halo) * RA.l2beta), ch);
         // ---- halo tile: stage, scan, finish -> old[3..15]; its end state starts the run ----
         tile_load(x4 + (size_t)halo * 2048, 256, raw, tid);
@@ -395,9 +411,11 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 #pragma unroll
         for (int f = 3; f < NB; f++) old[f] = cmul(old[f], (f & 1) ? Wb : Wa);
     }
+    LSTAMP(13);
     const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
     float2 prev = (w == 0 && owned) ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
     const bool vec_out = ((A.out_stride | A.out_t0) % 4u) == 0;
+    const bool st_ok = !(CSDR_ABLATE & 2) || A.nb == 0xffffffffu;   // timing experiments: no output stores
     const PhaseK &pk = RA.pk;
 
     tile_load(x4 + (size_t)first * 2048, 256, raw, tid);
@@ -405,14 +423,23 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         // every tile of a run is a full tile (the host hands ragged tails to k_tile256).
         // keep the per-phase LDS address arithmetic inside the iteration: hoisted out of the tile
         // loop it would pin >100 VGPRs and halve the occupancy
+        if (RA.prio_div) {
+            // the CU issues oldest-wave-first, so the 3 co-resident runs would finish 45 us apart and leave the
+            // CU under-filled at the end; rotating s_setprio per tile shares the issue slots evenly
+            const unsigned pr = (b - first + w / RA.prio_div) % 3u;
+            if (pr == 0) __builtin_amdgcn_s_setprio(0);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        }
         int tid_i = tid;
         asm volatile("" : "+v"(tid_i));
         const int j_i = tid_i;
         const int col_off_i = 16 * (j_i >> 4) + 2 * (((j_i & 15) >> 1) ^ (j_i >> 5)) + (j_i & 1);
-        STAMP(0);
+        if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+        RSTAMP(0);
         // ---- stage + scan this tile, prefetch the next one ----
         stage_and_scan(raw, R, E, Tt, A, tid_i);
-        STAMP(1);
+        RSTAMP(1);
 #pragma unroll
         for (int f = 0; f < NB; f++) nw[f] = R[256 * f + col_off_i];
         const float kj = -A.alpha * A.bj[j_i & 15];
@@ -422,7 +449,7 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         E[tid_i] = cfma(cfma(c, bf, vb), br, E[tid_i]);
         c = cfma(c, A.b256[16], ve);
         __syncthreads();
-        STAMP(2);
+        RSTAMP(2);
         // ---- finish the DC blocker and apply the NCO pre-mix (nco_crcf_mix_block_down) ----
         {
             const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j_i], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j_i];
@@ -432,11 +459,16 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 #pragma unroll
                 for (int f = 3; f < NB; f++) A.yhist_out[(f - 3) * M256 + j_i] = nw[f];
             }
+            const v2f Wav = to_v(Wa), Wbv = to_v(Wb);
 #pragma unroll
-            for (int f = 0; f < NB; f++) nw[f] = cmul(nw[f], (f & 1) ? Wb : Wa);
+            for (int f = 0; f < NB; f += 2) {
+                v2f a0 = to_v(nw[f]), a1 = to_v(nw[f + 1]);
+                cmul2_v(a0, Wav, a1, Wbv);
+                nw[f] = to_f2(a0); nw[f + 1] = to_f2(a1);
+            }
         }
         __syncthreads();                                            // P consumed, R free
-        STAMP(3);
+        RSTAMP(3);
 
         // ---- polyphase FIR on the pre-mixed window, oldest tap first ----
         {
@@ -444,23 +476,31 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 #pragma unroll
             for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j_i) + n * M256];
 #pragma unroll
-            for (int f = 0; f < NB; f++) {
-                v2f acc = {0.f, 0.f};
+            for (int f0 = 0; f0 < NB; f0 += 4) {
+                // four frames at a time: consecutive FMAs are independent (a dependent packed chain costs a
+                // wait state per tap)
+                v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-                for (int n = P - 1; n >= 0; n--) {
-                    const int i = f - n;
-                    const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
-                    const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
-                    acc = __builtin_elementwise_fma(sv, hv, acc);
+                for (int n = ((CSDR_ABLATE & 4) ? 0 : P - 1); n >= 0; n--) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int i = f0 + q - n;
+                        const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
+                        const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
+                        acc[q] = __builtin_elementwise_fma(sv, hv, acc[q]);
+                    }
                 }
-                R[f * FS_X + j_i] = make_float2(acc.x, acc.y);
+#pragma unroll
+                for (int q = 0; q < 4; q++) R[(f0 + q) * FS_X + j_i] = make_float2(acc[q].x, acc[q].y);
             }
         }
 #pragma unroll
         for (int f = 3; f < NB; f++) old[f] = nw[f];                // next tile's window
         __syncthreads();                                            // X complete
-        STAMP(4);
+        RSTAMP(4);
+#if !(CSDR_ABLATE & 1)
         if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, 256, raw, tid_i);
+#endif
 
         v2f vv[16];
         {
@@ -470,23 +510,29 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
             fft16_v(vv);
 #pragma unroll
             for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + b1]));
+#if !(CSDR_ABLATE & 8)
             __syncthreads();                                        // everyone has read X
 #pragma unroll
             for (int i = 0; i < 16; i++) R[f * FS_Z + XIDX(i) * RS_Z + b1] = to_f2(vv[i]);
+#endif
         }
+#if !(CSDR_ABLATE & 8)
         __syncthreads();                                            // Z complete
-        STAMP(5);
+#endif
+        RSTAMP(5);
         {
             const int f = tid_i >> 4, k1 = tid_i & 15;
+#if !(CSDR_ABLATE & 8)
 #pragma unroll
             for (int b1 = 0; b1 < 16; b1++) vv[b1] = to_v(R[f * FS_Z + k1 * RS_Z + b1]);
+#endif
             fft16_v(vv);
             __syncthreads();                                        // everyone has read Z
 #pragma unroll
             for (int i = 0; i < 16; i++) R[(k1 + 16 * XIDX(i)) * RS_Y + f] = to_f2(vv[i]);
         }
         __syncthreads();                                            // Y complete
-        STAMP(6);
+        RSTAMP(6);
 
         // ---- tail: thread k owns channel k ----
         float2 v[16];
@@ -516,7 +562,7 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 #pragma unroll
                 for (int it = 0; it < 4; it++) {
                     const int item = tid_i + 256 * it, rowk = item >> 2, piece = item & 3;
-                    if ((uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
+                    if (st_ok && (uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
                         *reinterpret_cast<float4 *>(obase + (size_t)(rowk - A.c0) * A.out_stride + 4 * piece) = M4[rowk * 5 + piece];
                 }
             } else if (owned) {
@@ -532,7 +578,7 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
             for (int it = 0; it < 8; it++) {
                 const int item = tid_i + 256 * it, rowk = item >> 3, piece = item & 7;
                 const float2 a0 = R[rowk * RS_Y + 2 * piece], a1 = R[rowk * RS_Y + 2 * piece + 1];
-                if ((uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
+                if (st_ok && (uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
                     *reinterpret_cast<float4 *>(obase + (size_t)(rowk - A.c0) * A.out_stride + 2 * piece) = make_float4(a0.x, a0.y, a1.x, a1.y);
             }
         } else if (owned) {
@@ -540,10 +586,12 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 #pragma unroll
             for (int f = 0; f < NB; f++) o[f] = v[f];
         }
-        STAMP(7);
+        RSTAMP(7);
         __syncthreads();                                            // Y consumed, R free
-        STAMP(8);
+        RSTAMP(8);
+        if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b * 16 + 10] = __builtin_amdgcn_s_memrealtime();
     }
+    LSTAMP(14);
     // ---- stream state after the run that ends the launch ----
     if (FM) reinterpret_cast<float2 *>(A.ylast)[(size_t)w * M256 + tid] = prev;
     if (last == A.nb) {
@@ -554,7 +602,7 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 
 // first freqdem sample of every run w >= 1: needs the last frame of run w-1
 __global__ __launch_bounds__(256) void k_run_fixup(const float2 *__restrict__ yfirst, const float2 *__restrict__ ylast,
-                                                   float *__restrict__ out, uint32_t nf, uint32_t nb, uint32_t nruns, uint32_t c0,
+                                                   float *__restrict__ out, uint32_t nf, RunSplit split, uint32_t c0,
                                                    uint32_t C, float ref)
 {
     const uint32_t k = threadIdx.x, w = blockIdx.x + 1;
@@ -562,11 +610,39 @@ __global__ __launch_bounds__(256) void k_run_fixup(const float2 *__restrict__ yf
     const float2 r = yfirst[(size_t)w * M256 + k], rp = ylast[(size_t)(w - 1) * M256 + k];
     const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
     const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
-    const size_t first = (size_t)((unsigned long long)w * nb / nruns);
-    out[(size_t)(k - c0) * nf + 16 * first] = fast_atan2f(im, re) * ref;
+    uint32_t first, last;
+    run_range(split, w, first, last);
+    out[(size_t)(k - c0) * nf + (size_t)16 * first] = fast_atan2f(im, re) * ref;
 }
 
 }  // namespace
+
+// Split nb tiles into nruns runs.  With one run per resident workgroup slot (nruns = slots x cus) slot k's runs
+// get a share proportional to weight[k]; otherwise the split is uniform.  Every run keeps >= 8 tiles.
+static RunSplit make_split(uint32_t nb, uint32_t nruns, uint32_t cus, const float *weight)
+{
+    RunSplit sp{};
+    const uint32_t slots = (cus && nruns % cus == 0) ? nruns / cus : 0;
+    if (slots >= 2 && slots <= 8) {
+        double tot = 0;
+        for (uint32_t k = 0; k < slots; k++) tot += weight[k];
+        sp.rps = cus; sp.nslots = slots;
+        uint32_t base = 0;
+        bool ok = true;
+        for (uint32_t k = 0; k < slots; k++) {
+            double cum = 0;
+            for (uint32_t q = 0; q <= k; q++) cum += weight[q];
+            const uint32_t end = (k + 1 == slots) ? nb : (uint32_t)std::llround((double)nb * cum / tot);
+            sp.base[k] = base; sp.tiles[k] = end - base;
+            if (end < base || sp.tiles[k] < 8 * cus) ok = false;
+            base = end;
+        }
+        if (ok) return sp;
+    }
+    sp = RunSplit{};
+    sp.rps = nruns; sp.nslots = 1; sp.base[0] = 0; sp.tiles[0] = nb;
+    return sp;
+}
 
 struct FusedPlan {
     FusedConfig cfg;
@@ -583,6 +659,8 @@ struct FusedPlan {
     u64 *d_trace = nullptr;
     float2 *d_yfirst = nullptr;
     uint32_t run_min_tiles = 2048;   // chunks with at least this many tiles use the run kernel (measured crossover)
+    uint32_t cus = 256;
+    float slot_weight[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // tile share of the k-th co-resident run of a CU
     uint32_t resident_wgs = 512;     // workgroups of k_run256 the device holds at once
     TileArgs proto;
 };
@@ -655,7 +733,12 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run256<false>, 256, 0);
         if (occ < 1) occ = 1;
         p->resident_wgs = (uint32_t)(cus * occ);
+        p->cus = (uint32_t)cus;
         if (const char *e = getenv("CSDR_RESIDENT_WGS")) p->resident_wgs = (uint32_t)atol(e);
+        if (const char *e = getenv("CSDR_RUN_WEIGHTS")) {
+            int k = 0;
+            for (const char *q = e; *q && k < 8; k++) { p->slot_weight[k] = (float)atof(q); q = strchr(q, ','); if (!q) break; q++; }
+        }
     }
     *out = p;
     return 0;
@@ -700,14 +783,18 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         if (nruns > A.nb / 8) nruns = A.nb / 8;
         if (nruns < 1) nruns = 1;
         RA.nruns = nruns; RA.S = (A.nb + nruns - 1) / nruns;
+        RA.split = make_split(A.nb, nruns, p->cus, p->slot_weight);
+        { const char *e = getenv("CSDR_PRIO_ROT"); RA.prio_div = (e && atoi(e) == 0) ? 0u : p->cus; }
+        { const char *e = getenv("CSDR_TRACE"); RA.trace_light = (e && atoi(e) == 2) ? 1u : 0u; }
         RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;
         if (timer && (r = timer->begin(s))) return r;
-        if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), 0, s, RA);
-        else hipLaunchKernelGGL(k_run256<false>, dim3(nruns), dim3(256), 0, s, RA);
+        static const size_t extra_lds = getenv("CSDR_EXTRA_LDS") ? (size_t)atol(getenv("CSDR_EXTRA_LDS")) : 0;   // occupancy experiments
+        if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), extra_lds, s, RA);
+        else hipLaunchKernelGGL(k_run256<false>, dim3(nruns), dim3(256), extra_lds, s, RA);
         if (timer && (r = timer->end(s))) return r;
         if (c.fm && nruns > 1)
             hipLaunchKernelGGL(k_run_fixup, dim3(nruns - 1), dim3(256), 0, s, p->d_yfirst, (const float2 *)p->d_ylast,
-                               (float *)A.out, nf, A.nb, nruns, c.c0, c.C, c.fm_ref);
+                               (float *)A.out, nf, RA.split, c.c0, c.C, c.fm_ref);
         const uint32_t rem = nf - nb_full * NB;
         if (rem) {
             p->cur ^= 1;                                         // the tail starts from the run kernel's state

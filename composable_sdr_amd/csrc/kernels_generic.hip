@@ -3,6 +3,7 @@
 // do not cover, for the standalone Pipes (dcBlocker, mixDown/mixUp, AGC, freqdem)
 // and for the sequential AGC tail.  Wave = 64 lanes throughout.
 #include "csdr_internal.h"
+#include "fm_common.h"
 
 namespace csdr {
 
@@ -475,7 +476,7 @@ __device__ __forceinline__ float2 agc_step(float2 x, AgcState &q, const AgcParam
     // the dependent chain is what bounds this kernel, so the gain update uses the hardware
     // log2/exp2 (1 ulp) instead of libm's expf/logf: g*2^(-alpha/2 * log2 y2') is the same function.
     float2 y = make_float2(x.x * q.g, x.y * q.g);
-    const float y2 = __fadd_rn(__fmul_rn(y.x, y.x), __fmul_rn(y.y, y.y));
+    const float y2 = fmaf(y.x, y.x, y.y * y.y);          // explicit: must round the same in every kernel
     q.y2 = fmaf(1.0f - p.alpha, q.y2, p.alpha * y2);
     const float upd = __builtin_amdgcn_exp2f((-0.5f * p.alpha) * __builtin_amdgcn_logf(q.y2));
     q.g = (q.y2 > 1e-6f) ? q.g * upd : q.g;
@@ -554,9 +555,7 @@ __global__ __launch_bounds__(256) void k_fm(const float2 *__restrict__ Z, float 
     const uint32_t c = (uint32_t)(gid / nf);
     const float2 r = Z[gid];
     const float2 rp = t ? Z[gid - 1] : rp_in[c];
-    const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
-    const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
-    F[gid] = atan2f(im, re) * ref;
+    F[gid] = fm_sample_rn(rp, r, ref);
     if (t == nf - 1) rp_out[c] = r;
 }
 
@@ -579,9 +578,7 @@ int launch_fm(const float2 *Z, float *F, uint32_t C, uint32_t nf, float ref, con
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float fm_sample(float2 rp, float2 r, float ref)
 {
-    const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
-    const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
-    return atan2f(im, re) * ref;
+    return fm_sample_rn(rp, r, ref);
 }
 
 __global__ __launch_bounds__(256) void k_transpose_fm(const float2 *__restrict__ Y, float *__restrict__ F, uint32_t M,

@@ -232,6 +232,12 @@ class Chain:
         name = lib().csdr_chain_kernel_time(self.h, C.byref(ms), C.byref(n))
         return name.decode(), ms.value, n.value
 
+    def agc_stats(self):
+        """(segments checked, segments recomputed) of the time-parallel AGC tail since create"""
+        a, b = C.c_uint32(), C.c_uint32()
+        check(lib().csdr_chain_debug_agc(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def reset(self):
         check(lib().csdr_chain_reset(self.h))
 

@@ -51,6 +51,9 @@ extern "C" {
 #define CSDR_FLAG_FORCE_GENERIC 2u  /* use the any-M multi-kernel path even where a fused
                                        kernel exists (for A/B tests)                      */
 #define CSDR_FLAG_QUIET 4u          /* do not print the configuration at create           */
+#define CSDR_FLAG_AGC_SEQUENTIAL 8u /* run the per-channel AGC as one lane per channel instead of
+                                       the time-parallel verified tail; both give bit-identical
+                                       output (for A/B tests)                                */
 
 const char *csdr_last_error(void);
 int  csdr_device_count(void);
@@ -171,6 +174,9 @@ const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *la
  * s_memtime stamps per 16-frame tile; copies the stamps of the first `ntiles` tiles of the last
  * launch into out[ntiles][16] and returns the number of tiles copied (0 when tracing is off). */
 int  csdr_chain_debug_trace(csdr_chain *h, unsigned long long *out, uint32_t ntiles);
+/* Diagnostics of the time-parallel AGC tail since create: segments whose speculative start state was
+ * checked against the true state, and how many of them had to be recomputed sequentially. */
+int  csdr_chain_debug_agc(csdr_chain *h, uint32_t *checked, uint32_t *redone);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@
 prints the median cycles between consecutive s_memtime stamps of thread 0, over all tiles."""
 import os
 import sys
-os.environ["CSDR_TRACE"] = "1"
+os.environ.setdefault("CSDR_TRACE", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
@@ -16,20 +16,64 @@ M, nf = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 dev = torch.device("cuda", 0)
 x = synth_cf32_torch(M * nf, M, dev)
 out = torch.empty(M * nf, dtype=torch.float32, device=dev)
-ch = cs.Chain(channels=M, demod="fm", max_frames=nf, flags=_lib.FLAG_QUIET)
+ch = cs.Chain(channels=M, demod="fm", max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
 for _ in range(3):
+    ch.process_device(x.data_ptr(), M * nf, out.data_ptr(), 0)
+torch.cuda.synchronize()
+ch.kernel_time()
+for _ in range(5):
     ch.process_device(x.data_ptr(), M * nf, out.data_ptr(), 0)
 torch.cuda.synchronize()
 nb = nf // 16
 buf = np.zeros((nb, 16), dtype=np.uint64)
 got = _lib.lib().csdr_chain_debug_trace(ch.h, buf.ctypes.data, nb)
-run = "k_run256" in ch.kernel_time()[0] or nf // 16 >= 8192
+kn, kms, kl = ch.kernel_time()
+run = "k_run256" in kn or nf // 16 >= 8192
+if run and os.environ["CSDR_TRACE"] == "2":
+    L = buf[:got, 11:15].astype(np.int64)
+    ent = L[L[:, 0] > 0]; e0 = ent[:, 0].min()
+    endt = L[L[:, 3] > 0][:, 3]
+    print(f"light trace: {len(ent)} runs; kernel {kn} avg {kms / max(kl, 1) * 1e3:.1f} us (hipEvent)")
+    q = [0, .1, .5, .9, 1]
+    print("  run entry      (us after first entry):", (np.quantile(ent[:, 0] - e0, q) / 100).round(1))
+    wu = ent[ent[:, 1] > 0]
+    print("  warm-up done   :", (np.quantile(wu[:, 1] - e0, q) / 100).round(1), " duration", (np.quantile(wu[:, 1] - wu[:, 0], q) / 100).round(1))
+    print("  prologue done  :", (np.quantile(ent[:, 2] - e0, q) / 100).round(1), " halo duration", (np.quantile(wu[:, 2] - wu[:, 1], q) / 100).round(1))
+    print("  run end        :", (np.quantile(endt - e0, q) / 100).round(1))
+    idx = np.flatnonzero(buf[:got, 11] > 0)                      # row = first tile of run w, ascending in w
+    endw = (buf[idx, 14].astype(np.int64) - e0) / 100.0
+    prow = (buf[idx, 13].astype(np.int64) - e0) / 100.0
+    wv = np.arange(len(idx))
+    print("  mean run end by w%8 (XCD):", [round(float(endw[wv % 8 == k].mean()), 1) for k in range(8)])
+    print("  mean prologue end by w%8 :", [round(float(prow[wv % 8 == k].mean()), 1) for k in range(8)])
+    print("  mean run end by w//256   :", [round(float(endw[wv // 256 == k].mean()), 1) for k in range(3)])
+    print("  mean run end by (w//8)%32 (CU slot in XCD):", [round(float(endw[(wv // 8) % 32 == k].mean()), 0) for k in range(32)])
+    ntl = np.diff(np.append(idx, got))
+    print("  tiles per run min/max:", ntl.min(), ntl.max(), " corr(end, ntiles) =", round(float(np.corrcoef(endw, ntl)[0, 1]), 3))
+    sys.exit(0)
 if run:
+    rt = buf[:got, 9:11].astype(np.int64)
+    ok = (rt[:, 0] > 0) & (rt[:, 1] > 0)
+    r0 = rt[ok, 0].min()
+    print(f"s_memrealtime (100 MHz): launch span {(rt[ok, 1].max() - r0) / 100:.1f} us")
+    ntile = ok.sum()
+    starts = np.sort(rt[ok, 0] - r0) / 100.0; ends = np.sort(rt[ok, 1] - r0) / 100.0
+    print("  tile start times us (quantiles 0,25,50,75,100):", np.quantile(starts, [0, .25, .5, .75, 1]).round(1))
+    print("  tile end   times us (quantiles 0,25,50,75,100):", np.quantile(ends, [0, .25, .5, .75, 1]).round(1))
+    dm = (buf[:got, 8].astype(np.int64) - buf[:got, 0].astype(np.int64))[ok]; dr = (rt[ok, 1] - rt[ok, 0])
+    print(f"  shader clock from per-tile memtime/realtime: median {np.median(dm / np.maximum(dr, 1)) * 0.1:.3f} GHz")
     t = buf[:got, :9].astype(np.int64)
-    t = t[t[:, 8] > 0]
+    t = t[(t[:, 8] > 0) & (t[:, 0] > 0)]
     names = ["stage+scan (incl. load wait)", "column read + P", "DC finish + premix", "FIR", "pass1", "pass2", "tail (FM + stores)", "end barrier"]
     d = np.diff(t, axis=1)
     print(f"run kernel: tiles traced {len(t)}; median tile time {np.median(t[:, 8] - t[:, 0]):.0f} cycles")
+    o = np.argsort(t[:, 0]); ts = t[o]
+    cuts = np.flatnonzero(np.diff(ts[:, 0]) > 5_000_000)          # per-XCD counters are not aligned
+    groups = np.split(ts, cuts + 1)
+    spans = [int(g[:, 8].max() - g[:, 0].min()) for g in groups]
+    print("clusters:", [(len(g), sp) for g, sp in zip(groups, spans)])
+    span = int(np.median(spans))
+    print(f"launch span {span} ticks; kernel {kn} avg {kms / max(kl, 1):.4f} ms over {kl} launches -> {span / (kms / max(kl, 1)) / 1e6:.3f} GHz tick rate (if span ~ launch)")
     for i in range(8):
         print(f"  {names[i]:32s} median {np.median(d[:, i]):8.0f}  p90 {np.quantile(d[:, i], 0.9):8.0f}")
 else:
