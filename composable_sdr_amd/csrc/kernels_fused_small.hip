@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256, 3) void k_run64(SmallArgs SA)
         if (FM) {
             const float2 prev = g_i ? R[j_i * YS + 16 * g_i - 1] : yprev[b & 1][j_i];
             if (g_i == 0 && b == first && w > 0) SA.yfirst[(size_t)w * MS + j_i] = v[0];
-            if (owned_i && nv > 0) {
-                float m[16];
+            float m[16];
+            if (nv > 0) {
 #pragma unroll
                 for (int f = 0; f < 16; f++) {
                     const float2 rp = f ? v[f - 1] : prev, r = v[f];
@@ -257,31 +257,53 @@ __global__ __launch_bounds__(256, 3) void k_run64(SmallArgs SA)
                     const float im = fmaf(rp.x, r.y, -(rp.y * r.x));
                     m[f] = scaled_atan2f(im, re, pk);
                 }
-                float *o = (float *)A.out + row;
-                if (vec_out && nv >= 16) {
+            }
+            if (vec_out && nvalid == TS) {
+                // whole tile: transpose the demodulated samples through LDS so that 16 consecutive lanes write the
+                // 16 x 16-byte pieces of one channel's 64 frames (a wave instruction = 4 rows x 256 B)
+                __syncthreads();                                        // Y consumed by everyone
+                float4 *M4 = reinterpret_cast<float4 *>(R);
 #pragma unroll
-                    for (int q = 0; q < 4; q++) *reinterpret_cast<float4 *>(o + 4 * q) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
-                } else {
+                for (int q = 0; q < 4; q++) M4[j_i * 17 + 4 * g_i + q] = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+                // the next tile's r' is read from Y below: keep it before Y's region is reused
+                if (g_i == 3) yprev[(b + 1) & 1][j_i] = v[15];
+                __syncthreads();
+                float *obase = (float *)A.out + A.out_t0 + (size_t)TS * b;
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int item = tid_i + 256 * it, rowk = item >> 4, piece = item & 15;
+                    if ((uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
+                        *reinterpret_cast<float4 *>(obase + (size_t)(rowk - A.c0) * A.out_stride + 4 * piece) = M4[rowk * 17 + piece];
+                }
+            } else {
+                if (owned_i && nv > 0) {
+                    float *o = (float *)A.out + row;
 #pragma unroll
                     for (int f = 0; f < 16; f++) if (f < nv) o[f] = m[f];
                 }
-            }
-            // last valid frame of the tile -> next tile's r'
-            if (nv >= 1 && nv <= 16) {
-                float2 lv = v[0];
+                // last valid frame of the tile -> next tile's r'
+                if (nv >= 1 && nv <= 16) {
+                    float2 lv = v[0];
 #pragma unroll
-                for (int f = 1; f < 16; f++) if (f < nv) lv = v[f];
-                yprev[(b + 1) & 1][j_i] = lv;
+                    for (int f = 1; f < 16; f++) if (f < nv) lv = v[f];
+                    yprev[(b + 1) & 1][j_i] = lv;
+                }
+            }
+        } else if (vec_out && nvalid == TS) {
+            // CF32 rows leave as whole lines: 32 consecutive lanes write the 32 x 16-byte pieces of one channel's
+            // 64 frames (a wave instruction = 2 rows x 512 B) instead of 64 lanes x 16 B of scattered rows
+            float2 *obase = (float2 *)A.out + A.out_t0 + (size_t)TS * b;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int item = tid_i + 256 * it, rowk = item >> 5, piece = item & 31;
+                const float2 a0 = R[rowk * YS + 2 * piece], a1 = R[rowk * YS + 2 * piece + 1];
+                if ((uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
+                    *reinterpret_cast<float4 *>(obase + (size_t)(rowk - A.c0) * A.out_stride + 2 * piece) = make_float4(a0.x, a0.y, a1.x, a1.y);
             }
         } else if (owned_i && nv > 0) {
             float2 *o = (float2 *)A.out + row;
-            if (vec_out && nv >= 16) {
 #pragma unroll
-                for (int q = 0; q < 8; q++) *reinterpret_cast<float4 *>(o + 2 * q) = make_float4(v[2 * q].x, v[2 * q].y, v[2 * q + 1].x, v[2 * q + 1].y);
-            } else {
-#pragma unroll
-                for (int f = 0; f < 16; f++) if (f < nv) o[f] = v[f];
-            }
+            for (int f = 0; f < 16; f++) if (f < nv) o[f] = v[f];
         }
         __syncthreads();                                                // Y consumed, R free
     }
