@@ -30,8 +30,22 @@ namespace {
 
 struct AgcSeg { float g, y2; int32_t mode; uint32_t timer; float rx, ry; uint32_t pad0, pad1; };   // 32 B
 
-// agc_crcf_execute + squelch update + the reference's mute rule; the same code as agc_step in
-// kernels_generic.hip (kept textually identical so that both kernels round the same way)
+// agc_crcf_execute + squelch update + the reference's mute rule.  The float path is agc_step's of
+// kernels_generic.hip operation for operation (both kernels must round the same way); the squelch state machine
+// (agc_crcf_squelch_update_mode, modes 1..6 + timer) is folded into ONE integer S so that a step costs ~12
+// integer instructions instead of ~27:
+//   S = 1 ENABLED, 2 RISE, 3 SIGNALHI, 4 FALL, 8 TIMEOUT, 8+k SIGNALLO with k samples left on the timer
+// SIGNALLO counts down by S-1 and runs into TIMEOUT (8) on its own; the other transitions come out of two 3-bit
+// tables indexed by S.  The timer of the reference only lives in SIGNALLO (every other mode rewrites it before
+// reading it), so nothing is lost.
+constexpr uint32_t S_TEX = (2u << 3) | (3u << 6) | (3u << 9) | (3u << 12) | (1u << 24);   // threshold exceeded
+constexpr uint32_t S_TNO = (1u << 3) | (4u << 6) | (4u << 9) | (5u << 12) | (1u << 24);   // not exceeded; 5 = "enter SIGNALLO"
+__device__ __forceinline__ uint32_t s_encode(int32_t mode, uint32_t timer) { return mode == 6 ? 8u : (mode == 5 ? 8u + timer : (uint32_t)mode); }
+__device__ __forceinline__ void s_decode(uint32_t S, uint32_t timeout, int32_t &mode, uint32_t &timer)
+{
+    mode = S > 8u ? 5 : (S == 8u ? 6 : (int32_t)S);
+    timer = S > 8u ? S - 8u : timeout;
+}
 __device__ __forceinline__ float2 agc_tail_step(float2 x, AgcSeg &q, const AgcParams &p)
 {
     float2 y = make_float2(x.x * q.g, x.y * q.g);
@@ -41,15 +55,13 @@ __device__ __forceinline__ float2 agc_tail_step(float2 x, AgcSeg &q, const AgcPa
     q.g = (q.y2 > 1e-6f) ? q.g * upd : q.g;
     q.g = fminf(q.g, 1e6f);
     const bool ex = q.g < p.g_thr;                    // rssi > threshold
-    int m = q.mode;
-    const bool lo_to = (m == 5) && (q.timer == 1u);
-    q.timer = (m == 4) ? p.timeout : ((m == 5) ? q.timer - 1u : q.timer);
-    const int nxt_ex = (m == 1) ? 2 : ((m == 6) ? 1 : 3);
-    const int nxt_no = (m == 1) ? 1 : ((m == 4) ? 5 : ((m == 5) ? 5 : ((m == 6) ? 1 : 4)));
-    m = ex ? nxt_ex : nxt_no;
-    m = lo_to ? 6 : m;
-    q.mode = m;
-    if (m != 3) y = make_float2(0.f, 0.f);
+    const uint32_t S = (uint32_t)q.mode;              // AgcSeg.mode carries S inside this file
+    uint32_t t = __builtin_amdgcn_ubfe(ex ? S_TEX : S_TNO, 3u * S, 3u);
+    t = (t == 5u) ? 8u + p.timeout : t;
+    const uint32_t r9 = (ex && S >= 10u) ? 3u : S - 1u;
+    const uint32_t Sn = (S >= 9u) ? r9 : t;
+    q.mode = (int32_t)Sn;
+    if (Sn != 3u) y = make_float2(0.f, 0.f);          // reference mute rule (Liquid.chs:703-704)
     return y;
 }
 
@@ -61,9 +73,7 @@ __device__ __forceinline__ float fm_tail_sample(float2 rp, float2 r, float ref)
 
 __device__ __forceinline__ bool same_state(const AgcSeg &a, const AgcSeg &b, bool fm)
 {
-    // the timer only lives in SIGNALLO (mode 5): every other mode rewrites it before reading it
-    bool ok = __float_as_uint(a.g) == __float_as_uint(b.g) && __float_as_uint(a.y2) == __float_as_uint(b.y2) &&
-              a.mode == b.mode && (a.mode != 5 || a.timer == b.timer);
+    bool ok = __float_as_uint(a.g) == __float_as_uint(b.g) && __float_as_uint(a.y2) == __float_as_uint(b.y2) && a.mode == b.mode;
     if (fm) ok = ok && __float_as_uint(a.rx) == __float_as_uint(b.rx) && __float_as_uint(a.ry) == __float_as_uint(b.ry);
     return ok;
 }
@@ -82,41 +92,63 @@ struct TailArgs {
 // LDS slot of 16-byte piece `pc` (0..7) of stream `j` (0..63): XOR swizzle, conflict-free for the cooperative
 // side (8 streams x 8 pieces per instruction) and for the owner side (64 streams, one piece per instruction)
 __device__ __forceinline__ int slot8(int j, int pc) { return 8 * j + (pc ^ ((j ^ (j >> 3)) & 7)); }
-__device__ __forceinline__ int slot4(int j, int pc) { return 4 * j + (pc ^ ((j ^ (j >> 2)) & 3)); }
 
-template <bool FM>
-__global__ __launch_bounds__(64) void k_agc_spec(TailArgs A)
+// four consecutive samples of one stream: AGC (+ freqdem); GUARD: only samples t < end exist
+template <bool FM, bool GUARD>
+__device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, AgcSeg &q, const AgcParams &p, float ref,
+                                         uint32_t t, uint32_t end, float4 &oa, float4 &ob)
 {
-    __shared__ float4 ibuf[64 * 8];
-    __shared__ float4 obuf[64 * (FM ? 4 : 8)];
+    float2 y[4];
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    const float2 x[4] = {make_float2(va.x, va.y), make_float2(va.z, va.w), make_float2(vb.x, vb.y), make_float2(vb.z, vb.w)};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        y[i] = make_float2(0.f, 0.f);
+        if (!GUARD || t + i < end) {
+            y[i] = agc_tail_step(x[i], q, p);
+            if (FM) { m[i] = fm_tail_sample(make_float2(q.rx, q.ry), y[i], ref); q.rx = y[i].x; q.ry = y[i].y; }
+        }
+    }
+    if (FM) oa = make_float4(m[0], m[1], m[2], m[3]);
+    else { oa = make_float4(y[0].x, y[0].y, y[1].x, y[1].y); ob = make_float4(y[2].x, y[2].y, y[3].x, y[3].y); }
+}
+
+// One lane per (channel, segment); 64 streams per wave.  Each block of 16 samples goes
+//   global --(8 lanes per 128-byte line)--> registers --> LDS (one line per stream) --> its lane, four samples at a
+//   time; the outputs are written back over the stream's own consumed input pieces and leave the same
+//   cooperative way.  8 KiB of LDS and ~100 VGPRs per wave: the dependent AGC chain (~14 VALU + log2 + exp2 per
+//   sample) needs many waves per SIMD, not a fat one.
+template <bool FM>
+__global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A)   // <= 128 VGPRs: 4 waves per SIMD
+{
+    __shared__ float4 buf[64 * 8];
     const int lane = threadIdx.x;
     const uint32_t total = A.C * A.nseg;
     const uint32_t gid0 = blockIdx.x * 64u;
     const uint32_t gid = gid0 + lane;
     const bool mine = gid < total;
     const uint32_t c = mine ? gid / A.nseg : 0, sg = mine ? gid % A.nseg : 0;
-    const uint32_t start = sg * A.L, end = min(A.nf, start + A.L);
+    const uint32_t start = sg * A.L, end = mine ? min(A.nf, start + A.L) : 0u;
     const int32_t t00 = (int32_t)start - (int32_t)A.W;          // first sample of block 0 (may be negative)
-    const uint32_t nblk = (A.W + A.L) / 16u;
+    const uint32_t nblk = (A.W + A.L) / 16u, kreal = A.W / 16u;
 
-    // helper streams of this lane: instruction m of a cooperative access handles stream 8m + (lane >> 3)
-    // (CF32 lines) -- row offset and first sample index of each
-    uint32_t hrow[8]; int32_t ht0[8]; uint32_t hend[8];
+    // helper streams of this lane: instruction m of a cooperative access handles stream 8m + (lane >> 3):
+    // row offset (in samples) and segment start of each; hseg = 0xffffffff: no such stream
+    uint32_t hrow[8], hseg[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         const uint32_t g = gid0 + 8 * m + (lane >> 3);
         const bool ok = g < total;
         const uint32_t cc = ok ? g / A.nseg : 0, ss = ok ? g % A.nseg : 0;
         hrow[m] = cc * A.nf;                                   // C*nf < 2^32 samples (checked on the host)
-        ht0[m] = (int32_t)(ss * A.L) - (int32_t)A.W;
-        hend[m] = ok ? min(A.nf, ss * A.L + A.L) : 0u;        // 0: never loads
+        hseg[m] = ok ? ss * A.L : 0xffffffffu;
     }
     const int pc = lane & 7;
 
     AgcSeg q;
     {
         const AgcState s0 = A.st_in[c];
-        q.g = s0.g; q.y2 = s0.y2; q.mode = s0.mode; q.timer = s0.timer;
+        q.g = s0.g; q.y2 = s0.y2; q.mode = (int32_t)s_encode(s0.mode, s0.timer); q.timer = 0;
         const float2 r0 = FM ? A.rp_in[c] : make_float2(0.f, 0.f);
         q.rx = r0.x; q.ry = r0.y; q.pad0 = q.pad1 = 0;
     }
@@ -125,78 +157,72 @@ __global__ __launch_bounds__(64) void k_agc_spec(TailArgs A)
     auto coop_load = [&](uint32_t k) {
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-            const int32_t t = ht0[m] + (int32_t)(16 * k) + 2 * pc;          // first of the two samples of this piece
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && (uint32_t)t + 1 < hend[m]) {
-                const float2 *ptr = A.Z + (size_t)hrow[m] + (uint32_t)t;
-                if ((((size_t)hrow[m] + (uint32_t)t) & 1) == 0) v = *reinterpret_cast<const float4 *>(ptr);
-                else { const float2 a = ptr[0], b = ptr[1]; v = make_float4(a.x, a.y, b.x, b.y); }
-            } else if (t >= 0 && (uint32_t)t < hend[m]) {
-                const float2 a = A.Z[(size_t)hrow[m] + (uint32_t)t];
-                v = make_float4(a.x, a.y, 0.f, 0.f);
+            if (hseg[m] != 0xffffffffu) {
+                const int32_t t = (int32_t)hseg[m] - (int32_t)A.W + (int32_t)(16 * k) + 2 * pc;     // first of the piece's two samples
+                const uint32_t e = min(A.nf, hseg[m] + A.L);
+                if (t >= 0 && (uint32_t)t + 1 < e) {
+                    const size_t idx = (size_t)hrow[m] + (uint32_t)t;
+                    const float2 *ptr = A.Z + idx;
+                    if ((idx & 1) == 0) v = *reinterpret_cast<const float4 *>(ptr);
+                    else { const float2 a = ptr[0], b = ptr[1]; v = make_float4(a.x, a.y, b.x, b.y); }
+                } else if (t >= 0 && (uint32_t)t < e) {
+                    const float2 a = A.Z[(size_t)hrow[m] + (uint32_t)t];
+                    v = make_float4(a.x, a.y, 0.f, 0.f);
+                }
             }
             ld[m] = v;
         }
     };
 
-    coop_load(0);
     for (uint32_t k = 0; k < nblk; k++) {
-        __syncthreads();                                        // previous block's ibuf / obuf consumed
+        // no software prefetch: the loaded lines would pin 32 VGPRs through the whole block; the other waves of the
+        // SIMD cover the load latency instead
+        coop_load(k);
+        __syncthreads();                                        // previous block's buffer consumed
 #pragma unroll
-        for (int m = 0; m < 8; m++) ibuf[slot8(8 * m + (lane >> 3), pc)] = ld[m];
+        for (int m = 0; m < 8; m++) buf[slot8(8 * m + (lane >> 3), pc)] = ld[m];
         __syncthreads();
-        if (k + 1 < nblk) coop_load(k + 1);
 
         const int32_t t0 = t00 + (int32_t)(16 * k);
-        if (mine && k == A.W / 16u) A.seg_start[gid] = q;       // state at the segment start, after the warm-up
-        const bool real = k >= A.W / 16u;
-        const bool live = mine && t0 >= 0 && (uint32_t)t0 < end;
-        float4 o[FM ? 4 : 8];
-#pragma unroll
-        for (int i = 0; i < (FM ? 4 : 8); i++) o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) {
-            float4 in[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) in[i] = ibuf[slot8(lane, i)];
-            if ((uint32_t)t0 + 16 <= end) {
-                float fo[16];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float2 a = agc_tail_step(make_float2(in[i].x, in[i].y), q, A.p);
-                    if (FM) { fo[2 * i] = fm_tail_sample(make_float2(q.rx, q.ry), a, A.ref); q.rx = a.x; q.ry = a.y; }
-                    const float2 b = agc_tail_step(make_float2(in[i].z, in[i].w), q, A.p);
-                    if (FM) { fo[2 * i + 1] = fm_tail_sample(make_float2(q.rx, q.ry), b, A.ref); q.rx = b.x; q.ry = b.y; }
-                    else o[i] = make_float4(a.x, a.y, b.x, b.y);
-                }
-                if (FM) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) o[i] = make_float4(fo[4 * i], fo[4 * i + 1], fo[4 * i + 2], fo[4 * i + 3]);
+        if (mine && k == kreal) A.seg_start[gid] = q;           // state at the segment start, after the warm-up
+        const bool live = t0 >= 0 && (uint32_t)t0 < end;
+        const bool full = (uint32_t)t0 + 16 <= end;
+        if (live && k < kreal) {
+            // warm-up block (always whole): only the state matters -- no freqdem, nothing stored
+#pragma unroll 1
+            for (int h = 0; h < 4; h++) {
+                const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
+                float4 oa, ob;
+                agc_quad<false, false>(va, vb, q, A.p, A.ref, 0u, 0u, oa, ob);
+                if (FM) { q.rx = ob.z; q.ry = ob.w; }           // r' = the last (possibly muted) AGC output
+            }
+        } else if (live) {
+            if (full) {
+#pragma unroll 1
+                for (int h = 0; h < 4; h++) {
+                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
+                    float4 oa, ob;
+                    agc_quad<FM, false>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, end, oa, ob);
+                    // in place: output piece h (F32) / pieces 2h, 2h+1 (CF32) over input pieces already consumed
+                    if (FM) buf[slot8(lane, h)] = oa;
+                    else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
                 }
             } else {
-                // the row's last, partial block
-                float fo[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    fo[i] = 0.f;
-                    const float4 v = in[i >> 1];
-                    float2 a = make_float2(0.f, 0.f);
-                    if ((uint32_t)t0 + i < end) {
-                        a = agc_tail_step((i & 1) ? make_float2(v.z, v.w) : make_float2(v.x, v.y), q, A.p);
-                        if (FM) { fo[i] = fm_tail_sample(make_float2(q.rx, q.ry), a, A.ref); q.rx = a.x; q.ry = a.y; }
-                    }
-                    if (!FM) { if (i & 1) { o[i >> 1].z = a.x; o[i >> 1].w = a.y; } else { o[i >> 1].x = a.x; o[i >> 1].y = a.y; } }
-                }
-                if (FM) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++) o[i] = make_float4(fo[4 * i], fo[4 * i + 1], fo[4 * i + 2], fo[4 * i + 3]);
+#pragma unroll 1
+                for (int h = 0; h < 4; h++) {
+                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
+                    float4 oa, ob;
+                    agc_quad<FM, true>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, end, oa, ob);
+                    if (FM) buf[slot8(lane, h)] = oa;
+                    else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
                 }
             }
         }
-        if (real) {
-            // outputs leave as whole lines: transpose back through LDS
-#pragma unroll
-            for (int i = 0; i < (FM ? 4 : 8); i++) obuf[FM ? slot4(lane, i) : slot8(lane, i)] = o[i];
+        if (k >= kreal) {
+            // outputs leave as whole lines
             __syncthreads();
+            const uint32_t tb = 16 * (k - kreal);
             if (FM) {
                 float *outp = (float *)A.out;
 #pragma unroll
@@ -204,11 +230,12 @@ __global__ __launch_bounds__(64) void k_agc_spec(TailArgs A)
                     const int j = 16 * m + (lane >> 2), p4 = lane & 3;
                     const uint32_t g = gid0 + j;
                     if (g < total) {
-                        const uint32_t cc = g / A.nseg, ss = g % A.nseg;
-                        const uint32_t t = ss * A.L + 16 * (k - A.W / 16u) + 4 * p4, e = min(A.nf, ss * A.L + A.L);
-                        const float4 v = obuf[slot4(j, p4)];
-                        float *dst = outp + (size_t)cc * A.nf + t;
-                        if (t + 4 <= e && ((((size_t)cc * A.nf + t) & 3) == 0)) *reinterpret_cast<float4 *>(dst) = v;
+                        const uint32_t cc = g / A.nseg, ss = g - cc * A.nseg;
+                        const uint32_t t = ss * A.L + tb + 4 * p4, e = min(A.nf, ss * A.L + A.L);
+                        const float4 v = buf[slot8(j, p4)];
+                        const size_t idx = (size_t)cc * A.nf + t;
+                        float *dst = outp + idx;
+                        if (t + 4 <= e && (idx & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
                         else {
                             if (t < e) dst[0] = v.x;
                             if (t + 1 < e) dst[1] = v.y;
@@ -221,14 +248,12 @@ __global__ __launch_bounds__(64) void k_agc_spec(TailArgs A)
                 float2 *outp = (float2 *)A.out;
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
-                    const int j = 8 * m + (lane >> 3);
-                    const uint32_t g = gid0 + j;
-                    if (g < total) {
-                        const uint32_t cc = hrow[m] / max(A.nf, 1u), ss = g - cc * A.nseg;
-                        const uint32_t t = ss * A.L + 16 * (k - A.W / 16u) + 2 * pc, e = hend[m];
-                        const float4 v = obuf[slot8(j, pc)];
-                        float2 *dst = outp + (size_t)hrow[m] + t;
-                        if (t + 2 <= e && ((((size_t)hrow[m] + t) & 1) == 0)) *reinterpret_cast<float4 *>(dst) = v;
+                    if (hseg[m] != 0xffffffffu) {
+                        const uint32_t t = hseg[m] + tb + 2 * pc, e = min(A.nf, hseg[m] + A.L);
+                        const float4 v = buf[slot8(8 * m + (lane >> 3), pc)];
+                        const size_t idx = (size_t)hrow[m] + t;
+                        float2 *dst = outp + idx;
+                        if (t + 2 <= e && (idx & 1) == 0) *reinterpret_cast<float4 *>(dst) = v;
                         else {
                             if (t < e) dst[0] = make_float2(v.x, v.y);
                             if (t + 1 < e) dst[1] = make_float2(v.z, v.w);
@@ -274,7 +299,7 @@ __global__ __launch_bounds__(64) void k_agc_fix(TailArgs A, AgcState *st_out, fl
             } else ((float2 *)A.out)[(size_t)c * A.nf + t] = y;
         }
     }
-    AgcState o; o.g = cur.g; o.y2 = cur.y2; o.mode = cur.mode; o.timer = cur.timer;
+    AgcState o; o.g = cur.g; o.y2 = cur.y2; s_decode((uint32_t)cur.mode, A.p.timeout, o.mode, o.timer);
     st_out[c] = o;
     if (FM) rp_out[c] = make_float2(cur.rx, cur.ry);
     if (redone) atomicAdd(&stats[1], redone);
@@ -284,7 +309,7 @@ __global__ __launch_bounds__(64) void k_agc_fix(TailArgs A, AgcState *st_out, fl
 }  // namespace
 
 struct AgcTailPlan {
-    uint32_t C = 0, max_nf = 0, L = 512, W = 1024, max_seg = 0;
+    uint32_t C = 0, max_nf = 0, L = 384, W = 1024, max_seg = 0;
     AgcSeg *d_start = nullptr, *d_end = nullptr;
     AgcState *d_st_tmp = nullptr;
     unsigned *d_stats = nullptr;
@@ -303,7 +328,9 @@ int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        p->lanes_target = (uint32_t)cus * 4u * 64u * 2u;
+        uint32_t wps = 3;                                   // waves per SIMD the segment length aims for
+        if (const char *e = getenv("CSDR_AGC_WAVES")) wps = (uint32_t)atol(e);
+        p->lanes_target = (uint32_t)cus * 4u * 64u * (wps ? wps : 1u);
     }
     p->max_seg = (max_nf + 15u) / 16u + 1;                      // L >= 16
     const size_t n = (size_t)C * p->max_seg;

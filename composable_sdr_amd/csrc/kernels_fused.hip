@@ -376,15 +376,30 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
             }
         }
         float2 acc = make_float2(0.f, 0.f);
-        for (unsigned t = h0; t < halo; t++) {
-            tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
+        auto fold = [&](const float4 (&r)[8]) {
             float2 p = make_float2(0.f, 0.f);
 #pragma unroll
             for (int it = 0; it < 8; it++) {
-                p = cfma(make_float2(raw[it].x, raw[it].y), w0[it], p);
-                p = cfma(make_float2(raw[it].z, raw[it].w), w1[it], p);
+                p = cfma(make_float2(r[it].x, r[it].y), w0[it], p);
+                p = cfma(make_float2(r[it].z, r[it].w), w1[it], p);
             }
             acc = cfma(acc, A.b256[16], p);
+        };
+        unsigned t = h0;
+        if (halo - h0 == (unsigned)WU) {
+            // the usual case: two batches of three tiles, so that only two load latencies are exposed instead of six
+            float4 rb[8], rc[8];
+#pragma unroll 1
+            for (int half = 0; half < 2; half++, t += 3) {
+                tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
+                tile_load(x4 + (size_t)(t + 1) * 2048, 256, rb, tid);
+                tile_load(x4 + (size_t)(t + 2) * 2048, 256, rc, tid);
+                fold(raw); fold(rb); fold(rc);
+            }
+        }
+        for (; t < halo; t++) {
+            tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
+            fold(raw);
         }
         float2 ch = wg_sum(acc, red, tid);                          // also orders tw_s
         LSTAMP(12);
