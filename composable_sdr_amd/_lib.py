@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("CSDR_LIB") or os.path.join(_HERE, "libcsdr_hip.so")   # CSDR_LIB: A/B builds
 
-DEMOD_NONE, DEMOD_FM = 0, 1
+DEMOD_NONE, DEMOD_FM, DEMOD_AM = 0, 1, 2
 FLAG_TIME_KERNELS, FLAG_FORCE_GENERIC, FLAG_QUIET, FLAG_AGC_SEQUENTIAL = 1, 2, 4, 8
 
 ERR_INVALID, ERR_HIP, ERR_NODEV, ERR_SIZE, ERR_NOMEM = -1, -2, -3, -4, -5
@@ -52,6 +52,9 @@ SIGNATURES = {
     "csdr_freqdem_create": (_i32, [_f32, _u32, _u32, _pp]),
     "csdr_freqdem_process": (_i32, [_vp, _vp, _u32, _vp]),
     "csdr_freqdem_destroy": (_i32, [_vp]),
+    "csdr_ampdem_create": (_i32, [_f32, _u32, _u32, _pp]),
+    "csdr_ampdem_process": (_i32, [_vp, _vp, _u32, _vp]),
+    "csdr_ampdem_destroy": (_i32, [_vp]),
     "csdr_chain_cfg_default": (None, [C.POINTER(ChainCfg), _u32]),
     "csdr_chain_create": (_i32, [C.POINTER(ChainCfg), _pp]),
     "csdr_chain_process": (_i32, [_vp, _vp, _u32, _vp, _pu32]),

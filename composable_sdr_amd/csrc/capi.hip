@@ -80,6 +80,10 @@ struct csdr_nco {
 struct csdr_agc {
     int device; uint32_t C, max_n; AgcParams p; AgcState *d_st = nullptr; float2 *d_z = nullptr;
 };
+struct csdr_ampdem {
+    int device; uint32_t C, max_n; float *d_q[2] = {nullptr, nullptr}; int cur = 0;
+    float2 *d_z = nullptr; float *d_f = nullptr;
+};
 struct csdr_freqdem {
     int device; uint32_t C, max_n; float ref; float2 *d_rp[2] = {nullptr, nullptr}; int cur = 0;
     float2 *d_z = nullptr; float *d_f = nullptr;
@@ -107,6 +111,9 @@ struct csdr_chain {
     SmallPlan *small = nullptr;
     DcTilePlan *dctile = nullptr;   // generic path with the DC blocker: single-pass scan kernel
     AgcTailPlan *agc_tail = nullptr; // AGC on: time-parallel verified tail (unless CSDR_FLAG_AGC_SEQUENTIAL)
+    // DeAM: the chain runs as DeNo into d_amz, then the ampmodem peak detector (kernels_am.hip) [+ mix]
+    bool am = false, am_mix = false;
+    float2 *d_amz = nullptr; float *d_amf = nullptr; float *d_amq[2] = {nullptr, nullptr}; int amq_cur = 0;
     KernelTimer timer;
     std::string timed_kernel;
 };
@@ -300,6 +307,47 @@ int csdr_freqdem_destroy(csdr_freqdem *h)
 }
 
 // ---------------------------------------------------------------------------
+// amDemodulator (Liquid.chs:439-469)
+// ---------------------------------------------------------------------------
+int csdr_ampdem_create(float mod_index, uint32_t nchan, uint32_t max_samples, csdr_ampdem **out)
+{
+    if (!out || !nchan || !(mod_index > 0.f)) { set_error("ampdem: bad arguments (mod_index must be > 0)"); return CSDR_ERR_INVALID; }
+    int dev; int r = check_device(-1, &dev); if (r) return r;
+    csdr_ampdem *h = new (std::nothrow) csdr_ampdem();
+    if (!h) return CSDR_ERR_NOMEM;
+    h->device = dev; h->C = nchan; h->max_n = max_samples ? max_samples : 4096;
+    if ((r = dev_alloc(&h->d_z, (size_t)nchan * h->max_n)) || hipMalloc(&h->d_f, sizeof(float) * (size_t)nchan * h->max_n) != hipSuccess ||
+        hipMalloc(&h->d_q[0], sizeof(float) * nchan) != hipSuccess || hipMalloc(&h->d_q[1], sizeof(float) * nchan) != hipSuccess) {
+        set_error("ampdem: device allocation failed");
+        csdr_ampdem_destroy(h); return r ? r : CSDR_ERR_HIP;
+    }
+    CSDR_HIP(hipMemset(h->d_q[0], 0, sizeof(float) * nchan));
+    CSDR_HIP(hipMemset(h->d_q[1], 0, sizeof(float) * nchan));
+    *out = h;
+    return CSDR_OK;
+}
+int csdr_ampdem_process(csdr_ampdem *h, const float *x, uint32_t n, float *m)
+{
+    if (!h || (n && (!x || !m))) { set_error("ampdem: null argument"); return CSDR_ERR_INVALID; }
+    if (n > h->max_n) { set_error("ampdem: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
+    if (!n) return CSDR_OK;
+    DevGuard guard(h->device);
+    CSDR_HIP(hipMemcpy(h->d_z, x, sizeof(float2) * (size_t)h->C * n, hipMemcpyHostToDevice));
+    int r = launch_am(h->d_z, h->d_f, h->C, n, h->d_q[h->cur], h->d_q[h->cur ^ 1], 0.01f, nullptr);
+    if (r) return r;
+    h->cur ^= 1;
+    CSDR_HIP(hipMemcpy(m, h->d_f, sizeof(float) * (size_t)h->C * n, hipMemcpyDeviceToHost));
+    return CSDR_OK;
+}
+int csdr_ampdem_destroy(csdr_ampdem *h)
+{
+    if (!h) return CSDR_OK;
+    (void)hipFree(h->d_q[0]); (void)hipFree(h->d_q[1]); (void)hipFree(h->d_z); (void)hipFree(h->d_f);
+    delete h;
+    return CSDR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // fused chain
 // ---------------------------------------------------------------------------
 void csdr_chain_cfg_default(csdr_chain_cfg *cfg, uint32_t channels)
@@ -329,18 +377,29 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
         CSDR_HIP(hipMemsetAsync(h->d_rp[0], 0, sizeof(float2) * h->C, s));
         CSDR_HIP(hipMemsetAsync(h->d_rp[1], 0, sizeof(float2) * h->C, s));
     }
+    if (h->d_amq[0]) {
+        h->amq_cur = 0;
+        CSDR_HIP(hipMemsetAsync(h->d_amq[0], 0, sizeof(float) * h->C, s));     // ampmodem_reset: q_hat = 0
+        CSDR_HIP(hipMemsetAsync(h->d_amq[1], 0, sizeof(float) * h->C, s));
+    }
     if (h->fused) { int r = fused_reset(h->fused, s); if (r) return r; }
     if (h->small) { int r = small_reset(h->small, s); if (r) return r; }
     if (h->dctile) { int r = dctile_reset(h->dctile, s); if (r) return r; }
     return 0;
 }
 
-int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
+int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
 {
-    if (!cfg || !out) { set_error("chain: null argument"); return CSDR_ERR_INVALID; }
-    if (cfg->struct_size != sizeof(csdr_chain_cfg)) { set_error("chain: cfg.struct_size %u != %zu", cfg->struct_size, sizeof(csdr_chain_cfg)); return CSDR_ERR_INVALID; }
+    if (!cfg_in || !out) { set_error("chain: null argument"); return CSDR_ERR_INVALID; }
+    if (cfg_in->struct_size != sizeof(csdr_chain_cfg)) { set_error("chain: cfg.struct_size %u != %zu", cfg_in->struct_size, sizeof(csdr_chain_cfg)); return CSDR_ERR_INVALID; }
+    if (cfg_in->demod > CSDR_DEMOD_AM) { set_error("chain: unknown demod %u", cfg_in->demod); return CSDR_ERR_INVALID; }
+    // DeAM = amDemodulator . agc (SoapySDR.hs:265-272): everything up to the per-channel CF32 samples is the DeNo
+    // chain; the peak detector and the mix follow as a tail (see csdr_chain_process_device)
+    csdr_chain_cfg eff = *cfg_in;
+    const bool am = cfg_in->demod == CSDR_DEMOD_AM, am_mix = am && cfg_in->mix != 0 && cfg_in->channels > 1;
+    if (am) { eff.demod = CSDR_DEMOD_NONE; eff.mix = 0; }
+    const csdr_chain_cfg *cfg = &eff;
     if (cfg->channels < 1 || cfg->channels > (1u << 16)) { set_error("chain: channels %u out of range", cfg->channels); return CSDR_ERR_INVALID; }
-    if (cfg->demod > CSDR_DEMOD_FM) { set_error("chain: unknown demod %u", cfg->demod); return CSDR_ERR_INVALID; }
     if (cfg->demod == CSDR_DEMOD_FM && !(cfg->kf > 0.f)) { set_error("chain: FM needs kf > 0"); return CSDR_ERR_INVALID; }
     if (cfg->dc_block && !(cfg->dc_alpha > 0.f && cfg->dc_alpha < 1.f)) { set_error("chain: dc_alpha out of (0,1)"); return CSDR_ERR_INVALID; }
     const uint32_t M = cfg->channels;
@@ -426,6 +485,13 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
         if ((r = dev_alloc(&h->d_A, h->max_nx)) || (r = dev_alloc(&h->d_B, h->max_nx))) return fail(r);
         if (M > 1 && cfg->dc_block && (r = dctile_create(h->dc, h->max_nx, &h->dctile))) return fail(r);
     }
+    if (am) {
+        h->am = true; h->am_mix = am_mix;
+        if ((r = dev_alloc(&h->d_amz, (size_t)C * h->max_nf))) return fail(r);
+        if (am_mix) { CSDR_HIP(hipMalloc(&h->d_amf, sizeof(float) * (size_t)C * h->max_nf)); }
+        CSDR_HIP(hipMalloc(&h->d_amq[0], sizeof(float) * C)); CSDR_HIP(hipMalloc(&h->d_amq[1], sizeof(float) * C));
+        h->path += "+am";
+    }
     if (h->d_agc && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL)) {
         if ((r = agc_tail_create(C, h->max_nf, &h->agc_tail))) return fail(r);
         h->path += h->use_fused ? "-spec" : "+agc-spec";
@@ -438,14 +504,14 @@ int csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out)
         printf("csdr chain [%s] on HIP device %d: channels=%u (shard %u..%u) taps=%u (m=%u, As=%.1f) "
                "nco.d_theta=0x%08x dc_block=%u(alpha=%g) agc=%g dB demod=%s kf=%g mix=%u\n",
                h->path.c_str(), dev, M, c0, c0 + C - 1, M > 1 ? M * h->p : 0, m, As, h->d_theta, cfg->dc_block,
-               cfg->dc_alpha, cfg->agc_threshold_db, cfg->demod == CSDR_DEMOD_FM ? "FM" : "none", cfg->kf, cfg->mix);
+               cfg->dc_alpha, cfg->agc_threshold_db, am ? "AM" : (cfg->demod == CSDR_DEMOD_FM ? "FM" : "none"), cfg->kf, cfg_in->mix);
         fflush(stdout);
     }
     *out = h;
     return CSDR_OK;
 }
 
-uint32_t csdr_chain_out_elem_size(const csdr_chain *h) { return h && h->cfg.demod == CSDR_DEMOD_FM ? 4u : 8u; }
+uint32_t csdr_chain_out_elem_size(const csdr_chain *h) { return h && (h->cfg.demod == CSDR_DEMOD_FM || h->am) ? 4u : 8u; }
 
 // AGC on: Z[C][nf] (channel-major CF32 in d_A) -> AGC + squelch [+ freqdem] [+ mix] -> d_out
 static int chain_agc_tail(csdr_chain *h, const float2 *Z, uint32_t nf, void *d_out, hipStream_t s)
@@ -511,7 +577,28 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
     return 0;
 }
 
+static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream);
+
 int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
+{
+    if (!h || !h->am) return chain_process_device_inner(h, d_in, n_in, d_out, n_out, stream);
+    if (n_out) *n_out = 0;
+    if (n_in == 0) return CSDR_OK;
+    if (!d_out) { set_error("chain: null buffer"); return CSDR_ERR_INVALID; }
+    int r = chain_process_device_inner(h, d_in, n_in, h->d_amz, nullptr, stream);
+    if (r) return r;
+    DevGuard guard(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nf = n_in / h->M;
+    float *F = h->am_mix ? h->d_amf : (float *)d_out;
+    if ((r = launch_am(h->d_amz, F, h->C, nf, h->d_amq[h->amq_cur], h->d_amq[h->amq_cur ^ 1], 0.01f, s))) return r;
+    h->amq_cur ^= 1;
+    if (h->am_mix && (r = launch_mix(F, (float *)d_out, h->C, nf, s))) return r;
+    if (n_out) *n_out = h->am_mix ? nf : h->C * nf;
+    return CSDR_OK;
+}
+
+static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
 {
     if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
     if (n_out) *n_out = 0;
@@ -656,7 +743,7 @@ int csdr_chain_destroy(csdr_chain *h)
     if (h->agc_tail) agc_tail_destroy(h->agc_tail);
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
-                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_in_stage, h->d_out_stage};
+                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_in_stage, h->d_out_stage, h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return CSDR_OK;

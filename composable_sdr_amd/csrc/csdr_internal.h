@@ -92,6 +92,10 @@ int launch_transpose_fm(const float2 *Y, float *F, uint32_t M, uint32_t nf, uint
 int launch_mix_frames(const float2 *Y, void *out, bool fm, uint32_t M, uint32_t nf, uint32_t c0, uint32_t C, float ref,
                       const float2 *rp_in, float2 *rp_out, hipStream_t s);
 
+// ---- ampmodem DSB peak detector (kernels_am.hip): F[c][t] = 2 (|Z| - q_hat), q_hat a one-pole smoother per channel;
+// q_in / q_out must be different arrays (ping-pong)
+int launch_am(const float2 *Z, float *F, uint32_t C, uint32_t nf, const float *q_in, float *q_out, float alpha, hipStream_t s);
+
 // ---- time-parallel exact AGC [+ freqdem] tail (kernels_agc_tail.hip) ----
 struct AgcTailPlan;
 int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out);

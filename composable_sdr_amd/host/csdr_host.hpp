@@ -127,7 +127,7 @@ template <class T> struct FileSink : Fold<Array<T>> {
 
 // ---- the fused chain as a Pipe (replaces mix . mux (replicate nch demod) . firpfbchChannelizer nc) ----
 struct ChainOpts {
-    uint32_t channels = 1; bool dc_block = true; float agc = 0.f; bool fm = false; float kf = 0.3f; bool mix = false;
+    uint32_t channels = 1; bool dc_block = true; float agc = 0.f; bool fm = false; bool am = false; float kf = 0.3f; bool mix = false;
     uint32_t max_frames = 4096; uint32_t flags = CSDR_FLAG_QUIET;
 };
 
@@ -138,7 +138,7 @@ template <class Out> Pipe<Array<cf32>, std::vector<Array<Out>>> fusedChain(const
         csdr_chain_cfg cfg;
         csdr_chain_cfg_default(&cfg, o.channels);
         cfg.channels = o.channels; cfg.dc_block = o.dc_block; cfg.agc_threshold_db = o.agc;
-        cfg.demod = o.fm ? CSDR_DEMOD_FM : CSDR_DEMOD_NONE; cfg.kf = o.kf; cfg.mix = o.mix; cfg.max_frames = o.max_frames; cfg.flags = o.flags;
+        cfg.demod = o.fm ? CSDR_DEMOD_FM : (o.am ? CSDR_DEMOD_AM : CSDR_DEMOD_NONE); cfg.kf = o.kf; cfg.mix = o.mix; cfg.max_frames = o.max_frames; cfg.flags = o.flags;
         csdr_chain *h = nullptr;
         check(csdr_chain_create(&cfg, &h));
         return std::shared_ptr<void>(h, [](void *q) { csdr_chain_destroy(static_cast<csdr_chain *>(q)); });

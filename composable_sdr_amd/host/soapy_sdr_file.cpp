@@ -1,5 +1,5 @@
 // soapy-sdr's file-input mode (apps/SoapySDR.hs:181-283) on the C-ABI chain:
-//   soapy_sdr_file --filename in.cf32 -n N -c M [--demod DeNo|DeNBFM kf] [-a dB] [-m] [-o output] [--chunksize 1024]
+//   soapy_sdr_file --filename in.cf32 -n N -c M [--demod DeNo|DeNBFM kf|DeAM] [-a dB] [-m] [-o output] [--chunksize 1024]
 // readFromFile -> takeNArr -> compact(4*M*1024) -> fused chain (dcBlocker + PFB + demod [+mix]) -> fileSinks
 // named <out>.cf32 / <out>_ch<k>.cf32 (DeNo, SoapySDR.hs:240) or raw .f32 for FM (the reference wraps
 // the same samples in WAV/AU through libsndfile).
@@ -52,12 +52,12 @@ int main(int argc, char **argv)
         else if (a == "-m" || a == "--mix") o.mix = true;
         else if (a == "-o" || a == "--output") out = next();
         else if (a == "--chunksize") chunk = std::strtoull(next(), nullptr, 10);
-        else if (a == "--demod") { demod = next(); if (demod == "DeNBFM") { o.fm = true; o.kf = (float)std::atof(next()); } }
+        else if (a == "--demod") { demod = next(); if (demod == "DeNBFM") { o.fm = true; o.kf = (float)std::atof(next()); } else if (demod == "DeAM") o.am = true; }
         else { std::cerr << "unknown option " << a << "\n"; return 2; }
     }
     if (in.empty()) { std::cerr << "--filename is required (SoapySDR live sources are out of scope)\n"; return 2; }
     try {
-        return o.fm ? run<float>(in, o, n, out, chunk, ".f32") : run<cf32>(in, o, n, out, chunk, ".cf32");
+        return (o.fm || o.am) ? run<float>(in, o, n, out, chunk, ".f32") : run<cf32>(in, o, n, out, chunk, ".cf32");
     } catch (const std::exception &e) {
         std::cerr << e.what() << "\n";
         return 1;

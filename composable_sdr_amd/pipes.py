@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import CsdrError, check, lib, DEMOD_FM, DEMOD_NONE
+from ._lib import CsdrError, check, lib, DEMOD_AM, DEMOD_FM, DEMOD_NONE
 
 
 def _c64(x):
@@ -140,13 +140,29 @@ def fmDemodulator(kf, nchan=1, max_samples=4096):
     return Pipe(start, process, lambda r: r.close())
 
 
+def amDemodulator(nchan=1, max_samples=4096, mod_index=0.8):
+    """amDemodulator (Liquid.chs:468-469): ampmodem_create 0.8 DSB, carrier present."""
+    def start():
+        h = C.c_void_p()
+        check(lib().csdr_ampdem_create(mod_index, nchan, max_samples, C.byref(h)))
+        return _Handle(h, lib().csdr_ampdem_destroy)
+
+    def process(r, a):
+        x = _c64(a)
+        n = x.size // nchan
+        m = np.empty(x.shape, dtype=np.float32)
+        check(lib().csdr_ampdem_process(r.h, _ptr(x), n, _ptr(m)))
+        return m
+    return Pipe(start, process, lambda r: r.close())
+
+
 @dataclass
 class ChainConfig:
     channels: int = 1
     dc_block: bool = True
     dc_alpha: float = 0.0005
     agc: float = 0.0            # -a; 0 = off
-    demod: str = "none"         # "none" (DeNo) | "fm" (DeNBFM kf)
+    demod: str = "none"         # "none" (DeNo) | "fm" (DeNBFM kf) | "am" (DeAM)
     kf: float = 0.3
     mix: bool = False
     chan_first: int = 0
@@ -169,7 +185,7 @@ class Chain:
         c.channels = cfg.channels
         c.dc_block, c.dc_alpha = int(cfg.dc_block), cfg.dc_alpha
         c.agc_threshold_db = cfg.agc
-        c.demod = {"none": DEMOD_NONE, "fm": DEMOD_FM}[cfg.demod]
+        c.demod = {"none": DEMOD_NONE, "fm": DEMOD_FM, "am": DEMOD_AM}[cfg.demod]
         c.kf, c.mix = cfg.kf, int(cfg.mix)
         c.chan_first, c.chan_count = cfg.chan_first, cfg.chan_count
         c.device, c.max_frames, c.flags = cfg.device, cfg.max_frames, cfg.flags
@@ -180,7 +196,7 @@ class Chain:
         self.M = cfg.channels
         self.C = cfg.chan_count or (cfg.channels - cfg.chan_first)
         self.mixed = bool(cfg.mix) and self.M > 1
-        self.out_dtype = np.float32 if cfg.demod == "fm" else np.complex64
+        self.out_dtype = np.float32 if cfg.demod in ("fm", "am") else np.complex64
 
     @property
     def h(self):

@@ -45,6 +45,8 @@ extern "C" {
 
 #define CSDR_DEMOD_NONE 0u      /* DeNo: per-channel CF32 out (SoapySDR.hs:236-243)      */
 #define CSDR_DEMOD_FM   1u      /* DeNBFM kf: freqdem, F32 out (SoapySDR.hs:244-251)     */
+#define CSDR_DEMOD_AM   2u      /* DeAM: ampmodem DSB peak detector, F32 out
+                                   (SoapySDR.hs:265-272, Liquid.chs:439-469)              */
 
 /* cfg.flags */
 #define CSDR_FLAG_TIME_KERNELS 1u   /* bracket the dominant kernel with hipEvents         */
@@ -106,6 +108,18 @@ typedef struct csdr_freqdem csdr_freqdem;
 int csdr_freqdem_create(float kf, uint32_t nchan, uint32_t max_samples, csdr_freqdem **out);
 int csdr_freqdem_process(csdr_freqdem *h, const float *x_cf32, uint32_t n, float *m_f32);
 int csdr_freqdem_destroy(csdr_freqdem *h);
+
+/* ------------------------------------------------------------------------ *
+ * amDemodulator  (Liquid.chs:439-469), `nchan` independent instances.
+ *   replaces ampmodem_create(0.8, LIQUID_AMPMODEM_DSB, 0) / ampmodem_demodulate_block /
+ *   ampmodem_destroy (imports :441-450).  x is [nchan][n] CF32, m is [nchan][n] F32.
+ *   Arithmetic = liquid-dsp 1.3.2's non-coherent peak detector as recalled (unpinned):
+ *   t = |x|, q <- 0.01 t + 0.99 q, m = 2 (t - q); mod_index is accepted and unused, as there.
+ * ------------------------------------------------------------------------ */
+typedef struct csdr_ampdem csdr_ampdem;
+int csdr_ampdem_create(float mod_index, uint32_t nchan, uint32_t max_samples, csdr_ampdem **out);
+int csdr_ampdem_process(csdr_ampdem *h, const float *x_cf32, uint32_t n, float *m_f32);
+int csdr_ampdem_destroy(csdr_ampdem *h);
 
 /* ------------------------------------------------------------------------ *
  * The fused chain: everything assembleFold (apps/SoapySDR.hs:208-226) puts

@@ -450,6 +450,35 @@ void orc_freqdem_demodulate_block(orc_freqdem *q, const cf32 *r, unsigned n, flo
 }
 
 /* ------------------------------------------------------------------ */
+/* ampmodem (ampmodem.c); reference amDemodulator Liquid.chs:439-469:    */
+/* ampmodem_create(0.8, 0 = LIQUID_AMPMODEM_DSB, 0 = carrier present).   */
+/* RECALLED, UNPINNED: liquid-dsp 1.3.2's DSB / non-suppressed-carrier   */
+/* branch is the non-coherent peak detector                             */
+/*     t = cabsf(y);  q_hat = alpha*t + (1-alpha)*q_hat;  x = 2*(t-q_hat)*/
+/* with ssb_alpha = 0.01 and q_hat = 0 after create/reset.  The          */
+/* modulation index (0.8) is not used on this branch.  Nothing in the    */
+/* reference (no test, no printed state) confirms the constants.         */
+/* ------------------------------------------------------------------ */
+typedef struct { float mod_index, alpha, q_hat; } orc_ampdem;
+
+orc_ampdem *orc_ampdem_create(float mod_index)
+{
+    orc_ampdem *q = (orc_ampdem *)calloc(1, sizeof(*q));
+    q->mod_index = mod_index; q->alpha = 0.01f; q->q_hat = 0.0f;
+    return q;
+}
+void orc_ampdem_destroy(orc_ampdem *q) { free(q); }
+
+void orc_ampdem_demodulate_block(orc_ampdem *q, const cf32 *y, unsigned n, float *x)
+{
+    for (unsigned i = 0; i < n; i++) {
+        float t = hypotf(y[i].re, y[i].im);          /* cabsf */
+        q->q_hat = q->alpha * t + (1.0f - q->alpha) * q->q_hat;
+        x[i] = 2.0f * (t - q->q_hat);
+    }
+}
+
+/* ------------------------------------------------------------------ */
 /* mix (Trans.hs:119-122): strict left fold of element-wise +.          */
 /* ------------------------------------------------------------------ */
 void orc_mix_f32(const float *chans, unsigned M, unsigned n, float *out)
@@ -474,6 +503,7 @@ typedef struct {
     orc_chan *chan;
     orc_agc **agc;
     orc_freqdem **fm;
+    orc_ampdem **am;
 } orc_chain;
 
 orc_chain *orc_chain_create(unsigned M, int dc_block, int agc_enable, float agc_thr_db,
@@ -491,6 +521,10 @@ orc_chain *orc_chain_create(unsigned M, int dc_block, int agc_enable, float agc_
         q->fm = (orc_freqdem **)calloc(M, sizeof(orc_freqdem *));
         for (unsigned k = 0; k < M; k++) q->fm[k] = orc_freqdem_create(kf);
     }
+    if (demod == 2) {                                    /* DeAM: amDemodulator . agc (SoapySDR.hs:265-272) */
+        q->am = (orc_ampdem **)calloc(M, sizeof(orc_ampdem *));
+        for (unsigned k = 0; k < M; k++) q->am[k] = orc_ampdem_create(0.8f);   /* Liquid.chs:455 */
+    }
     return q;
 }
 void orc_chain_destroy(orc_chain *q)
@@ -500,6 +534,7 @@ void orc_chain_destroy(orc_chain *q)
     if (q->chan) orc_chan_destroy(q->chan);
     if (q->agc) { for (unsigned k = 0; k < q->M; k++) orc_agc_destroy(q->agc[k]); free(q->agc); }
     if (q->fm) { for (unsigned k = 0; k < q->M; k++) orc_freqdem_destroy(q->fm[k]); free(q->fm); }
+    if (q->am) { for (unsigned k = 0; k < q->M; k++) orc_ampdem_destroy(q->am[k]); free(q->am); }
     free(q);
 }
 
@@ -520,10 +555,12 @@ void orc_chain_process(orc_chain *q, const cf32 *x, unsigned nx, void *out)
             orc_agc_execute_block_ref(q->agc[k], cur + (size_t)k * nf, nf, t + (size_t)k * nf);
         cur = t;
     }
-    if (q->demod == 1) {
+    if (q->demod == 1 || q->demod == 2) {
         float *f = (float *)malloc(sizeof(float) * (tot ? tot : 1));
-        for (unsigned k = 0; k < M; k++)
-            orc_freqdem_demodulate_block(q->fm[k], cur + (size_t)k * nf, nf, f + (size_t)k * nf);
+        for (unsigned k = 0; k < M; k++) {
+            if (q->demod == 1) orc_freqdem_demodulate_block(q->fm[k], cur + (size_t)k * nf, nf, f + (size_t)k * nf);
+            else orc_ampdem_demodulate_block(q->am[k], cur + (size_t)k * nf, nf, f + (size_t)k * nf);
+        }
         if (q->mix && M > 1) orc_mix_f32(f, M, nf, (float *)out);
         else memcpy(out, f, sizeof(float) * tot);
         free(f);

@@ -64,6 +64,9 @@ def lib():
             "orc_freqdem_destroy": (None, [vp]),
             "orc_freqdem_ref": (f32, [vp]),
             "orc_freqdem_demodulate_block": (None, [vp, vp, u32, vp]),
+            "orc_ampdem_create": (vp, [f32]),
+            "orc_ampdem_destroy": (None, [vp]),
+            "orc_ampdem_demodulate_block": (None, [vp, vp, u32, vp]),
             "orc_mix_f32": (None, [vp, u32, u32, vp]),
             "orc_chain_create": (vp, [u32, i32, i32, f32, i32, f32, i32]),
             "orc_chain_destroy": (None, [vp]),
@@ -250,6 +253,20 @@ class FreqDem(_Obj):
         return m
 
 
+class AmpDem(_Obj):
+    """ampmodem DSB, carrier present (amdemodCreate, Liquid.chs:452-457) -- recalled, unpinned"""
+    _destroy = "orc_ampdem_destroy"
+
+    def __init__(self, mod_index=0.8):
+        self.h = lib().orc_ampdem_create(np.float32(mod_index))
+
+    def demodulate_block(self, y):
+        y = _c64(y)
+        x = np.empty(y.size, dtype=np.float32)
+        lib().orc_ampdem_demodulate_block(self.h, _p(y), y.size, _p(x))
+        return x
+
+
 def mix_f32(chans):
     chans = np.ascontiguousarray(chans, dtype=np.float32)
     M, n = chans.shape
@@ -264,7 +281,7 @@ class Chain(_Obj):
 
     def __init__(self, M, dc_block=True, agc_db=0.0, demod="none", kf=0.3, mix=False):
         self.M = M
-        self.demod = {"none": 0, "fm": 1}[demod]
+        self.demod = {"none": 0, "fm": 1, "am": 2}[demod]
         self.mix = bool(mix) and M > 1
         self.h = lib().orc_chain_create(M, int(dc_block), int(agc_db != 0.0), np.float32(agc_db),
                                         self.demod, np.float32(kf), int(self.mix))
@@ -273,7 +290,7 @@ class Chain(_Obj):
         x = _c64(x)
         assert x.size % self.M == 0
         nf = x.size // self.M
-        dt = np.float32 if self.demod == 1 else np.complex64
+        dt = np.float32 if self.demod in (1, 2) else np.complex64
         shape = (nf,) if self.mix else (self.M, nf)
         out = np.empty(shape, dtype=dt)
         lib().orc_chain_process(self.h, _p(x), x.size, _p(out))
