@@ -7,6 +7,6 @@ symbol table can be checked), but creating any object without one raises CsdrErr
 from ._lib import CsdrError, lib, lib_path, build_library, DEMOD_NONE, DEMOD_FM, DEMOD_AM  # noqa: F401
 from .pipes import (  # noqa: F401
     Pipe, compose, Chain, ChainConfig, dcBlocker, mixDown, mixUp, automaticGainControl,
-    fmDemodulator, amDemodulator, firpfbchChannelizer,
+    fmDemodulator, amDemodulator, resampler, firpfbchChannelizer,
 )
 from .trans import compact, takeNArr, mix, mux, distribute_, addPipe  # noqa: F401

@@ -52,6 +52,12 @@ SIGNATURES = {
     "csdr_freqdem_create": (_i32, [_f32, _u32, _u32, _pp]),
     "csdr_freqdem_process": (_i32, [_vp, _vp, _u32, _vp]),
     "csdr_freqdem_destroy": (_i32, [_vp]),
+    "csdr_resamp_create": (_i32, [_f32, _f32, _u32, _pp]),
+    "csdr_resamp_get_rate": (_f32, [_vp]),
+    "csdr_resamp_max_out": (_u32, [_vp, _u32]),
+    "csdr_resamp_process": (_i32, [_vp, _vp, _u32, _vp, _vp]),
+    "csdr_resamp_process_device": (_i32, [_vp, _vp, _u32, _vp, _vp, _vp]),
+    "csdr_resamp_destroy": (_i32, [_vp]),
     "csdr_ampdem_create": (_i32, [_f32, _u32, _u32, _pp]),
     "csdr_ampdem_process": (_i32, [_vp, _vp, _u32, _vp]),
     "csdr_ampdem_destroy": (_i32, [_vp]),

@@ -10,7 +10,7 @@ with the DSP behind `compact` done by the fused C-ABI chain.  Sinks are the refe
 the sample values and their order are the same).  `--offset` is the reference's mixDown/mixUp in front; the msresamp resampler (`-b`) is not built (f2)."""
 import numpy as np
 
-from .pipes import Chain, ChainConfig, mixDown, mixUp
+from .pipes import Chain, ChainConfig, mixDown, mixUp, resampler
 from .trans import Fold, compact, takeNArr
 
 
@@ -66,26 +66,35 @@ class _FusedFold(Fold):
 
 
 def sdr_process(filename, channels=1, demod="none", kf=0.3, agc=0.0, mix=False, numsamples=1024,
-                outname="output", chunksize=1024, m=4, offset=0.0, samplerate=2.56e6):
-    """soapy-sdr --filename F -c channels --demod ... -a agc [-m] -n numsamples -o outname
-    (bandwidth 0, offset 0).  Returns the list of files written."""
+                outname="output", chunksize=1024, m=4, offset=0.0, samplerate=2.56e6, bandwidth=0.0):
+    """soapy-sdr --filename F -s samplerate -b bandwidth --offset f -c channels --demod ... -a agc [-m]
+    -n numsamples -o outname.  Returns the list of files written."""
     nch = channels
     mixed = bool(mix) and nch > 1
     ext = ".cf32" if demod == "none" else ".f32"
     names = [outname + ext] if (mixed or nch == 1) else [f"{outname}_ch{k}{ext}" for k in range(1, nch + 1)]
     chain = Chain(ChainConfig(channels=nch, demod=demod, kf=kf, agc=agc, mix=mixed, max_frames=m * 1024))
     fold = compact(m * nch * 1024, _FusedFold(chain, [fileSink(n) for n in names], mixed))
-    # --offset: f = 2*pi*offset/fs; mixDown f if f > 0, mixUp (-f) if f < 0 (SoapySDR.hs:200-205),
-    # applied per source chunk BEFORE takeNArr (SoapySDR.hs:206-207)
+    # prep = takeNArr ns . (resampler . offset)   (SoapySDR.hs:206-207): per source chunk, the --offset mixer first
+    # (f = 2*pi*offset/fs; mixDown f if f > 0, mixUp (-f) if f < 0, :200-205), then the resampler
+    # (rate = bandwidth / samplerate, 60 dB, identity when -b 0, :190-194)
     f = np.float32(2 * np.pi * offset / samplerate)
-    front = None if f == 0 else (mixDown(float(f), max_samples=chunksize) if f > 0 else mixUp(float(-f), max_samples=chunksize))
-    r = front._start() if front else None
+    stages = []
+    if f != 0:
+        stages.append(mixDown(float(f), max_samples=chunksize) if f > 0 else mixUp(float(-f), max_samples=chunksize))
+    if bandwidth != 0:
+        stages.append(resampler(float(np.float32(bandwidth / samplerate)), 60.0, max_samples=chunksize))
+    states = [p._start() for p in stages]
     src = readFromFile(chunksize, filename)
-    if front:
-        src = (front._process(r, a) for a in src)
-    for a in takeNArr(numsamples, src):
+
+    def front(gen):
+        for a in gen:
+            for p, st in zip(stages, states):
+                a = p._process(st, a)
+            yield a
+    for a in takeNArr(numsamples, front(src) if stages else src):
         fold.step(a)
     fold.done()
-    if front:
-        front._done(r)
+    for p, st in zip(stages, states):
+        p._done(st)
     return names

@@ -80,6 +80,14 @@ struct csdr_nco {
 struct csdr_agc {
     int device; uint32_t C, max_n; AgcParams p; AgcState *d_st = nullptr; float2 *d_z = nullptr;
 };
+struct csdr_resamp {
+    int device; uint32_t max_in; ResampDesign d;
+    // stage s (s < K: half-band decimators; s == K: the arbitrary stage): history-prefixed input buffer
+    std::vector<float2 *> d_buf; std::vector<float *> d_h; std::vector<uint32_t> H; std::vector<uint64_t> n_seen;
+    float *d_pfb = nullptr; float2 *d_out = nullptr;
+    uint64_t t_next = 0;         // Q32.32 absolute time (arbitrary-stage input samples) of the next output
+    bool passthrough = false;    // rate 0: the reference's "no resampler" (Liquid.chs:100-103)
+};
 struct csdr_ampdem {
     int device; uint32_t C, max_n; float *d_q[2] = {nullptr, nullptr}; int cur = 0;
     float2 *d_z = nullptr; float *d_f = nullptr;
@@ -302,6 +310,132 @@ int csdr_freqdem_destroy(csdr_freqdem *h)
 {
     if (!h) return CSDR_OK;
     (void)hipFree(h->d_rp[0]); (void)hipFree(h->d_rp[1]); (void)hipFree(h->d_z); (void)hipFree(h->d_f);
+    delete h;
+    return CSDR_OK;
+}
+
+// ---------------------------------------------------------------------------
+// resampler r as (Liquid.chs:56-117)
+// ---------------------------------------------------------------------------
+int csdr_resamp_create(float rate, float As, uint32_t max_in, csdr_resamp **out)
+{
+    if (!out || rate < 0.f || !(rate == rate)) { set_error("resamp: bad arguments"); return CSDR_ERR_INVALID; }
+    if (rate > 2.0f) { set_error("resamp: rate %g > 2 (interpolating half-band stages are not built)", rate); return CSDR_ERR_INVALID; }
+    int dev; int r = check_device(-1, &dev); if (r) return r;
+    csdr_resamp *h = new (std::nothrow) csdr_resamp();
+    if (!h) return CSDR_ERR_NOMEM;
+    h->device = dev; h->max_in = max_in ? max_in : 4096;
+    if (rate == 0.f) { h->passthrough = true; *out = h; return CSDR_OK; }
+    h->d = design_msresamp(rate, As);
+    const uint32_t K = h->d.K, P = 2 * h->d.m_arb;
+    h->d_buf.assign(K + 1, nullptr); h->d_h.assign(K, nullptr); h->H.assign(K + 1, 0); h->n_seen.assign(K + 1, 0);
+    auto fail = [&](int rc) { csdr_resamp_destroy(h); return rc; };
+    uint32_t cap = h->max_in;
+    for (uint32_t s = 0; s <= K; s++) {
+        h->H[s] = s < K ? 4 * h->d.m_hb[s] + 1 : P + 1;
+        if ((r = dev_alloc(&h->d_buf[s], (size_t)h->H[s] + cap + 2))) return fail(r);
+        CSDR_HIP(hipMemset(h->d_buf[s], 0, sizeof(float2) * ((size_t)h->H[s] + cap + 2)));
+        if (s < K) {
+            if (hipMalloc(&h->d_h[s], sizeof(float) * h->d.h_hb[s].size()) != hipSuccess) { set_error("resamp: allocation failed"); return fail(CSDR_ERR_HIP); }
+            CSDR_HIP(hipMemcpy(h->d_h[s], h->d.h_hb[s].data(), sizeof(float) * h->d.h_hb[s].size(), hipMemcpyHostToDevice));
+            cap = cap / 2 + 1;
+        }
+    }
+    if (hipMalloc(&h->d_pfb, sizeof(float) * h->d.pfb.size()) != hipSuccess) { set_error("resamp: allocation failed"); return fail(CSDR_ERR_HIP); }
+    CSDR_HIP(hipMemcpy(h->d_pfb, h->d.pfb.data(), sizeof(float) * h->d.pfb.size(), hipMemcpyHostToDevice));
+    if ((r = dev_alloc(&h->d_out, (size_t)csdr_resamp_max_out(h, h->max_in)))) return fail(r);
+    if (!getenv("CSDR_QUIET")) {
+        // what msresamp_crcf_print shows in the reference ("Using resampler:", Liquid.chs:105-106)
+        printf("csdr resampler: rate=%g = 2^-%u x %g, half-band taps:", rate, K, h->d.rho);
+        for (uint32_t s = 0; s < K; s++) printf(" %u", 4 * h->d.m_hb[s] + 1);
+        printf(", arbitrary stage: npfb=%u m=%u fc=%g As=%g\n", h->d.npfb, h->d.m_arb, h->d.fc, As);
+        fflush(stdout);
+    }
+    *out = h;
+    return CSDR_OK;
+}
+float csdr_resamp_get_rate(const csdr_resamp *h) { return h ? (h->passthrough ? 1.0f : h->d.rate) : 0.f; }
+uint32_t csdr_resamp_max_out(const csdr_resamp *h, uint32_t n_in)
+{
+    if (!h) return 0;
+    if (h->passthrough) return n_in;
+    return 2u * (uint32_t)std::ceil((double)h->d.rate * n_in) + 2u;      // the reference's 2*ceil(r*nx) (Liquid.chs:81)
+}
+int csdr_resamp_process_device(csdr_resamp *h, const void *d_x, uint32_t n_in, void *d_y, uint32_t *n_out, void *stream)
+{
+    if (!h || !n_out) { set_error("resamp: null argument"); return CSDR_ERR_INVALID; }
+    *n_out = 0;
+    if (!n_in) return CSDR_OK;
+    if (!d_x || !d_y) { set_error("resamp: null buffer"); return CSDR_ERR_INVALID; }
+    if (n_in > h->max_in) { set_error("resamp: %u samples > max %u", n_in, h->max_in); return CSDR_ERR_SIZE; }
+    DevGuard guard(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (h->passthrough) {
+        CSDR_HIP(hipMemcpyAsync(d_y, d_x, sizeof(float2) * (size_t)n_in, hipMemcpyDeviceToDevice, s));
+        *n_out = n_in;
+        return CSDR_OK;
+    }
+    const uint32_t K = h->d.K, P = 2 * h->d.m_arb;
+    int r;
+    if ((const void *)(h->d_buf[0] + h->H[0]) != d_x)
+        CSDR_HIP(hipMemcpyAsync(h->d_buf[0] + h->H[0], d_x, sizeof(float2) * (size_t)n_in, hipMemcpyDeviceToDevice, s));
+    uint32_t n = n_in;
+    for (uint32_t st = 0; st < K; st++) {
+        // stage input: absolute samples [N0 - H, N0 + n) sit at buffer positions [0, H + n); output j = sum h[i] x[2j+1-i]
+        const uint64_t N0 = h->n_seen[st], N1 = N0 + n;
+        const uint32_t ny = (uint32_t)(N1 / 2 - N0 / 2);
+        const uint32_t base0 = (uint32_t)((2 * (N0 / 2) + 1) - N0 + h->H[st]);
+        float2 *dst = h->d_buf[st + 1] + h->H[st + 1];
+        if ((r = launch_hb_decim(h->d_buf[st], h->d_h[st], dst, ny, base0, h->d.m_hb[st], s))) return r;
+        if ((r = launch_keep_tail(h->d_buf[st], h->H[st], n, s))) return r;
+        h->n_seen[st] = N1;
+        n = ny;
+    }
+    {
+        const uint64_t N0 = h->n_seen[K], N1 = N0 + n;
+        uint32_t ny = 0;
+        if (N1 >= 2) {
+            // outputs while floor(t) + 1 <= N1 - 1, i.e. t < (N1 - 1) * 2^32
+            const uint64_t lim = (N1 - 1) << 32;
+            if (h->t_next < lim) ny = (uint32_t)((lim - h->t_next + h->d.delta - 1) / h->d.delta);
+        }
+        // buffer position of absolute sample a is a - (N0 - H)
+        const uint64_t t_first = h->t_next - (N0 << 32) + ((uint64_t)h->H[K] << 32);
+        if ((r = launch_resamp_arb(h->d_buf[K], h->d_pfb, (float2 *)d_y, ny, t_first, h->d.delta, h->d.npfb, P, s))) return r;
+        if ((r = launch_keep_tail(h->d_buf[K], h->H[K], n, s))) return r;
+        h->t_next += (uint64_t)ny * h->d.delta;
+        h->n_seen[K] = N1;
+        *n_out = ny;
+    }
+    return CSDR_OK;
+}
+int csdr_resamp_process(csdr_resamp *h, const float *x, uint32_t n_in, float *y, uint32_t *n_out)
+{
+    if (!h || !n_out) { set_error("resamp: null argument"); return CSDR_ERR_INVALID; }
+    *n_out = 0;
+    if (!n_in) return CSDR_OK;
+    if (!x || !y) { set_error("resamp: null buffer"); return CSDR_ERR_INVALID; }
+    if (n_in > h->max_in) { set_error("resamp: %u samples > max %u", n_in, h->max_in); return CSDR_ERR_SIZE; }
+    if (h->passthrough) { memcpy(y, x, sizeof(float2) * (size_t)n_in); *n_out = n_in; return CSDR_OK; }
+    DevGuard guard(h->device);
+    // the first stage's buffer doubles as the H2D landing area
+    float2 *stage0 = h->d_buf[0] + h->H[0];
+    CSDR_HIP(hipMemcpy(stage0, x, sizeof(float2) * (size_t)n_in, hipMemcpyHostToDevice));
+    // process_device copies d_x into the same place: skip that by handing it the landing area itself
+    uint32_t no = 0;
+    int r = csdr_resamp_process_device(h, stage0, n_in, h->d_out, &no, nullptr);
+    if (r) return r;
+    CSDR_HIP(hipMemcpy(y, h->d_out, sizeof(float2) * (size_t)no, hipMemcpyDeviceToHost));
+    *n_out = no;
+    return CSDR_OK;
+}
+int csdr_resamp_destroy(csdr_resamp *h)
+{
+    if (!h) return CSDR_OK;
+    for (float2 *p : h->d_buf) if (p) (void)hipFree(p);
+    for (float *p : h->d_h) if (p) (void)hipFree(p);
+    if (h->d_pfb) (void)hipFree(h->d_pfb);
+    if (h->d_out) (void)hipFree(h->d_out);
     delete h;
     return CSDR_OK;
 }

@@ -21,6 +21,14 @@ int  hip_fail(hipError_t e, const char *what, const char *file, int line);
 // Kaiser prototype of firpfbch_crcf_create_kaiser(ANALYZER, M, m, As)
 // (reference call: Liquid.chs:813).  Returns the M*2m taps the bank uses.
 std::vector<float> design_pfb_taps(uint32_t M, uint32_t m, float As);
+// msresamp_crcf(r, As) decomposition and filters (reference call: Liquid.chs:104, rate = bw/fs, As = 60)
+struct ResampDesign {
+    float rate = 0.f; double rho = 0.0; uint32_t K = 0;
+    std::vector<uint32_t> m_hb; std::vector<std::vector<float>> h_hb;   // half-band stage s: 4 m + 1 taps
+    uint32_t npfb = 256, m_arb = 7; float fc = 0.f; std::vector<float> pfb;   // [npfb][2 m_arb]
+    uint64_t delta = 0;          // input samples per output at the arbitrary stage, Q32.32
+};
+ResampDesign design_msresamp(float rate, float As);
 // nco_crcf_set_frequency's float -> uint32 phase-step conversion.
 uint32_t nco_freq_word(float freq);
 // Haskell-Float value of  -0.5*(M-1)/M*2*pi  (Liquid.chs:817).
@@ -95,6 +103,15 @@ int launch_mix_frames(const float2 *Y, void *out, bool fm, uint32_t M, uint32_t 
 // ---- ampmodem DSB peak detector (kernels_am.hip): F[c][t] = 2 (|Z| - q_hat), q_hat a one-pole smoother per channel;
 // q_in / q_out must be different arrays (ping-pong)
 int launch_am(const float2 *Z, float *F, uint32_t C, uint32_t nf, const float *q_in, float *q_out, float alpha, hipStream_t s);
+
+// ---- multi-stage resampler kernels (kernels_resamp.hip) ----
+// y[j] = sum_i h[i] w[base0 + 2 j - i], i <= 4m (half-band decimator over a history-prefixed buffer)
+int launch_hb_decim(const float2 *w, const float *h, float2 *y, uint32_t ny, uint32_t base0, uint32_t m, hipStream_t s);
+// y[k] = (1-mu) F_b(n) + mu F_{b+1}(n) at t = t_first + k delta (Q32.32 over buffer positions)
+int launch_resamp_arb(const float2 *w, const float *pfb, float2 *y, uint32_t ny, uint64_t t_first, uint64_t delta, uint32_t npfb,
+                      uint32_t P, hipStream_t s);
+// w[0..H) <- w[n..n+H)  (keep the last H samples of a history-prefixed buffer; H <= 1024)
+int launch_keep_tail(float2 *w, uint32_t H, uint32_t n, hipStream_t s);
 
 // ---- time-parallel exact AGC [+ freqdem] tail (kernels_agc_tail.hip) ----
 struct AgcTailPlan;

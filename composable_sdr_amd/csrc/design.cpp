@@ -71,6 +71,55 @@ std::vector<float> design_pfb_taps(uint32_t M, uint32_t m, float As)
     return h;
 }
 
+// liquid_firdes_kaiser(N, fc, As, 0): h[i] = sinc(2 fc t) w_kaiser(i), t = i - (N-1)/2 (f64)
+static std::vector<double> firdes_kaiser(uint32_t N, double fc, double As)
+{
+    const double beta = kaiser_beta(As), ib = bessel_i0(beta);
+    const double pi = 3.14159265358979323846;
+    std::vector<double> h(N);
+    for (uint32_t i = 0; i < N; i++) {
+        double t = (double)i - 0.5 * (double)(N - 1);
+        double x = 2.0 * fc * t;
+        double sinc = std::fabs(x) < 0.01
+                          ? std::cos(pi * x / 2) * std::cos(pi * x / 4) * std::cos(pi * x / 8)
+                          : std::sin(pi * x) / (pi * x);
+        double r = 2.0 * t / (double)(N - 1);
+        double a = 1.0 - r * r;
+        h[i] = sinc * bessel_i0(beta * std::sqrt(a > 0 ? a : 0)) / ib;
+    }
+    return h;
+}
+
+// ---- multi-stage resampler (msresamp_crcf's structure; "csdr msresamp v1" parameters) ----
+ResampDesign design_msresamp(float rate, float As)
+{
+    ResampDesign d;
+    d.rate = rate; d.rho = (double)rate; d.K = 0;
+    while (d.rho < 0.5 && d.K < 24) { d.K++; d.rho *= 2.0; }
+    for (uint32_t s = 0; s < d.K; s++) {
+        // half-band stage s sees the final band at fb = 0.45 r 2^s of its input rate
+        double fb = 0.45 * (double)rate * (double)(1u << s), ft = 0.5 - 2.0 * fb;
+        if (ft < 0.01) ft = 0.01;
+        double N = (std::fabs((double)As) - 7.95) / (14.36 * ft);
+        int m = (int)std::ceil((N - 1.0) / 4.0);
+        if (m < 2) m = 2;
+        std::vector<double> hd = firdes_kaiser(4 * m + 1, 0.25, As);
+        std::vector<float> h(4 * m + 1);
+        for (size_t i = 0; i < h.size(); i++) h[i] = (float)(0.5 * hd[i]);
+        d.m_hb.push_back((uint32_t)m); d.h_hb.push_back(h);
+    }
+    d.npfb = 256; d.m_arb = 7;
+    double fc = 0.515 * d.rho; if (fc > 0.49) fc = 0.49;
+    d.fc = (float)fc;
+    const uint32_t P = 2 * d.m_arb;
+    std::vector<double> hd = firdes_kaiser(P * d.npfb + 1, fc / (double)d.npfb, As);
+    d.pfb.resize((size_t)d.npfb * P);
+    for (uint32_t b = 0; b < d.npfb; b++)
+        for (uint32_t j = 0; j < P; j++) d.pfb[(size_t)b * P + j] = (float)(2.0 * fc * hd[b + (size_t)j * d.npfb]);
+    d.delta = (uint64_t)std::llround(4294967296.0 / d.rho);
+    return d;
+}
+
 uint32_t nco_freq_word(float freq)
 {
     float p = (float)((double)freq * 0.159154943091895);   // freq / 2pi, rounded to f32

@@ -125,6 +125,47 @@ template <class T> struct FileSink : Fold<Array<T>> {
     void done() override { if (f) { std::fclose(f); f = nullptr; } }
 };
 
+// ---- front-end Pipes: resampler r as (Liquid.chs:115-117), mixDown / mixUp f (Liquid.chs:805-809) ----
+inline Pipe<Array<cf32>, Array<cf32>> resampler(float r, float as_db, uint32_t max_in)
+{
+    Pipe<Array<cf32>, Array<cf32>> p;
+    p.start = [=]() {
+        csdr_resamp *h = nullptr;
+        check(csdr_resamp_create(r, as_db, max_in, &h));
+        return std::shared_ptr<void>(h, [](void *q) { csdr_resamp_destroy(static_cast<csdr_resamp *>(q)); });
+    };
+    p.process = [](void *rr, const Array<cf32> &a) {
+        auto *h = static_cast<csdr_resamp *>(rr);
+        Array<cf32> y(csdr_resamp_max_out(h, (uint32_t)a.size()));          // 2*ceil(r*nx), Liquid.chs:81
+        uint32_t n = 0;
+        check(csdr_resamp_process(h, reinterpret_cast<const float *>(a.data()), (uint32_t)a.size(), reinterpret_cast<float *>(y.data()), &n));
+        y.resize(n);                                                         // shrinkToFit, Liquid.chs:98
+        return y;
+    };
+    p.done = [](void *) {};
+    return p;
+}
+inline Pipe<Array<cf32>, Array<cf32>> ncoMixer(float f, bool up, uint32_t max_in)
+{
+    Pipe<Array<cf32>, Array<cf32>> p;
+    p.start = [=]() {
+        csdr_nco *h = nullptr;
+        check(csdr_nco_create(f, max_in, &h));
+        return std::shared_ptr<void>(h, [](void *q) { csdr_nco_destroy(static_cast<csdr_nco *>(q)); });
+    };
+    p.process = [up](void *rr, const Array<cf32> &a) {
+        auto *h = static_cast<csdr_nco *>(rr);
+        Array<cf32> y(a.size());
+        if (!a.empty())
+            check((up ? csdr_nco_mix_up : csdr_nco_mix_down)(h, reinterpret_cast<const float *>(a.data()), (uint32_t)a.size(), reinterpret_cast<float *>(y.data())));
+        return y;
+    };
+    p.done = [](void *) {};
+    return p;
+}
+inline Pipe<Array<cf32>, Array<cf32>> mixDown(float f, uint32_t max_in) { return ncoMixer(f, false, max_in); }
+inline Pipe<Array<cf32>, Array<cf32>> mixUp(float f, uint32_t max_in) { return ncoMixer(f, true, max_in); }
+
 // ---- the fused chain as a Pipe (replaces mix . mux (replicate nch demod) . firpfbchChannelizer nc) ----
 struct ChainOpts {
     uint32_t channels = 1; bool dc_block = true; float agc = 0.f; bool fm = false; bool am = false; float kf = 0.3f; bool mix = false;

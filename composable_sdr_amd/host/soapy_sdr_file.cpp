@@ -1,6 +1,7 @@
 // soapy-sdr's file-input mode (apps/SoapySDR.hs:181-283) on the C-ABI chain:
 //   soapy_sdr_file --filename in.cf32 -n N -c M [--demod DeNo|DeNBFM kf|DeAM] [-a dB] [-m] [-o output] [--chunksize 1024]
-// readFromFile -> takeNArr -> compact(4*M*1024) -> fused chain (dcBlocker + PFB + demod [+mix]) -> fileSinks
+//                  [-s samplerate] [-b bandwidth] [--offset Hz]
+// readFromFile -> [mixDown/mixUp (--offset)] -> [resampler (-b)] -> takeNArr -> compact(4*M*1024) -> fused chain (dcBlocker + PFB + demod [+mix]) -> fileSinks
 // named <out>.cf32 / <out>_ch<k>.cf32 (DeNo, SoapySDR.hs:240) or raw .f32 for FM (the reference wraps
 // the same samples in WAV/AU through libsndfile).
 #include <cstdlib>
@@ -10,6 +11,9 @@
 #include "csdr_host.hpp"
 
 using namespace csdrhost;
+
+struct FrontOpts { double samplerate = 2.56e6, bandwidth = 0.0, offset = 0.0; };
+static FrontOpts g_front;
 
 template <class Out> static int run(const std::string &in, const ChainOpts &o, size_t n, const std::string &out, size_t chunk, const char *ext)
 {
@@ -22,6 +26,14 @@ template <class Out> static int run(const std::string &in, const ChainOpts &o, s
                                                                                     std::make_shared<Distribute<Out>>(sinks))));
     FILE *f = std::fopen(in.c_str(), "rb");
     if (!f) { std::cerr << "Unable to open source: " << in << "\n"; return 1; }
+    // prep = takeNArr ns . (resampler . offset)  (SoapySDR.hs:190-207)
+    std::vector<Pipe<Array<cf32>, Array<cf32>>> front;
+    const float fo = (float)(2.0 * 3.14159265358979323846 * g_front.offset / g_front.samplerate);
+    if (fo > 0) front.push_back(mixDown(fo, (uint32_t)chunk));
+    else if (fo < 0) front.push_back(mixUp(-fo, (uint32_t)chunk));
+    if (g_front.bandwidth != 0.0) front.push_back(resampler((float)(g_front.bandwidth / g_front.samplerate), 60.0f, (uint32_t)chunk));
+    std::vector<std::shared_ptr<void>> fstate;
+    for (auto &p : front) fstate.push_back(p.start());
     TakeN take(n);
     Array<cf32> a(chunk);
     while (true) {
@@ -29,11 +41,14 @@ template <class Out> static int run(const std::string &in, const ChainOpts &o, s
         const size_t got = std::fread(a.data(), sizeof(cf32), chunk, f);
         if (!got) break;
         a.resize(got);
-        if (!take.feed(a)) break;
-        fold->step(a);
+        Array<cf32> b = a;
+        for (size_t i = 0; i < front.size(); i++) b = front[i].process(fstate[i].get(), b);
+        if (!take.feed(b)) break;
+        fold->step(b);
     }
     std::fclose(f);
     fold->done();
+    for (size_t i = 0; i < front.size(); i++) front[i].done(fstate[i].get());
     return 0;
 }
 
@@ -52,6 +67,9 @@ int main(int argc, char **argv)
         else if (a == "-m" || a == "--mix") o.mix = true;
         else if (a == "-o" || a == "--output") out = next();
         else if (a == "--chunksize") chunk = std::strtoull(next(), nullptr, 10);
+        else if (a == "-s" || a == "--samplerate") g_front.samplerate = std::atof(next());
+        else if (a == "-b" || a == "--bandwidth") g_front.bandwidth = std::atof(next());
+        else if (a == "--offset") g_front.offset = std::atof(next());
         else if (a == "--demod") { demod = next(); if (demod == "DeNBFM") { o.fm = true; o.kf = (float)std::atof(next()); } else if (demod == "DeAM") o.am = true; }
         else { std::cerr << "unknown option " << a << "\n"; return 2; }
     }

@@ -140,6 +140,23 @@ def fmDemodulator(kf, nchan=1, max_samples=4096):
     return Pipe(start, process, lambda r: r.close())
 
 
+def resampler(r, as_db=60.0, max_samples=1 << 20):
+    """resampler r as (Liquid.chs:115-117): Pipe IO (Array CF32) (Array CF32) with a variable-length output
+    (`shrinkToFit` to the count msresamp_crcf_execute reports, :79-98).  r == 0 is the identity."""
+    def start():
+        h = C.c_void_p()
+        check(lib().csdr_resamp_create(r, as_db, max_samples, C.byref(h)))
+        return _Handle(h, lib().csdr_resamp_destroy)
+
+    def process(rh, a):
+        x = _c64(a)
+        y = np.empty(int(lib().csdr_resamp_max_out(rh.h, x.size)), dtype=np.complex64)
+        n = C.c_uint32()
+        check(lib().csdr_resamp_process(rh.h, _ptr(x), x.size, _ptr(y), C.byref(n)))
+        return y[:n.value].copy()
+    return Pipe(start, process, lambda rh: rh.close())
+
+
 def amDemodulator(nchan=1, max_samples=4096, mod_index=0.8):
     """amDemodulator (Liquid.chs:468-469): ampmodem_create 0.8 DSB, carrier present."""
     def start():

@@ -110,6 +110,27 @@ int csdr_freqdem_process(csdr_freqdem *h, const float *x_cf32, uint32_t n, float
 int csdr_freqdem_destroy(csdr_freqdem *h);
 
 /* ------------------------------------------------------------------------ *
+ * resampler r as  (Liquid.chs:56-117): rate r = bandwidth / samplerate, as = 60 dB
+ * (SoapySDR.hs:190-194).
+ *   replaces msresamp_crcf_create / _print / _get_rate / _execute / _destroy
+ *   (imports :58-73).  Variable-length output like msresamp_crcf_execute's
+ *   out-count pointer (:79-98): the caller provides csdr_resamp_max_out(h, n_in)
+ *   samples of room (= the reference's 2*ceil(r*nx), :81).
+ *   Structure = liquid-dsp's msresamp (half-band decimators + one arbitrary-rate
+ *   polyphase stage); liquid's internal filter parameters are not recoverable from
+ *   the reference, so they are fixed by this library: unpinned.
+ *   rate == 0: pass-through (the reference's nullPtr resampler, :100-103);
+ *   rate > 2: CSDR_ERR_INVALID.  CSDR_QUIET in the environment silences the print.
+ * ------------------------------------------------------------------------ */
+typedef struct csdr_resamp csdr_resamp;
+int      csdr_resamp_create(float rate, float as_db, uint32_t max_in, csdr_resamp **out);
+float    csdr_resamp_get_rate(const csdr_resamp *h);
+uint32_t csdr_resamp_max_out(const csdr_resamp *h, uint32_t n_in);
+int      csdr_resamp_process(csdr_resamp *h, const float *x_cf32, uint32_t n_in, float *y_cf32, uint32_t *n_out);
+int      csdr_resamp_process_device(csdr_resamp *h, const void *d_x, uint32_t n_in, void *d_y, uint32_t *n_out, void *stream);
+int      csdr_resamp_destroy(csdr_resamp *h);
+
+/* ------------------------------------------------------------------------ *
  * amDemodulator  (Liquid.chs:439-469), `nchan` independent instances.
  *   replaces ampmodem_create(0.8, LIQUID_AMPMODEM_DSB, 0) / ampmodem_demodulate_block /
  *   ampmodem_destroy (imports :441-450).  x is [nchan][n] CF32, m is [nchan][n] F32.

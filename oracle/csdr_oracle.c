@@ -450,6 +450,175 @@ void orc_freqdem_demodulate_block(orc_freqdem *q, const cf32 *r, unsigned n, flo
 }
 
 /* ------------------------------------------------------------------ */
+/* msresamp_crcf(r, As); reference resampler Liquid.chs:56-117           */
+/* (resampler (bw/fs) 60, SoapySDR.hs:190-194).                          */
+/* STRUCTURE as in liquid-dsp 1.3.2's msresamp.c for decimation: as many  */
+/* half-band decimators as doublings bring the rate into [0.5, 1), then   */
+/* one arbitrary-rate polyphase resampler (resamp_crcf: bank of npfb      */
+/* Kaiser filters, linear interpolation between adjacent phases).        */
+/* PARAMETERS: liquid's internal choices (per-stage half-band lengths,    */
+/* resamp m / fc / npfb, float phase accumulator) are NOT reliably        */
+/* recalled and nothing in the reference prints them -> UNPINNED.  This   */
+/* file fixes them as follows ("csdr msresamp v1"):        */
+/*   K      = number of doublings: while (rho < 0.5) { K++; rho *= 2 }    */
+/*   stage s (input rate fs/2^s): half-band Kaiser h[i] = 0.5 sinc(t/2)   */
+/*            w_kaiser(i), t = i - 2 m_s, 4 m_s + 1 taps, As;              */
+/*            m_s from Kaiser's length estimate for the transition        */
+/*            [fb, 0.5 - fb], fb = 0.45 r 2^s (the final band seen at     */
+/*            this stage's rate): N = (As - 7.95) / (14.36 (0.5 - 2 fb)), */
+/*            m_s = max(2, ceil((N - 1) / 4));  y[j] = sum h[i] x[2j+1-i] */
+/*   arbitrary stage: npfb = 256, m = 7 (14 taps per phase), prototype    */
+/*            liquid_firdes_kaiser(2 m npfb + 1, fc / npfb, As),           */
+/*            fc = min(0.515 rho, 0.49), scaled by 2 fc (unity DC gain);   */
+/*            output k sits at input time t_k = k / rho kept EXACTLY as    */
+/*            Q32.32 (delta = round(2^32 / rho)): n = floor(t), b = top 8  */
+/*            bits of the fraction, mu = next 24 bits / 2^24,             */
+/*            y = (1-mu) F_b(n) + mu F_{b+1}(n), F_b(n) = sum_j            */
+/*            pfb[b][j] z[n-j], F_npfb(n) = F_0(n+1); produced once        */
+/*            z[n+1] exists.  Integer time makes the output chunk-        */
+/*            invariant (liquid's float accumulator is not).              */
+/* Interpolation (r >= 1 up to 2) uses the arbitrary stage alone.         */
+/* ------------------------------------------------------------------ */
+#define ORC_RS_MAXST 24
+typedef struct {
+    float rate, As; unsigned K; double rho;
+    unsigned m_hb[ORC_RS_MAXST]; float *h_hb[ORC_RS_MAXST];
+    cf32 *hist_hb[ORC_RS_MAXST];            /* last 4m+1 inputs of the stage */
+    uint64_t n_hb[ORC_RS_MAXST];            /* inputs received so far        */
+    unsigned npfb, m_arb; float fc; float *pfb;   /* [npfb][2m]               */
+    cf32 *hist_a; uint64_t n_a;             /* last 2m+1 inputs, inputs so far */
+    uint64_t delta, t_next;                 /* Q32.32; t_next absolute time of the next output */
+} orc_msresamp;
+
+static void orc_firdes_kaiser(unsigned N, double fc, double As, double *h)
+{
+    double beta = orc_kaiser_beta(As), ib = orc_besseli0(beta);
+    for (unsigned i = 0; i < N; i++) {
+        double t = (double)i - (double)(N - 1) / 2.0;
+        double r = 2.0 * t / (double)(N - 1), a = 1.0 - r * r;
+        if (a < 0.0) a = 0.0;
+        h[i] = orc_sinc(2.0 * fc * t) * orc_besseli0(beta * sqrt(a)) / ib;
+    }
+}
+
+unsigned orc_msresamp_halfband_m(float rate, float As, unsigned s)
+{
+    double fb = 0.45 * (double)rate * (double)(1u << s);
+    double ft = 0.5 - 2.0 * fb;
+    if (ft < 0.01) ft = 0.01;
+    double N = (fabs((double)As) - 7.95) / (14.36 * ft);
+    int m = (int)ceil((N - 1.0) / 4.0);
+    return (unsigned)(m < 2 ? 2 : m);
+}
+
+orc_msresamp *orc_msresamp_create(float rate, float As)
+{
+    if (!(rate > 0.0f) || rate > 2.0f) return NULL;
+    orc_msresamp *q = (orc_msresamp *)calloc(1, sizeof(*q));
+    q->rate = rate; q->As = As; q->rho = (double)rate;
+    while (q->rho < 0.5 && q->K < ORC_RS_MAXST) { q->K++; q->rho *= 2.0; }
+    for (unsigned s = 0; s < q->K; s++) {
+        unsigned m = orc_msresamp_halfband_m(rate, As, s), N = 4 * m + 1;
+        double *hd = (double *)malloc(sizeof(double) * N);
+        orc_firdes_kaiser(N, 0.25, As, hd);
+        q->m_hb[s] = m; q->h_hb[s] = (float *)malloc(sizeof(float) * N);
+        for (unsigned i = 0; i < N; i++) q->h_hb[s][i] = (float)(0.5 * hd[i]);
+        free(hd);
+        q->hist_hb[s] = (cf32 *)calloc(N, sizeof(cf32));
+    }
+    q->npfb = 256; q->m_arb = 7;
+    double fc = 0.515 * q->rho; if (fc > 0.49) fc = 0.49;
+    q->fc = (float)fc;
+    unsigned P = 2 * q->m_arb, N = P * q->npfb + 1;
+    double *hd = (double *)malloc(sizeof(double) * N);
+    orc_firdes_kaiser(N, fc / (double)q->npfb, As, hd);
+    q->pfb = (float *)malloc(sizeof(float) * q->npfb * P);
+    for (unsigned b = 0; b < q->npfb; b++)
+        for (unsigned j = 0; j < P; j++) q->pfb[b * P + j] = (float)(2.0 * fc * hd[b + j * q->npfb]);
+    free(hd);
+    q->hist_a = (cf32 *)calloc(P + 1, sizeof(cf32));
+    q->delta = (uint64_t)llround(4294967296.0 / q->rho);
+    q->t_next = 0;
+    return q;
+}
+void orc_msresamp_destroy(orc_msresamp *q)
+{
+    if (!q) return;
+    for (unsigned s = 0; s < q->K; s++) { free(q->h_hb[s]); free(q->hist_hb[s]); }
+    free(q->pfb); free(q->hist_a); free(q);
+}
+float orc_msresamp_get_rate(const orc_msresamp *q) { return q->rate; }
+unsigned orc_msresamp_num_halfband(const orc_msresamp *q) { return q->K; }
+unsigned orc_msresamp_halfband_len(const orc_msresamp *q, unsigned s) { return 4 * q->m_hb[s] + 1; }
+void orc_msresamp_get_pfb(const orc_msresamp *q, float *out) { memcpy(out, q->pfb, sizeof(float) * q->npfb * 2 * q->m_arb); }
+
+/* one stage over a block: hist = the H samples in front of x (oldest first), then shifted */
+static unsigned orc_hb_block(orc_msresamp *q, unsigned s, const cf32 *x, unsigned n, cf32 *y)
+{
+    unsigned m = q->m_hb[s], H = 4 * m + 1;
+    cf32 *w = (cf32 *)malloc(sizeof(cf32) * (H + n));
+    memcpy(w, q->hist_hb[s], sizeof(cf32) * H);
+    memcpy(w + H, x, sizeof(cf32) * n);
+    uint64_t N0 = q->n_hb[s], N1 = N0 + n;
+    unsigned ny = 0;
+    for (uint64_t j = N0 / 2; j < N1 / 2; j++) {
+        /* absolute input index a = 2j+1-i lives at w[a - (N0 - H)] */
+        float re = 0.0f, im = 0.0f;
+        int64_t base = (int64_t)(2 * j + 1) - ((int64_t)N0 - (int64_t)H);
+        for (unsigned i = 0; i < H - 0 && i <= 4 * m; i++) {
+            cf32 v = w[base - (int64_t)i];
+            re += q->h_hb[s][i] * v.re; im += q->h_hb[s][i] * v.im;
+        }
+        y[ny].re = re; y[ny].im = im; ny++;
+    }
+    memcpy(q->hist_hb[s], w + n, sizeof(cf32) * H);
+    q->n_hb[s] = N1;
+    free(w);
+    return ny;
+}
+
+/* x: n input samples; y must hold orc_msresamp_max_out(n) samples; returns the number written */
+unsigned orc_msresamp_max_out(const orc_msresamp *q, unsigned n) { return (unsigned)ceil((double)q->rate * n) + 2; }
+unsigned orc_msresamp_execute(orc_msresamp *q, const cf32 *x, unsigned n, cf32 *y)
+{
+    cf32 *a = (cf32 *)malloc(sizeof(cf32) * (n + 1)), *b = (cf32 *)malloc(sizeof(cf32) * (n + 1));
+    const cf32 *cur = x; unsigned cn = n;
+    for (unsigned s = 0; s < q->K; s++) {
+        cf32 *dst = (cur == a) ? b : a;
+        cn = orc_hb_block(q, s, cur, cn, dst);
+        cur = dst;
+    }
+    unsigned P = 2 * q->m_arb, H = P + 1;
+    cf32 *w = (cf32 *)malloc(sizeof(cf32) * (H + cn));
+    memcpy(w, q->hist_a, sizeof(cf32) * H);
+    memcpy(w + H, cur, sizeof(cf32) * cn);
+    uint64_t N0 = q->n_a, N1 = N0 + cn;
+    unsigned ny = 0;
+    while (N1 >= 2 && (q->t_next >> 32) + 1 <= N1 - 1) {
+        uint64_t nk = q->t_next >> 32; uint32_t frac = (uint32_t)q->t_next;
+        unsigned bidx = frac >> 24; float mu = (float)(frac & 0xffffffu) * (1.0f / 16777216.0f);
+        const float *f0 = q->pfb + bidx * P;
+        const float *f1 = (bidx + 1 < q->npfb) ? q->pfb + (bidx + 1) * P : q->pfb;
+        int64_t base0 = (int64_t)nk - ((int64_t)N0 - (int64_t)H);
+        int64_t base1 = base0 + ((bidx + 1 < q->npfb) ? 0 : 1);
+        float r0 = 0, i0 = 0, r1 = 0, i1 = 0;
+        for (unsigned j = 0; j < P; j++) {
+            cf32 v0 = w[base0 - (int64_t)j], v1 = w[base1 - (int64_t)j];
+            r0 += f0[j] * v0.re; i0 += f0[j] * v0.im;
+            r1 += f1[j] * v1.re; i1 += f1[j] * v1.im;
+        }
+        y[ny].re = (1.0f - mu) * r0 + mu * r1;
+        y[ny].im = (1.0f - mu) * i0 + mu * i1;
+        ny++;
+        q->t_next += q->delta;
+    }
+    memcpy(q->hist_a, w + cn, sizeof(cf32) * H);
+    q->n_a = N1;
+    free(w); free(a); free(b);
+    return ny;
+}
+
+/* ------------------------------------------------------------------ */
 /* ampmodem (ampmodem.c); reference amDemodulator Liquid.chs:439-469:    */
 /* ampmodem_create(0.8, 0 = LIQUID_AMPMODEM_DSB, 0 = carrier present).   */
 /* RECALLED, UNPINNED: liquid-dsp 1.3.2's DSB / non-suppressed-carrier   */

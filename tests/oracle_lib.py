@@ -64,6 +64,14 @@ def lib():
             "orc_freqdem_destroy": (None, [vp]),
             "orc_freqdem_ref": (f32, [vp]),
             "orc_freqdem_demodulate_block": (None, [vp, vp, u32, vp]),
+            "orc_msresamp_create": (vp, [f32, f32]),
+            "orc_msresamp_destroy": (None, [vp]),
+            "orc_msresamp_get_rate": (f32, [vp]),
+            "orc_msresamp_num_halfband": (u32, [vp]),
+            "orc_msresamp_halfband_len": (u32, [vp, u32]),
+            "orc_msresamp_max_out": (u32, [vp, u32]),
+            "orc_msresamp_execute": (u32, [vp, vp, u32, vp]),
+            "orc_msresamp_get_pfb": (None, [vp, vp]),
             "orc_ampdem_create": (vp, [f32]),
             "orc_ampdem_destroy": (None, [vp]),
             "orc_ampdem_demodulate_block": (None, [vp, vp, u32, vp]),
@@ -251,6 +259,29 @@ class FreqDem(_Obj):
         m = np.empty(r.size, dtype=np.float32)
         lib().orc_freqdem_demodulate_block(self.h, _p(r), r.size, _p(m))
         return m
+
+
+class MsResamp(_Obj):
+    """resampler r as (Liquid.chs:115-117): msresamp_crcf structure, parameters fixed by this repo (unpinned)"""
+    _destroy = "orc_msresamp_destroy"
+
+    def __init__(self, rate, As=60.0):
+        self.h = lib().orc_msresamp_create(np.float32(rate), np.float32(As))
+        if not self.h:
+            raise ValueError("rate out of range")
+
+    @property
+    def num_halfband(self):
+        return int(lib().orc_msresamp_num_halfband(self.h))
+
+    def halfband_len(self, s):
+        return int(lib().orc_msresamp_halfband_len(self.h, s))
+
+    def execute(self, x):
+        x = _c64(x)
+        y = np.empty(int(lib().orc_msresamp_max_out(self.h, x.size)), dtype=np.complex64)
+        n = int(lib().orc_msresamp_execute(self.h, _p(x), x.size, _p(y)))
+        return y[:n].copy()
 
 
 class AmpDem(_Obj):

@@ -142,3 +142,33 @@ def test_ampdem_peak_detector_recovers_the_envelope():
     ref = 2 * 0.5 * np.sin(2 * np.pi * t[3000:] / 40.0)
     # the 0.01-pole smoother leaks a little of a period-40 tone: gain within 3 %, phase within a degree or two
     assert np.corrcoef(tail, ref)[0, 1] > 0.995 and abs(tail.std() / ref.std() - 1) < 0.05
+
+
+def test_msresamp_restatement_properties():
+    """resampler r 60 (Liquid.chs:56-117): liquid's msresamp structure with this repo's parameters (unpinned).
+    Pins what the spec promises: the rate decomposition, output count, unity passband gain, stop-band rejection
+    past the transition, and exact chunk invariance (integer output timing)."""
+    import oracle_lib as O
+    r = np.float32(200e3 / 2.56e6)                       # BASELINE configs[0]: 0.078125 = 2^-3 * 0.625
+    q = O.MsResamp(r)
+    assert q.num_halfband == 3 and [q.halfband_len(s) for s in range(3)] == [9, 13, 17]
+    assert O.MsResamp(0.625).num_halfband == 0 and O.MsResamp(0.3).num_halfband == 1 and O.MsResamp(1.7).num_halfband == 0
+    n = 200000
+    t = np.arange(n)
+    gains = {}
+    for f_out in (0.05, 0.3, 1.5, 4.0):                  # cycles per OUTPUT sample
+        y = O.MsResamp(r).execute(np.exp(2j * np.pi * f_out * r * t).astype(np.complex64))
+        assert abs(y.size - r * n) <= 1
+        gains[f_out] = 20 * np.log10(np.abs(y[1000:]).mean() + 1e-12)
+    assert abs(gains[0.05]) < 0.05 and abs(gains[0.3]) < 0.05
+    assert gains[1.5] < -60 and gains[4.0] < -60
+    # a tone keeps its frequency: phase advance per output sample = 2 pi f_out
+    y = O.MsResamp(r).execute(np.exp(2j * np.pi * 0.2 * r * t).astype(np.complex64))[2000:]
+    adv = np.angle(y[1:] * np.conj(y[:-1]))
+    assert np.abs(adv - 2 * np.pi * 0.2).max() < 1e-3
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    whole = O.MsResamp(r).execute(x)
+    b = O.MsResamp(r)
+    parts = np.concatenate([b.execute(x[:1]), b.execute(x[1:1000]), b.execute(x[1000:123457]), b.execute(x[123457:])])
+    assert np.array_equal(whole, parts)
