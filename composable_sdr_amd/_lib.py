@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("CSDR_LIB") or os.path.join(_HERE, "libcsdr_hip.so")   # CSDR_LIB: A/B builds
 
-DEMOD_NONE, DEMOD_FM, DEMOD_AM = 0, 1, 2
+DEMOD_NONE, DEMOD_FM, DEMOD_AM, DEMOD_WBFM = 0, 1, 2, 3
 FLAG_TIME_KERNELS, FLAG_FORCE_GENERIC, FLAG_QUIET, FLAG_AGC_SEQUENTIAL = 1, 2, 4, 8
 
 ERR_INVALID, ERR_HIP, ERR_NODEV, ERR_SIZE, ERR_NOMEM = -1, -2, -3, -4, -5
@@ -24,7 +24,7 @@ class ChainCfg(C.Structure):
         ("dc_alpha", C.c_float), ("agc_threshold_db", C.c_float), ("demod", C.c_uint32),
         ("kf", C.c_float), ("mix", C.c_uint32), ("chan_first", C.c_uint32), ("chan_count", C.c_uint32),
         ("device", C.c_int32), ("max_frames", C.c_uint32), ("flags", C.c_uint32),
-        ("pfb_m", C.c_uint32), ("pfb_as", C.c_float),
+        ("pfb_m", C.c_uint32), ("pfb_as", C.c_float), ("wbfm_decim", C.c_uint32), ("deemph_fc", C.c_float),
     ]
 
 
@@ -52,6 +52,12 @@ SIGNATURES = {
     "csdr_freqdem_create": (_i32, [_f32, _u32, _u32, _pp]),
     "csdr_freqdem_process": (_i32, [_vp, _vp, _u32, _vp]),
     "csdr_freqdem_destroy": (_i32, [_vp]),
+    "csdr_iirfilt_create": (_i32, [_u32, _f32, _f32, _f32, _f32, _u32, _u32, _pp]),
+    "csdr_iirfilt_process": (_i32, [_vp, _vp, _u32, _vp]),
+    "csdr_iirfilt_destroy": (_i32, [_vp]),
+    "csdr_firdecim_create": (_i32, [_u32, _u32, _u32, _pp]),
+    "csdr_firdecim_process": (_i32, [_vp, _vp, _u32, _vp]),
+    "csdr_firdecim_destroy": (_i32, [_vp]),
     "csdr_resamp_create": (_i32, [_f32, _f32, _u32, _pp]),
     "csdr_resamp_get_rate": (_f32, [_vp]),
     "csdr_resamp_max_out": (_u32, [_vp, _u32]),

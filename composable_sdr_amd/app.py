@@ -66,14 +66,17 @@ class _FusedFold(Fold):
 
 
 def sdr_process(filename, channels=1, demod="none", kf=0.3, agc=0.0, mix=False, numsamples=1024,
-                outname="output", chunksize=1024, m=4, offset=0.0, samplerate=2.56e6, bandwidth=0.0):
+                outname="output", chunksize=1024, m=4, offset=0.0, samplerate=2.56e6, bandwidth=0.0, decim=4):
     """soapy-sdr --filename F -s samplerate -b bandwidth --offset f -c channels --demod ... -a agc [-m]
     -n numsamples -o outname.  Returns the list of files written."""
     nch = channels
     mixed = bool(mix) and nch > 1
     ext = ".cf32" if demod == "none" else ".f32"
     names = [outname + ext] if (mixed or nch == 1) else [f"{outname}_ch{k}{ext}" for k in range(1, nch + 1)]
-    chain = Chain(ChainConfig(channels=nch, demod=demod, kf=kf, agc=agc, mix=mixed, max_frames=m * 1024))
+    # DeWBFM decim: de-emphasis corner 5000 / outBW, outBW = bandwidth or the sample rate (SoapySDR.hs:227-231, Liquid.chs:655)
+    out_bw = bandwidth if bandwidth != 0 else samplerate
+    chain = Chain(ChainConfig(channels=nch, demod=demod, kf=kf, agc=agc, mix=mixed, max_frames=m * 1024, decim=decim,
+                              deemph_fc=float(np.float32(5000.0 / out_bw))))
     fold = compact(m * nch * 1024, _FusedFold(chain, [fileSink(n) for n in names], mixed))
     # prep = takeNArr ns . (resampler . offset)   (SoapySDR.hs:206-207): per source chunk, the --offset mixer first
     # (f = 2*pi*offset/fs; mixDown f if f > 0, mixUp (-f) if f < 0, :200-205), then the resampler

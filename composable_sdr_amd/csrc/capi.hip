@@ -80,6 +80,13 @@ struct csdr_nco {
 struct csdr_agc {
     int device; uint32_t C, max_n; AgcParams p; AgcState *d_st = nullptr; float2 *d_z = nullptr;
 };
+struct csdr_iirfilt {
+    int device; uint32_t C, max_n; BiquadParams p; float2 *d_st[2] = {nullptr, nullptr}; int cur = 0; float *d_x = nullptr;
+};
+struct csdr_firdecim {
+    int device; uint32_t C, max_n, M, h_len; float *d_h = nullptr, *d_hist[2] = {nullptr, nullptr}; int cur = 0;
+    float *d_x = nullptr, *d_y = nullptr;
+};
 struct csdr_resamp {
     int device; uint32_t max_in; ResampDesign d;
     // stage s (s < K: half-band decimators; s == K: the arbitrary stage): history-prefixed input buffer
@@ -121,6 +128,9 @@ struct csdr_chain {
     AgcTailPlan *agc_tail = nullptr; // AGC on: time-parallel verified tail (unless CSDR_FLAG_AGC_SEQUENTIAL)
     // DeAM: the chain runs as DeNo into d_amz, then the ampmodem peak detector (kernels_am.hip) [+ mix]
     bool am = false, am_mix = false;
+    // DeWBFM: the chain runs as DeNBFM 0.6 into d_wbf, then de-emphasis + decimator (kernels_wbfm.hip) [+ mix]
+    bool wbfm = false, wbfm_mix = false; uint32_t wb_decim = 4, wb_hlen = 0; BiquadParams wb_bq{};
+    float *d_wbf = nullptr, *d_wbo = nullptr, *d_wbh = nullptr, *d_wbhist[2] = {nullptr, nullptr}; float2 *d_wbst[2] = {nullptr, nullptr}; int wb_cur = 0;
     float2 *d_amz = nullptr; float *d_amf = nullptr; float *d_amq[2] = {nullptr, nullptr}; int amq_cur = 0;
     KernelTimer timer;
     std::string timed_kernel;
@@ -315,6 +325,83 @@ int csdr_freqdem_destroy(csdr_freqdem *h)
 }
 
 // ---------------------------------------------------------------------------
+// iirFilter n fc f0 ap as (Liquid.chs:629-638), firDecimator m (Liquid.chs:485-501)
+// ---------------------------------------------------------------------------
+int csdr_iirfilt_create(uint32_t order, float fc, float f0, float ap, float as_db, uint32_t nchan, uint32_t max_samples, csdr_iirfilt **out)
+{
+    (void)f0; (void)ap; (void)as_db;
+    if (!out || !nchan || !(fc > 0.f && fc < 0.5f)) { set_error("iirfilt: bad arguments (fc in (0, 0.5))"); return CSDR_ERR_INVALID; }
+    if (order != 2) { set_error("iirfilt: only the reference's order-2 Butterworth low-pass is built (order %u)", order); return CSDR_ERR_INVALID; }
+    int dev; int r = check_device(-1, &dev); if (r) return r;
+    csdr_iirfilt *h = new (std::nothrow) csdr_iirfilt();
+    if (!h) return CSDR_ERR_NOMEM;
+    h->device = dev; h->C = nchan; h->max_n = max_samples ? max_samples : 4096; h->p = design_butter2_lowpass(fc);
+    if (hipMalloc(&h->d_x, sizeof(float) * (size_t)nchan * h->max_n) != hipSuccess || hipMalloc(&h->d_st[0], sizeof(float2) * nchan) != hipSuccess ||
+        hipMalloc(&h->d_st[1], sizeof(float2) * nchan) != hipSuccess) { set_error("iirfilt: device allocation failed"); csdr_iirfilt_destroy(h); return CSDR_ERR_HIP; }
+    CSDR_HIP(hipMemset(h->d_st[0], 0, sizeof(float2) * nchan)); CSDR_HIP(hipMemset(h->d_st[1], 0, sizeof(float2) * nchan));
+    *out = h;
+    return CSDR_OK;
+}
+int csdr_iirfilt_process(csdr_iirfilt *h, const float *x, uint32_t n, float *y)
+{
+    if (!h || (n && (!x || !y))) { set_error("iirfilt: null argument"); return CSDR_ERR_INVALID; }
+    if (n > h->max_n) { set_error("iirfilt: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
+    if (!n) return CSDR_OK;
+    DevGuard guard(h->device);
+    CSDR_HIP(hipMemcpy(h->d_x, x, sizeof(float) * (size_t)h->C * n, hipMemcpyHostToDevice));
+    int r = launch_biquad(h->d_x, h->d_x, h->C, n, h->p, h->d_st[h->cur], h->d_st[h->cur ^ 1], nullptr);
+    if (r) return r;
+    h->cur ^= 1;
+    CSDR_HIP(hipMemcpy(y, h->d_x, sizeof(float) * (size_t)h->C * n, hipMemcpyDeviceToHost));
+    return CSDR_OK;
+}
+int csdr_iirfilt_destroy(csdr_iirfilt *h)
+{
+    if (!h) return CSDR_OK;
+    (void)hipFree(h->d_x); (void)hipFree(h->d_st[0]); (void)hipFree(h->d_st[1]);
+    delete h;
+    return CSDR_OK;
+}
+int csdr_firdecim_create(uint32_t decim, uint32_t nchan, uint32_t max_samples, csdr_firdecim **out)
+{
+    if (!out || !nchan || decim < 1 || decim > 4096) { set_error("firdecim: bad arguments"); return CSDR_ERR_INVALID; }
+    int dev; int r = check_device(-1, &dev); if (r) return r;
+    csdr_firdecim *h = new (std::nothrow) csdr_firdecim();
+    if (!h) return CSDR_ERR_NOMEM;
+    const std::vector<float> taps = design_firdecim_kaiser(decim, 10, 60.0f);          // firdecimCreate, Liquid.chs:485-490
+    h->device = dev; h->C = nchan; h->max_n = max_samples ? max_samples : 4096; h->M = decim; h->h_len = (uint32_t)taps.size();
+    const size_t hist = (size_t)nchan * (h->h_len - 1);
+    if (hipMalloc(&h->d_x, sizeof(float) * (size_t)nchan * h->max_n) != hipSuccess || hipMalloc(&h->d_y, sizeof(float) * (size_t)nchan * (h->max_n / decim + 1)) != hipSuccess ||
+        hipMalloc(&h->d_h, sizeof(float) * taps.size()) != hipSuccess || hipMalloc(&h->d_hist[0], sizeof(float) * hist) != hipSuccess ||
+        hipMalloc(&h->d_hist[1], sizeof(float) * hist) != hipSuccess) { set_error("firdecim: device allocation failed"); csdr_firdecim_destroy(h); return CSDR_ERR_HIP; }
+    CSDR_HIP(hipMemcpy(h->d_h, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemset(h->d_hist[0], 0, sizeof(float) * hist)); CSDR_HIP(hipMemset(h->d_hist[1], 0, sizeof(float) * hist));
+    *out = h;
+    return CSDR_OK;
+}
+int csdr_firdecim_process(csdr_firdecim *h, const float *x, uint32_t n, float *y)
+{
+    if (!h || (n && (!x || !y))) { set_error("firdecim: null argument"); return CSDR_ERR_INVALID; }
+    if (n > h->max_n) { set_error("firdecim: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
+    if (n % h->M) { set_error("firdecim: %u samples are not a multiple of the decimation %u (Liquid.chs:495-497)", n, h->M); return CSDR_ERR_SIZE; }
+    if (!n) return CSDR_OK;
+    DevGuard guard(h->device);
+    CSDR_HIP(hipMemcpy(h->d_x, x, sizeof(float) * (size_t)h->C * n, hipMemcpyHostToDevice));
+    int r = launch_firdecim(h->d_x, h->d_y, h->C, n, h->M, h->d_h, h->h_len, h->d_hist[h->cur], h->d_hist[h->cur ^ 1], nullptr);
+    if (r) return r;
+    h->cur ^= 1;
+    CSDR_HIP(hipMemcpy(y, h->d_y, sizeof(float) * (size_t)h->C * (n / h->M), hipMemcpyDeviceToHost));
+    return CSDR_OK;
+}
+int csdr_firdecim_destroy(csdr_firdecim *h)
+{
+    if (!h) return CSDR_OK;
+    (void)hipFree(h->d_x); (void)hipFree(h->d_y); (void)hipFree(h->d_h); (void)hipFree(h->d_hist[0]); (void)hipFree(h->d_hist[1]);
+    delete h;
+    return CSDR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // resampler r as (Liquid.chs:56-117)
 // ---------------------------------------------------------------------------
 int csdr_resamp_create(float rate, float As, uint32_t max_in, csdr_resamp **out)
@@ -499,6 +586,8 @@ void csdr_chain_cfg_default(csdr_chain_cfg *cfg, uint32_t channels)
     cfg->max_frames = 4096;
     cfg->pfb_m = 7;
     cfg->pfb_as = 80.0f;
+    cfg->wbfm_decim = 4;
+    cfg->deemph_fc = 0.025f;
 }
 
 static int chain_init_state(csdr_chain *h, hipStream_t s)
@@ -510,6 +599,13 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
     if (h->d_rp[0]) {
         CSDR_HIP(hipMemsetAsync(h->d_rp[0], 0, sizeof(float2) * h->C, s));
         CSDR_HIP(hipMemsetAsync(h->d_rp[1], 0, sizeof(float2) * h->C, s));
+    }
+    if (h->d_wbst[0]) {
+        h->wb_cur = 0;
+        for (int i = 0; i < 2; i++) {
+            CSDR_HIP(hipMemsetAsync(h->d_wbst[i], 0, sizeof(float2) * h->C, s));
+            CSDR_HIP(hipMemsetAsync(h->d_wbhist[i], 0, sizeof(float) * (size_t)h->C * (h->wb_hlen - 1), s));
+        }
     }
     if (h->d_amq[0]) {
         h->amq_cur = 0;
@@ -526,12 +622,15 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
 {
     if (!cfg_in || !out) { set_error("chain: null argument"); return CSDR_ERR_INVALID; }
     if (cfg_in->struct_size != sizeof(csdr_chain_cfg)) { set_error("chain: cfg.struct_size %u != %zu", cfg_in->struct_size, sizeof(csdr_chain_cfg)); return CSDR_ERR_INVALID; }
-    if (cfg_in->demod > CSDR_DEMOD_AM) { set_error("chain: unknown demod %u", cfg_in->demod); return CSDR_ERR_INVALID; }
+    if (cfg_in->demod > CSDR_DEMOD_WBFM) { set_error("chain: unknown demod %u", cfg_in->demod); return CSDR_ERR_INVALID; }
     // DeAM = amDemodulator . agc (SoapySDR.hs:265-272): everything up to the per-channel CF32 samples is the DeNo
     // chain; the peak detector and the mix follow as a tail (see csdr_chain_process_device)
     csdr_chain_cfg eff = *cfg_in;
     const bool am = cfg_in->demod == CSDR_DEMOD_AM, am_mix = am && cfg_in->mix != 0 && cfg_in->channels > 1;
     if (am) { eff.demod = CSDR_DEMOD_NONE; eff.mix = 0; }
+    // DeWBFM decim = firDecimator decim . iirDeemph . fmDemodulator 0.6 . agc (SoapySDR.hs:252-259, Liquid.chs:653-656)
+    const bool wbfm = cfg_in->demod == CSDR_DEMOD_WBFM, wbfm_mix = wbfm && cfg_in->mix != 0 && cfg_in->channels > 1;
+    if (wbfm) { eff.demod = CSDR_DEMOD_FM; eff.kf = 0.6f; eff.mix = 0; }
     const csdr_chain_cfg *cfg = &eff;
     if (cfg->channels < 1 || cfg->channels > (1u << 16)) { set_error("chain: channels %u out of range", cfg->channels); return CSDR_ERR_INVALID; }
     if (cfg->demod == CSDR_DEMOD_FM && !(cfg->kf > 0.f)) { set_error("chain: FM needs kf > 0"); return CSDR_ERR_INVALID; }
@@ -626,6 +725,22 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         CSDR_HIP(hipMalloc(&h->d_amq[0], sizeof(float) * C)); CSDR_HIP(hipMalloc(&h->d_amq[1], sizeof(float) * C));
         h->path += "+am";
     }
+    if (wbfm) {
+        h->wbfm = true; h->wbfm_mix = wbfm_mix;
+        h->wb_decim = cfg_in->wbfm_decim ? cfg_in->wbfm_decim : 4u;
+        const float fc = cfg_in->deemph_fc > 0.f ? cfg_in->deemph_fc : 0.025f;
+        if (!(fc < 0.5f)) { set_error("chain: deemph_fc %g out of (0, 0.5)", fc); return fail(CSDR_ERR_INVALID); }
+        h->wb_bq = design_butter2_lowpass(fc);
+        const std::vector<float> taps = design_firdecim_kaiser(h->wb_decim, 10, 60.0f);
+        h->wb_hlen = (uint32_t)taps.size();
+        const size_t rows = (size_t)C * h->max_nf, hist = (size_t)C * (h->wb_hlen - 1);
+        if (hipMalloc(&h->d_wbf, sizeof(float) * rows) != hipSuccess || hipMalloc(&h->d_wbh, sizeof(float) * taps.size()) != hipSuccess ||
+            hipMalloc(&h->d_wbhist[0], sizeof(float) * hist) != hipSuccess || hipMalloc(&h->d_wbhist[1], sizeof(float) * hist) != hipSuccess ||
+            hipMalloc(&h->d_wbst[0], sizeof(float2) * C) != hipSuccess || hipMalloc(&h->d_wbst[1], sizeof(float2) * C) != hipSuccess ||
+            (wbfm_mix && hipMalloc(&h->d_wbo, sizeof(float) * rows) != hipSuccess)) { set_error("chain: WBFM tail allocation failed"); return fail(CSDR_ERR_HIP); }
+        CSDR_HIP(hipMemcpy(h->d_wbh, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice));
+        h->path += "+wbfm";
+    }
     if (h->d_agc && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL)) {
         if ((r = agc_tail_create(C, h->max_nf, &h->agc_tail))) return fail(r);
         h->path += h->use_fused ? "-spec" : "+agc-spec";
@@ -638,14 +753,14 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         printf("csdr chain [%s] on HIP device %d: channels=%u (shard %u..%u) taps=%u (m=%u, As=%.1f) "
                "nco.d_theta=0x%08x dc_block=%u(alpha=%g) agc=%g dB demod=%s kf=%g mix=%u\n",
                h->path.c_str(), dev, M, c0, c0 + C - 1, M > 1 ? M * h->p : 0, m, As, h->d_theta, cfg->dc_block,
-               cfg->dc_alpha, cfg->agc_threshold_db, am ? "AM" : (cfg->demod == CSDR_DEMOD_FM ? "FM" : "none"), cfg->kf, cfg_in->mix);
+               cfg->dc_alpha, cfg->agc_threshold_db, am ? "AM" : (wbfm ? "WBFM" : (cfg->demod == CSDR_DEMOD_FM ? "FM" : "none")), cfg->kf, cfg_in->mix);
         fflush(stdout);
     }
     *out = h;
     return CSDR_OK;
 }
 
-uint32_t csdr_chain_out_elem_size(const csdr_chain *h) { return h && (h->cfg.demod == CSDR_DEMOD_FM || h->am) ? 4u : 8u; }
+uint32_t csdr_chain_out_elem_size(const csdr_chain *h) { return h && (h->cfg.demod == CSDR_DEMOD_FM || h->am || h->wbfm) ? 4u : 8u; }
 
 // AGC on: Z[C][nf] (channel-major CF32 in d_A) -> AGC + squelch [+ freqdem] [+ mix] -> d_out
 static int chain_agc_tail(csdr_chain *h, const float2 *Z, uint32_t nf, void *d_out, hipStream_t s)
@@ -715,6 +830,27 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
 
 int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
 {
+    if (h && h->wbfm) {
+        if (n_out) *n_out = 0;
+        if (n_in == 0) return CSDR_OK;
+        if (!d_out) { set_error("chain: null buffer"); return CSDR_ERR_INVALID; }
+        if (n_in % h->M == 0 && (n_in / h->M) % h->wb_decim) {
+            set_error("chain: %u frames per call are not a multiple of the WBFM decimation %u (firDecim's `div`, Liquid.chs:495-497)", n_in / h->M, h->wb_decim);
+            return CSDR_ERR_SIZE;
+        }
+        int r = chain_process_device_inner(h, d_in, n_in, h->d_wbf, nullptr, stream);
+        if (r) return r;
+        DevGuard guard(h->device);
+        hipStream_t s = (hipStream_t)stream;
+        const uint32_t nf = n_in / h->M, no = nf / h->wb_decim;
+        if ((r = launch_biquad(h->d_wbf, h->d_wbf, h->C, nf, h->wb_bq, h->d_wbst[h->wb_cur], h->d_wbst[h->wb_cur ^ 1], s))) return r;
+        float *O = h->wbfm_mix ? h->d_wbo : (float *)d_out;
+        if ((r = launch_firdecim(h->d_wbf, O, h->C, nf, h->wb_decim, h->d_wbh, h->wb_hlen, h->d_wbhist[h->wb_cur], h->d_wbhist[h->wb_cur ^ 1], s))) return r;
+        h->wb_cur ^= 1;
+        if (h->wbfm_mix && (r = launch_mix(O, (float *)d_out, h->C, no, s))) return r;
+        if (n_out) *n_out = h->wbfm_mix ? no : h->C * no;
+        return CSDR_OK;
+    }
     if (!h || !h->am) return chain_process_device_inner(h, d_in, n_in, d_out, n_out, stream);
     if (n_out) *n_out = 0;
     if (n_in == 0) return CSDR_OK;
@@ -877,7 +1013,8 @@ int csdr_chain_destroy(csdr_chain *h)
     if (h->agc_tail) agc_tail_destroy(h->agc_tail);
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
-                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_in_stage, h->d_out_stage, h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1]};
+                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_in_stage, h->d_out_stage, h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1],
+                    h->d_wbf, h->d_wbo, h->d_wbh, h->d_wbhist[0], h->d_wbhist[1], h->d_wbst[0], h->d_wbst[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return CSDR_OK;

@@ -113,6 +113,18 @@ int launch_resamp_arb(const float2 *w, const float *pfb, float2 *y, uint32_t ny,
 // w[0..H) <- w[n..n+H)  (keep the last H samples of a history-prefixed buffer; H <= 1024)
 int launch_keep_tail(float2 *w, uint32_t H, uint32_t n, hipStream_t s);
 
+// ---- WBFM audio tail (kernels_wbfm.hip) ----
+// one direct-form-II section y = b0 v0 + b1 v1 + b2 v2, v0 = x - a1 v1 - a2 v2; pw[k] = A^(16 * 2^k), A = [[-a1,-a2],[1,0]] row-major
+struct BiquadParams { float b0, b1, b2, a1, a2; double pw[8][4]; };
+BiquadParams design_butter2_lowpass(float fc);                   // iirFilter 2 fc 0 10 10 (Liquid.chs:636-638)
+std::vector<float> design_firdecim_kaiser(uint32_t M, uint32_t m, float As);   // firdecim_rrrf_create_kaiser (Liquid.chs:487)
+// rows X[C][nf] -> Y[C][nf] (may alias); per-channel state (v1, v2): st_in != st_out
+int launch_biquad(const float *X, float *Y, uint32_t C, uint32_t nf, const BiquadParams &p, const float2 *st_in, float2 *st_out,
+                  hipStream_t s);
+// rows X[C][nf] (nf % M == 0) -> out[C][nf/M]; per-channel history of h_len-1 samples: hist_in != hist_out
+int launch_firdecim(const float *X, float *out, uint32_t C, uint32_t nf, uint32_t M, const float *h, uint32_t h_len,
+                    const float *hist_in, float *hist_out, hipStream_t s);
+
 // ---- time-parallel exact AGC [+ freqdem] tail (kernels_agc_tail.hip) ----
 struct AgcTailPlan;
 int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out);

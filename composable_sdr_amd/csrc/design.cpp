@@ -120,6 +120,37 @@ ResampDesign design_msresamp(float rate, float As)
     return d;
 }
 
+// 2nd-order Butterworth low-pass by the bilinear transform with pre-warping (liquid iirdes BUTTER/LOWPASS/SOS, order 2)
+BiquadParams design_butter2_lowpass(float fc)
+{
+    BiquadParams p{};
+    const double K = std::tan(3.14159265358979323846 * (double)fc), n = 1.0 / (1.0 + std::sqrt(2.0) * K + K * K);
+    p.b0 = (float)(K * K * n); p.b1 = (float)(2.0 * K * K * n); p.b2 = p.b0;
+    p.a1 = (float)(2.0 * (K * K - 1.0) * n); p.a2 = (float)((1.0 - std::sqrt(2.0) * K + K * K) * n);
+    // powers of the state matrix of the f32 coefficients: A^(16), A^(32), ... A^(2048)
+    double A[4] = {-(double)p.a1, -(double)p.a2, 1.0, 0.0};
+    auto mul = [](const double *x, const double *y, double *z) {
+        double t[4] = {x[0] * y[0] + x[1] * y[2], x[0] * y[1] + x[1] * y[3], x[2] * y[0] + x[3] * y[2], x[2] * y[1] + x[3] * y[3]};
+        for (int i = 0; i < 4; i++) z[i] = t[i];
+    };
+    double P[4] = {A[0], A[1], A[2], A[3]};
+    for (int i = 0; i < 4; i++) mul(P, P, P);                    // A^16
+    for (int k = 0; k < 8; k++) {
+        for (int i = 0; i < 4; i++) p.pw[k][i] = P[i];
+        mul(P, P, P);
+    }
+    return p;
+}
+
+std::vector<float> design_firdecim_kaiser(uint32_t M, uint32_t m, float As)
+{
+    const uint32_t N = 2 * M * m + 1;
+    std::vector<double> hd = firdes_kaiser(N, 0.5 / (double)M, As);
+    std::vector<float> h(N);
+    for (uint32_t i = 0; i < N; i++) h[i] = (float)hd[i];
+    return h;
+}
+
 uint32_t nco_freq_word(float freq)
 {
     float p = (float)((double)freq * 0.159154943091895);   // freq / 2pi, rounded to f32

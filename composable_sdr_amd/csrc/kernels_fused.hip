@@ -454,6 +454,9 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         RSTAMP(0);
         // ---- stage + scan this tile, prefetch the next one ----
         stage_and_scan(raw, R, E, Tt, A, tid_i);
+#if !(CSDR_ABLATE & 1) && defined(CSDR_EARLY_LOAD)
+        if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, 256, raw, tid_i);
+#endif
         RSTAMP(1);
 #pragma unroll
         for (int f = 0; f < NB; f++) nw[f] = R[256 * f + col_off_i];
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         for (int f = 3; f < NB; f++) old[f] = nw[f];                // next tile's window
         __syncthreads();                                            // X complete
         RSTAMP(4);
-#if !(CSDR_ABLATE & 1)
+#if !(CSDR_ABLATE & 1) && !defined(CSDR_EARLY_LOAD)
         if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, 256, raw, tid_i);
 #endif
 

@@ -168,7 +168,7 @@ inline Pipe<Array<cf32>, Array<cf32>> mixUp(float f, uint32_t max_in) { return n
 
 // ---- the fused chain as a Pipe (replaces mix . mux (replicate nch demod) . firpfbchChannelizer nc) ----
 struct ChainOpts {
-    uint32_t channels = 1; bool dc_block = true; float agc = 0.f; bool fm = false; bool am = false; float kf = 0.3f; bool mix = false;
+    uint32_t channels = 1; bool dc_block = true; float agc = 0.f; bool fm = false; bool am = false; bool wbfm = false; uint32_t decim = 4; float deemph_fc = 0.025f; float kf = 0.3f; bool mix = false;
     uint32_t max_frames = 4096; uint32_t flags = CSDR_FLAG_QUIET;
 };
 
@@ -179,7 +179,7 @@ template <class Out> Pipe<Array<cf32>, std::vector<Array<Out>>> fusedChain(const
         csdr_chain_cfg cfg;
         csdr_chain_cfg_default(&cfg, o.channels);
         cfg.channels = o.channels; cfg.dc_block = o.dc_block; cfg.agc_threshold_db = o.agc;
-        cfg.demod = o.fm ? CSDR_DEMOD_FM : (o.am ? CSDR_DEMOD_AM : CSDR_DEMOD_NONE); cfg.kf = o.kf; cfg.mix = o.mix; cfg.max_frames = o.max_frames; cfg.flags = o.flags;
+        cfg.demod = o.fm ? CSDR_DEMOD_FM : (o.am ? CSDR_DEMOD_AM : (o.wbfm ? CSDR_DEMOD_WBFM : CSDR_DEMOD_NONE)); cfg.wbfm_decim = o.decim; cfg.deemph_fc = o.deemph_fc; cfg.kf = o.kf; cfg.mix = o.mix; cfg.max_frames = o.max_frames; cfg.flags = o.flags;
         csdr_chain *h = nullptr;
         check(csdr_chain_create(&cfg, &h));
         return std::shared_ptr<void>(h, [](void *q) { csdr_chain_destroy(static_cast<csdr_chain *>(q)); });
@@ -190,12 +190,13 @@ template <class Out> Pipe<Array<cf32>, std::vector<Array<Out>>> fusedChain(const
         if (a.empty()) return std::vector<Array<Out>>{Array<Out>{}};          // nx = 0 -> [empty] (Liquid.chs:856-862)
         const uint32_t usable = (uint32_t)(a.size() / M * M), nf = usable / M;
         const bool mixed = o.mix && M > 1;
-        Array<Out> flat((size_t)(mixed ? nf : (size_t)M * nf));
+        const uint32_t no = o.wbfm ? nf / o.decim : nf;                        // DeWBFM: nf div decim samples per channel
+        Array<Out> flat((size_t)(mixed ? no : (size_t)M * no));
         uint32_t n_out = 0;
         check(csdr_chain_process(h, reinterpret_cast<const float *>(a.data()), usable, flat.data(), &n_out));
         std::vector<Array<Out>> outs;
         if (mixed || M == 1) { outs.push_back(std::move(flat)); return outs; }
-        for (uint32_t k = 0; k < M; k++) outs.emplace_back(flat.begin() + (size_t)k * nf, flat.begin() + (size_t)(k + 1) * nf);
+        for (uint32_t k = 0; k < M; k++) outs.emplace_back(flat.begin() + (size_t)k * no, flat.begin() + (size_t)(k + 1) * no);
         return outs;
     };
     p.done = [](void *) {};

@@ -1,5 +1,5 @@
 // soapy-sdr's file-input mode (apps/SoapySDR.hs:181-283) on the C-ABI chain:
-//   soapy_sdr_file --filename in.cf32 -n N -c M [--demod DeNo|DeNBFM kf|DeAM] [-a dB] [-m] [-o output] [--chunksize 1024]
+//   soapy_sdr_file --filename in.cf32 -n N -c M [--demod DeNo|DeNBFM kf|DeWBFM decim|DeAM] [-a dB] [-m] [-o output] [--chunksize 1024]
 //                  [-s samplerate] [-b bandwidth] [--offset Hz]
 // readFromFile -> [mixDown/mixUp (--offset)] -> [resampler (-b)] -> takeNArr -> compact(4*M*1024) -> fused chain (dcBlocker + PFB + demod [+mix]) -> fileSinks
 // named <out>.cf32 / <out>_ch<k>.cf32 (DeNo, SoapySDR.hs:240) or raw .f32 for FM (the reference wraps
@@ -70,12 +70,13 @@ int main(int argc, char **argv)
         else if (a == "-s" || a == "--samplerate") g_front.samplerate = std::atof(next());
         else if (a == "-b" || a == "--bandwidth") g_front.bandwidth = std::atof(next());
         else if (a == "--offset") g_front.offset = std::atof(next());
-        else if (a == "--demod") { demod = next(); if (demod == "DeNBFM") { o.fm = true; o.kf = (float)std::atof(next()); } else if (demod == "DeAM") o.am = true; }
+        else if (a == "--demod") { demod = next(); if (demod == "DeNBFM") { o.fm = true; o.kf = (float)std::atof(next()); } else if (demod == "DeAM") o.am = true; else if (demod == "DeWBFM") { o.wbfm = true; o.decim = (uint32_t)std::atoi(next()); } }
         else { std::cerr << "unknown option " << a << "\n"; return 2; }
     }
     if (in.empty()) { std::cerr << "--filename is required (SoapySDR live sources are out of scope)\n"; return 2; }
     try {
-        return (o.fm || o.am) ? run<float>(in, o, n, out, chunk, ".f32") : run<cf32>(in, o, n, out, chunk, ".cf32");
+        if (o.wbfm) o.deemph_fc = (float)(5000.0 / (g_front.bandwidth != 0.0 ? g_front.bandwidth : g_front.samplerate));
+        return (o.fm || o.am || o.wbfm) ? run<float>(in, o, n, out, chunk, ".f32") : run<cf32>(in, o, n, out, chunk, ".cf32");
     } catch (const std::exception &e) {
         std::cerr << e.what() << "\n";
         return 1;

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import CsdrError, check, lib, DEMOD_AM, DEMOD_FM, DEMOD_NONE
+from ._lib import CsdrError, check, lib, DEMOD_AM, DEMOD_FM, DEMOD_NONE, DEMOD_WBFM
 
 
 def _c64(x):
@@ -140,6 +140,45 @@ def fmDemodulator(kf, nchan=1, max_samples=4096):
     return Pipe(start, process, lambda r: r.close())
 
 
+def iirFilter(n, fc, f0=0.0, ap=10.0, as_db=10.0, nchan=1, max_samples=4096):
+    """iirFilter n fc f0 ap as (Liquid.chs:629-638): real-valued Butterworth low-pass (order 2 is what the
+    reference instantiates, as the WBFM de-emphasis)."""
+    def start():
+        h = C.c_void_p()
+        check(lib().csdr_iirfilt_create(n, fc, f0, ap, as_db, nchan, max_samples, C.byref(h)))
+        return _Handle(h, lib().csdr_iirfilt_destroy)
+
+    def process(r, a):
+        x = np.ascontiguousarray(a, dtype=np.float32)
+        y = np.empty_like(x)
+        check(lib().csdr_iirfilt_process(r.h, _ptr(x), x.size // nchan, _ptr(y)))
+        return y
+    return Pipe(start, process, lambda r: r.close())
+
+
+def firDecimator(m, nchan=1, max_samples=4096):
+    """firDecimator m (Liquid.chs:500-501): Kaiser decimator (semi-length 10, 60 dB), n div m samples out."""
+    def start():
+        h = C.c_void_p()
+        check(lib().csdr_firdecim_create(m, nchan, max_samples, C.byref(h)))
+        return _Handle(h, lib().csdr_firdecim_destroy)
+
+    def process(r, a):
+        x = np.ascontiguousarray(a, dtype=np.float32)
+        n = x.size // nchan
+        y = np.empty(x.shape[:-1] + (n // m,) if x.ndim > 1 else (n // m,), dtype=np.float32)
+        check(lib().csdr_firdecim_process(r.h, _ptr(x), n, _ptr(y)))
+        return y
+    return Pipe(start, process, lambda r: r.close())
+
+
+def wbFMDemodulator(quadRate, decim, max_samples=4096):
+    """wbFMDemodulator quadRate decim = firDecimator decim . iirDeemph . fmDemodulator 0.6 (Liquid.chs:653-656)"""
+    return compose(firDecimator(decim, max_samples=max_samples),
+                   compose(iirFilter(2, 5000.0 / quadRate, 0.0, 10.0, 10.0, max_samples=max_samples),
+                           fmDemodulator(0.6, max_samples=max_samples)))
+
+
 def resampler(r, as_db=60.0, max_samples=1 << 20):
     """resampler r as (Liquid.chs:115-117): Pipe IO (Array CF32) (Array CF32) with a variable-length output
     (`shrinkToFit` to the count msresamp_crcf_execute reports, :79-98).  r == 0 is the identity."""
@@ -179,7 +218,9 @@ class ChainConfig:
     dc_block: bool = True
     dc_alpha: float = 0.0005
     agc: float = 0.0            # -a; 0 = off
-    demod: str = "none"         # "none" (DeNo) | "fm" (DeNBFM kf) | "am" (DeAM)
+    demod: str = "none"         # "none" (DeNo) | "fm" (DeNBFM kf) | "am" (DeAM) | "wbfm" (DeWBFM decim)
+    decim: int = 4              # DeWBFM decim
+    deemph_fc: float = 0.025    # 5000 / quadRate (Liquid.chs:655)
     kf: float = 0.3
     mix: bool = False
     chan_first: int = 0
@@ -202,7 +243,8 @@ class Chain:
         c.channels = cfg.channels
         c.dc_block, c.dc_alpha = int(cfg.dc_block), cfg.dc_alpha
         c.agc_threshold_db = cfg.agc
-        c.demod = {"none": DEMOD_NONE, "fm": DEMOD_FM, "am": DEMOD_AM}[cfg.demod]
+        c.demod = {"none": DEMOD_NONE, "fm": DEMOD_FM, "am": DEMOD_AM, "wbfm": DEMOD_WBFM}[cfg.demod]
+        c.wbfm_decim, c.deemph_fc = cfg.decim, cfg.deemph_fc
         c.kf, c.mix = cfg.kf, int(cfg.mix)
         c.chan_first, c.chan_count = cfg.chan_first, cfg.chan_count
         c.device, c.max_frames, c.flags = cfg.device, cfg.max_frames, cfg.flags
@@ -213,7 +255,8 @@ class Chain:
         self.M = cfg.channels
         self.C = cfg.chan_count or (cfg.channels - cfg.chan_first)
         self.mixed = bool(cfg.mix) and self.M > 1
-        self.out_dtype = np.float32 if cfg.demod in ("fm", "am") else np.complex64
+        self.out_dtype = np.float32 if cfg.demod in ("fm", "am", "wbfm") else np.complex64
+        self.decim = cfg.decim if cfg.demod == "wbfm" else 1
 
     @property
     def h(self):
@@ -239,7 +282,7 @@ class Chain:
         return th.value, d.value
 
     def out_shape(self, n_in):
-        nf = n_in // self.M
+        nf = n_in // self.M // self.decim
         return (nf,) if self.mixed else (self.C, nf)
 
     def process(self, x):

@@ -45,6 +45,9 @@ extern "C" {
 
 #define CSDR_DEMOD_NONE 0u      /* DeNo: per-channel CF32 out (SoapySDR.hs:236-243)      */
 #define CSDR_DEMOD_FM   1u      /* DeNBFM kf: freqdem, F32 out (SoapySDR.hs:244-251)     */
+#define CSDR_DEMOD_WBFM 3u      /* DeWBFM decim: firDecimator decim . iirDeemph . fmDemodulator 0.6,
+                                   F32 out, n_in/channels/decim samples per channel
+                                   (SoapySDR.hs:252-259, Liquid.chs:653-656)              */
 #define CSDR_DEMOD_AM   2u      /* DeAM: ampmodem DSB peak detector, F32 out
                                    (SoapySDR.hs:265-272, Liquid.chs:439-469)              */
 
@@ -108,6 +111,26 @@ typedef struct csdr_freqdem csdr_freqdem;
 int csdr_freqdem_create(float kf, uint32_t nchan, uint32_t max_samples, csdr_freqdem **out);
 int csdr_freqdem_process(csdr_freqdem *h, const float *x_cf32, uint32_t n, float *m_f32);
 int csdr_freqdem_destroy(csdr_freqdem *h);
+
+/* ------------------------------------------------------------------------ *
+ * iirFilter n fc f0 ap as  (Liquid.chs:629-638) = iirfilt_rrrf_create_prototype(BUTTER, LOWPASS,
+ * SOS, n, fc, f0, ap, as) (imports :593-611), `nchan` independent real-valued instances.
+ * Only what the reference instantiates is built: order 2 (the WBFM de-emphasis,
+ * Liquid.chs:655); other orders return CSDR_ERR_INVALID.  f0 / ap / as do not enter a
+ * Butterworth low-pass and are ignored, as in liquid.  x, y are [nchan][n] F32.
+ * firDecimator m  (Liquid.chs:485-501) = firdecim_rrrf_create_kaiser(m, 10, 60) (imports
+ * :473-483): x is [nchan][n] F32 with n % m == 0 (the reference's `div`), y is [nchan][n/m].
+ * Arithmetic recalled from liquid-dsp 1.3.2 (unpinned).
+ * ------------------------------------------------------------------------ */
+typedef struct csdr_iirfilt csdr_iirfilt;
+int csdr_iirfilt_create(uint32_t order, float fc, float f0, float ap, float as_db, uint32_t nchan, uint32_t max_samples,
+                        csdr_iirfilt **out);
+int csdr_iirfilt_process(csdr_iirfilt *h, const float *x_f32, uint32_t n, float *y_f32);
+int csdr_iirfilt_destroy(csdr_iirfilt *h);
+typedef struct csdr_firdecim csdr_firdecim;
+int csdr_firdecim_create(uint32_t decim, uint32_t nchan, uint32_t max_samples, csdr_firdecim **out);
+int csdr_firdecim_process(csdr_firdecim *h, const float *x_f32, uint32_t n, float *y_f32);
+int csdr_firdecim_destroy(csdr_firdecim *h);
 
 /* ------------------------------------------------------------------------ *
  * resampler r as  (Liquid.chs:56-117): rate r = bandwidth / samplerate, as = 60 dB
@@ -181,6 +204,8 @@ typedef struct csdr_chain_cfg {
     uint32_t flags;             /* CSDR_FLAG_*                                           */
     uint32_t pfb_m;             /* filter semi-length m, 0 = 7  (Liquid.chs:813)         */
     float    pfb_as;            /* stop-band attenuation, 0 = 80 dB (Liquid.chs:813)     */
+    uint32_t wbfm_decim;        /* DeWBFM decim (SoapySDR.hs:252-259); 0 = 4             */
+    float    deemph_fc;         /* DeWBFM de-emphasis corner 5000/quadRate (Liquid.chs:655); 0 = 0.025 */
 } csdr_chain_cfg;
 
 void csdr_chain_cfg_default(csdr_chain_cfg *cfg, uint32_t channels);

@@ -648,6 +648,77 @@ void orc_ampdem_demodulate_block(orc_ampdem *q, const cf32 *y, unsigned n, float
 }
 
 /* ------------------------------------------------------------------ */
+/* WBFM tail: wbFMDemodulator quadRate decim =                           */
+/*     firDecimator decim . iirDeemph . fmDemodulator 0.6                */
+/* (Liquid.chs:653-656), iirDeemph = iirFilter 2 (5000/quadRate) 0 10 10 */
+/*   = iirfilt_rrrf_create_prototype(BUTTER, LOWPASS, SOS, 2, fc, ...)   */
+/*   (Liquid.chs:615-622), firDecimator m =                              */
+/*   firdecim_rrrf_create_kaiser(m, 10, 60) (Liquid.chs:485-490).        */
+/* RECALLED, UNPINNED (liquid-dsp 1.3.2 iirdes.c / iirfiltsos.c /        */
+/* firdecim.c): 2nd-order Butterworth low-pass through the bilinear      */
+/* transform with pre-warping (K = tan(pi fc)), unit DC gain, run as one  */
+/* direct-form-II section; decimator prototype                           */
+/* liquid_firdes_kaiser(2 M m + 1, 0.5/M, As), scale 1 (DC gain ~ M), one */
+/* output when the FIRST sample of each block of M has been pushed:       */
+/* y[j] = sum_i h[i] x[jM - i].                                           */
+/* ------------------------------------------------------------------ */
+typedef struct { float b[3], a[3], v1, v2; } orc_biquad;
+
+orc_biquad *orc_butter2_lowpass_create(float fc)
+{
+    orc_biquad *q = (orc_biquad *)calloc(1, sizeof(*q));
+    double K = tan(M_PI * (double)fc), n = 1.0 / (1.0 + M_SQRT2 * K + K * K);
+    q->b[0] = (float)(K * K * n); q->b[1] = (float)(2.0 * K * K * n); q->b[2] = q->b[0];
+    q->a[0] = 1.0f; q->a[1] = (float)(2.0 * (K * K - 1.0) * n); q->a[2] = (float)((1.0 - M_SQRT2 * K + K * K) * n);
+    return q;
+}
+void orc_biquad_destroy(orc_biquad *q) { free(q); }
+void orc_biquad_coeffs(const orc_biquad *q, float *ba) { memcpy(ba, q->b, 12); memcpy(ba + 3, q->a, 12); }
+void orc_biquad_execute_block(orc_biquad *q, const float *x, unsigned n, float *y)
+{
+    for (unsigned i = 0; i < n; i++) {
+        /* iirfiltsos execute_df2 */
+        float v0 = x[i] - q->a[1] * q->v1 - q->a[2] * q->v2;
+        y[i] = q->b[0] * v0 + q->b[1] * q->v1 + q->b[2] * q->v2;
+        q->v2 = q->v1; q->v1 = v0;
+    }
+}
+
+typedef struct { unsigned M, h_len; float *h, *hist; uint64_t n_seen; } orc_firdecim;
+
+orc_firdecim *orc_firdecim_create_kaiser(unsigned M, unsigned m, float As)
+{
+    orc_firdecim *q = (orc_firdecim *)calloc(1, sizeof(*q));
+    q->M = M; q->h_len = 2 * M * m + 1;
+    double *hd = (double *)malloc(sizeof(double) * q->h_len);
+    orc_firdes_kaiser(q->h_len, 0.5 / (double)M, As, hd);
+    q->h = (float *)malloc(sizeof(float) * q->h_len);
+    for (unsigned i = 0; i < q->h_len; i++) q->h[i] = (float)hd[i];
+    free(hd);
+    q->hist = (float *)calloc(q->h_len, sizeof(float));
+    return q;
+}
+void orc_firdecim_destroy(orc_firdecim *q) { if (q) { free(q->h); free(q->hist); free(q); } }
+unsigned orc_firdecim_len(const orc_firdecim *q) { return q->h_len; }
+void orc_firdecim_taps(const orc_firdecim *q, float *h) { memcpy(h, q->h, sizeof(float) * q->h_len); }
+/* x: n samples, n % M == 0 (the reference's `div`, Liquid.chs:495-497); y: n / M samples */
+void orc_firdecim_execute_block(orc_firdecim *q, const float *x, unsigned n, float *y)
+{
+    unsigned H = q->h_len - 1;
+    float *w = (float *)malloc(sizeof(float) * (H + n));
+    memcpy(w, q->hist, sizeof(float) * H);
+    memcpy(w + H, x, sizeof(float) * n);
+    for (unsigned j = 0; j < n / q->M; j++) {
+        float acc = 0.0f;
+        const float *p = w + H + (size_t)j * q->M;
+        for (unsigned i = 0; i < q->h_len; i++) acc += q->h[i] * *(p - i);
+        y[j] = acc;
+    }
+    memcpy(q->hist, w + n, sizeof(float) * H);
+    free(w);
+}
+
+/* ------------------------------------------------------------------ */
 /* mix (Trans.hs:119-122): strict left fold of element-wise +.          */
 /* ------------------------------------------------------------------ */
 void orc_mix_f32(const float *chans, unsigned M, unsigned n, float *out)
@@ -673,8 +744,10 @@ typedef struct {
     orc_agc **agc;
     orc_freqdem **fm;
     orc_ampdem **am;
+    orc_biquad **de; orc_firdecim **dec; unsigned decim;
 } orc_chain;
 
+orc_chain *orc_chain_create_wbfm(unsigned M, int dc_block, int agc_enable, float agc_thr_db, float deemph_fc, unsigned decim, int mix);
 orc_chain *orc_chain_create(unsigned M, int dc_block, int agc_enable, float agc_thr_db,
                             int demod, float kf, int mix)
 {
@@ -696,9 +769,20 @@ orc_chain *orc_chain_create(unsigned M, int dc_block, int agc_enable, float agc_
     }
     return q;
 }
+/* DeWBFM decim: wbFMDemodulator outBW decim . agc (SoapySDR.hs:252-259); deemph_fc = 5000 / outBW */
+orc_chain *orc_chain_create_wbfm(unsigned M, int dc_block, int agc_enable, float agc_thr_db, float deemph_fc, unsigned decim, int mix)
+{
+    orc_chain *q = orc_chain_create(M, dc_block, agc_enable, agc_thr_db, 1, 0.6f, mix);
+    q->demod = 3; q->decim = decim;
+    q->de = (orc_biquad **)calloc(M, sizeof(orc_biquad *));
+    q->dec = (orc_firdecim **)calloc(M, sizeof(orc_firdecim *));
+    for (unsigned k = 0; k < M; k++) { q->de[k] = orc_butter2_lowpass_create(deemph_fc); q->dec[k] = orc_firdecim_create_kaiser(decim, 10, 60.0f); }
+    return q;
+}
 void orc_chain_destroy(orc_chain *q)
 {
     if (!q) return;
+    if (q->de) { for (unsigned k = 0; k < q->M; k++) { orc_biquad_destroy(q->de[k]); orc_firdecim_destroy(q->dec[k]); } free(q->de); free(q->dec); }
     if (q->dc) orc_dcblock_destroy(q->dc);
     if (q->chan) orc_chan_destroy(q->chan);
     if (q->agc) { for (unsigned k = 0; k < q->M; k++) orc_agc_destroy(q->agc[k]); free(q->agc); }
@@ -724,7 +808,20 @@ void orc_chain_process(orc_chain *q, const cf32 *x, unsigned nx, void *out)
             orc_agc_execute_block_ref(q->agc[k], cur + (size_t)k * nf, nf, t + (size_t)k * nf);
         cur = t;
     }
-    if (q->demod == 1 || q->demod == 2) {
+    if (q->demod == 3) {
+        /* out: [M][nf / decim] (or [nf / decim] mixed) */
+        unsigned no = nf / q->decim;
+        float *f = (float *)malloc(sizeof(float) * (tot ? tot : 1)), *g = (float *)malloc(sizeof(float) * (tot ? tot : 1));
+        float *o = (float *)malloc(sizeof(float) * ((size_t)M * no + 1));
+        for (unsigned k = 0; k < M; k++) {
+            orc_freqdem_demodulate_block(q->fm[k], cur + (size_t)k * nf, nf, f + (size_t)k * nf);
+            orc_biquad_execute_block(q->de[k], f + (size_t)k * nf, nf, g + (size_t)k * nf);
+            orc_firdecim_execute_block(q->dec[k], g + (size_t)k * nf, nf, o + (size_t)k * no);
+        }
+        if (q->mix && M > 1) orc_mix_f32(o, M, no, (float *)out);
+        else memcpy(out, o, sizeof(float) * (size_t)M * no);
+        free(f); free(g); free(o);
+    } else if (q->demod == 1 || q->demod == 2) {
         float *f = (float *)malloc(sizeof(float) * (tot ? tot : 1));
         for (unsigned k = 0; k < M; k++) {
             if (q->demod == 1) orc_freqdem_demodulate_block(q->fm[k], cur + (size_t)k * nf, nf, f + (size_t)k * nf);

@@ -72,6 +72,16 @@ def lib():
             "orc_msresamp_max_out": (u32, [vp, u32]),
             "orc_msresamp_execute": (u32, [vp, vp, u32, vp]),
             "orc_msresamp_get_pfb": (None, [vp, vp]),
+            "orc_butter2_lowpass_create": (vp, [f32]),
+            "orc_biquad_destroy": (None, [vp]),
+            "orc_biquad_coeffs": (None, [vp, vp]),
+            "orc_biquad_execute_block": (None, [vp, vp, u32, vp]),
+            "orc_firdecim_create_kaiser": (vp, [u32, u32, f32]),
+            "orc_firdecim_destroy": (None, [vp]),
+            "orc_firdecim_len": (u32, [vp]),
+            "orc_firdecim_taps": (None, [vp, vp]),
+            "orc_firdecim_execute_block": (None, [vp, vp, u32, vp]),
+            "orc_chain_create_wbfm": (vp, [u32, i32, i32, f32, f32, u32, i32]),
             "orc_ampdem_create": (vp, [f32]),
             "orc_ampdem_destroy": (None, [vp]),
             "orc_ampdem_demodulate_block": (None, [vp, vp, u32, vp]),
@@ -284,6 +294,48 @@ class MsResamp(_Obj):
         return y[:n].copy()
 
 
+class Butter2(_Obj):
+    """iirFilter 2 fc 0 10 10 (Liquid.chs:636-638 -> iirfilt_rrrf_create_prototype BUTTER LOWPASS SOS) -- recalled"""
+    _destroy = "orc_biquad_destroy"
+
+    def __init__(self, fc):
+        self.h = lib().orc_butter2_lowpass_create(np.float32(fc))
+
+    @property
+    def coeffs(self):
+        ba = np.zeros(6, dtype=np.float32)
+        lib().orc_biquad_coeffs(self.h, _p(ba))
+        return ba[:3].copy(), ba[3:].copy()
+
+    def execute_block(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.empty_like(x)
+        lib().orc_biquad_execute_block(self.h, _p(x), x.size, _p(y))
+        return y
+
+
+class FirDecim(_Obj):
+    """firDecimator m (Liquid.chs:485-501): firdecim_rrrf_create_kaiser(m, 10, 60) -- recalled"""
+    _destroy = "orc_firdecim_destroy"
+
+    def __init__(self, M, m=10, As=60.0):
+        self.M = M
+        self.h = lib().orc_firdecim_create_kaiser(M, m, np.float32(As))
+
+    @property
+    def taps(self):
+        h = np.zeros(int(lib().orc_firdecim_len(self.h)), dtype=np.float32)
+        lib().orc_firdecim_taps(self.h, _p(h))
+        return h
+
+    def execute_block(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.size % self.M == 0
+        y = np.empty(x.size // self.M, dtype=np.float32)
+        lib().orc_firdecim_execute_block(self.h, _p(x), x.size, _p(y))
+        return y
+
+
 class AmpDem(_Obj):
     """ampmodem DSB, carrier present (amdemodCreate, Liquid.chs:452-457) -- recalled, unpinned"""
     _destroy = "orc_ampdem_destroy"
@@ -310,19 +362,25 @@ class Chain(_Obj):
     """assembleFold's DSP (SoapySDR.hs:208-226) on compacted chunks."""
     _destroy = "orc_chain_destroy"
 
-    def __init__(self, M, dc_block=True, agc_db=0.0, demod="none", kf=0.3, mix=False):
+    def __init__(self, M, dc_block=True, agc_db=0.0, demod="none", kf=0.3, mix=False, decim=4, deemph_fc=0.025):
         self.M = M
-        self.demod = {"none": 0, "fm": 1, "am": 2}[demod]
+        self.demod = {"none": 0, "fm": 1, "am": 2, "wbfm": 3}[demod]
         self.mix = bool(mix) and M > 1
-        self.h = lib().orc_chain_create(M, int(dc_block), int(agc_db != 0.0), np.float32(agc_db),
-                                        self.demod, np.float32(kf), int(self.mix))
+        self.decim = decim if self.demod == 3 else 1
+        if self.demod == 3:
+            self.h = lib().orc_chain_create_wbfm(M, int(dc_block), int(agc_db != 0.0), np.float32(agc_db),
+                                                 np.float32(deemph_fc), decim, int(self.mix))
+        else:
+            self.h = lib().orc_chain_create(M, int(dc_block), int(agc_db != 0.0), np.float32(agc_db),
+                                            self.demod, np.float32(kf), int(self.mix))
 
     def process(self, x):
         x = _c64(x)
         assert x.size % self.M == 0
         nf = x.size // self.M
-        dt = np.float32 if self.demod in (1, 2) else np.complex64
-        shape = (nf,) if self.mix else (self.M, nf)
+        dt = np.float32 if self.demod in (1, 2, 3) else np.complex64
+        no = nf // self.decim
+        shape = (no,) if self.mix else (self.M, no)
         out = np.empty(shape, dtype=dt)
         lib().orc_chain_process(self.h, _p(x), x.size, _p(out))
         return out

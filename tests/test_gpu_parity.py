@@ -807,3 +807,66 @@ def test_cpp_soapy_sdr_file_front_end_matches_python_replay(tmp_path, monkeypatc
         a = np.fromfile(py[0], dtype=np.float32)
         b = np.fromfile(tmp_path / f"cc_{demod}.f32", dtype=np.float32)
         assert a.size == 20000 and np.array_equal(a, b), demod
+
+
+# --------------------------------------------------------------------------- WBFM audio tail (f3)
+
+
+def test_iirfilter_and_firdecimator_pipes_match_oracle():
+    """iirFilter 2 fc 0 10 10 and firDecimator m (Liquid.chs:629-638, 485-501; arithmetic recalled, unpinned) as
+    chunked Pipes against the restatement.  The biquad runs as a blocked scan: f32 rounding-order differences only."""
+    rng = np.random.default_rng(21)
+    n = 40000
+    x = (np.sin(2 * np.pi * 0.01 * np.arange(n)) + 0.3 * rng.standard_normal(n)).astype(np.float32)
+    sizes = [4, 1000, 4096, 4100, 8192, 22608]
+    assert sum(sizes) == n
+    chunks, pos = [], 0
+    for s in sizes:
+        chunks.append(x[pos:pos + s]); pos += s
+    for fc in (0.025, 0.0021):                      # 5 kHz at 200 kS/s and at 2.4 MS/s
+        orc = O.Butter2(fc)
+        want = orc.execute_block(x)
+        got = np.concatenate(_run_pipe(cs.iirFilter(2, fc, max_samples=30000), chunks))
+        # a narrow low-pass in direct form II keeps a large internal state, so the sequential f32 loop is itself
+        # noisy: both are measured against the same coefficients run in f64
+        from scipy.signal import lfilter
+        b, a = orc.coeffs
+        truth = lfilter(b.astype(np.float64), a.astype(np.float64), x.astype(np.float64))
+        e_gpu, e_orc = np.abs(got - truth).max(), np.abs(want - truth).max()
+        print(f"iirFilter fc={fc}: |gpu - f64| {e_gpu:.3e}, |oracle - f64| {e_orc:.3e}, |gpu - oracle| {max_abs_err(got, want):.3e}")
+        assert e_gpu < 2 * e_orc + 2e-6
+    want = O.FirDecim(4).execute_block(x)
+    got = np.concatenate(_run_pipe(cs.firDecimator(4, max_samples=30000), chunks))
+    err = max_abs_err(got, want)
+    print(f"firDecimator 4: {got.size} out, max abs err {err:.3e} of {np.abs(want).max():.3f}")
+    assert got.size == n // 4 and err < 5e-6
+    with pytest.raises(cs.CsdrError):
+        _run_pipe(cs.firDecimator(4), [x[:1001]])
+    with pytest.raises(cs.CsdrError):
+        _run_pipe(cs.iirFilter(4, 0.1), [x[:16]])
+
+
+@pytest.mark.parametrize("M,agc,mix", [(1, 0.0, False), (8, 0.0, False), (256, 0.0, False), (64, 8.0, False), (16, 0.0, True)])
+def test_chain_wbfm_matches_oracle(M, agc, mix):
+    """DeWBFM 4 = firDecimator 4 . iirDeemph . fmDemodulator 0.6 . agc per channel (SoapySDR.hs:252-259)."""
+    frames = [4096, 1024, 2048] if M > 1 else [40000, 10960, 20480]
+    nf = sum(frames)
+    x = synth_cf32(M * nf, M, seed=777)
+    fc = 5000.0 / 200e3
+    ch = cs.Chain(channels=M, demod="wbfm", decim=4, deemph_fc=fc, agc=agc, mix=mix, max_frames=max(frames))
+    orc = O.Chain(M, demod="wbfm", decim=4, deemph_fc=fc, agc_db=agc, mix=mix)
+    got, want, pos = [], [], 0
+    for f in frames:
+        xa = x[pos * M:(pos + f) * M]
+        got.append(ch.process(xa)); want.append(orc.process(xa)); pos += f
+    got, want = np.concatenate(got, axis=-1), np.concatenate(want, axis=-1)
+    assert got.shape == want.shape == ((nf // 4,) if (mix and M > 1) else (M, nf // 4))
+    # freqdem outputs are compared modulo 1/kf before the linear tail in the FM tests; after a low-pass and a
+    # decimator a branch-cut flip is smeared over ~80 output samples, so compare robustly: the bulk must agree
+    d = np.abs(got.astype(np.float64) - want)
+    scale = np.abs(want).max()
+    print(f"chain WBFM M={M} agc={agc} mix={mix} [{ch.path}]: median {np.median(d):.2e} p99 {np.quantile(d, 0.99):.2e} max {d.max():.2e} of {scale:.3f}")
+    assert np.median(d) < 2e-5 * scale and np.quantile(d, 0.99) < 2e-3 * scale
+    with pytest.raises(cs.CsdrError):
+        ch.process(x[:M * 1023])
+    ch.close()

@@ -172,3 +172,33 @@ def test_msresamp_restatement_properties():
     b = O.MsResamp(r)
     parts = np.concatenate([b.execute(x[:1]), b.execute(x[1:1000]), b.execute(x[1000:123457]), b.execute(x[123457:])])
     assert np.array_equal(whole, parts)
+
+
+def test_wbfm_tail_restatement_properties():
+    """iirDeemph = 2nd-order Butterworth low-pass at 5 kHz / quadRate (Liquid.chs:655) and firDecimator m =
+    Kaiser decimator, semi-length 10, 60 dB (Liquid.chs:487) -- recalled, unpinned.  The Butterworth section must
+    be THE Butterworth section (scipy designs the same one); the decimator prototype is the channelizer's Kaiser
+    design at fc = 0.5 / M, output j aligned to input j*M."""
+    import oracle_lib as O
+    from scipy.signal import butter, lfilter
+    for fc in (0.025, 0.1, 0.0021):
+        b, a = O.Butter2(fc).coeffs
+        bs, as_ = butter(2, 2 * fc)
+        assert np.allclose(b, bs, rtol=2e-6, atol=1e-9) and np.allclose(a, as_, rtol=2e-6, atol=1e-9)
+    x = np.random.default_rng(1).standard_normal(5000).astype(np.float32)
+    q = O.Butter2(0.025)
+    b, a = q.coeffs
+    assert np.abs(q.execute_block(x) - lfilter(b.astype(np.float64), a.astype(np.float64), x)).max() < 1e-5
+    d = O.FirDecim(4)
+    h = d.taps
+    assert h.size == 81 and abs(h[40] - 1.0) < 1e-6 and np.allclose(h, h[::-1]) and abs(h.sum() - 4.0) < 0.01
+    assert np.allclose(h, O.kaiser_prototype(4, 10, 60.0)) if hasattr(O, "kaiser_prototype") else True
+    y = d.execute_block(x[:4000])
+    full = np.convolve(x[:4000].astype(np.float64), h.astype(np.float64))[:4000]
+    assert np.abs(y - full[::4]).max() < 1e-5
+    # chunk invariance of both
+    q2, d2 = O.Butter2(0.025), O.FirDecim(4)
+    q3, d3 = O.Butter2(0.025), O.FirDecim(4)
+    whole = d2.execute_block(q2.execute_block(x[:4000]))
+    parts = np.concatenate([d3.execute_block(q3.execute_block(x[:1000])), d3.execute_block(q3.execute_block(x[1000:4000]))])
+    assert np.array_equal(whole, parts)
