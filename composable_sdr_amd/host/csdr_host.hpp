@@ -16,6 +16,7 @@
 #include <complex>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <memory>
 #include <stdexcept>
@@ -123,6 +124,47 @@ template <class T> struct FileSink : Fold<Array<T>> {
     ~FileSink() override { if (f) std::fclose(f); }
     void step(const Array<T> &a) override { if (!a.empty() && std::fwrite(a.data(), sizeof(T), a.size(), f) != a.size()) throw std::runtime_error("short write"); }
     void done() override { if (f) { std::fclose(f); f = nullptr; } }
+};
+
+// audioFileSink fmt sr sn nch fp (Sink.hs:41-74): libsndfile float, big-endian, fp + ".au" / ".wav".  AU: 24-byte
+// header (".snd", 24, data bytes, 6 = IEEE float, rate, channels).  WAV: libsndfile writes RIFX with a time-stamped
+// PEAK chunk (not reproducible); this writer emits RIFX + fmt(tag 3) + fact + data.  Unverified against libsndfile.
+struct AudioFileSink : Fold<Array<float>> {
+    FILE *f = nullptr; bool au; uint32_t sr, nch; uint64_t nbytes = 0; std::string path;
+    static void be32(unsigned char *p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; }
+    static void be16(unsigned char *p, uint16_t v) { p[0] = v >> 8; p[1] = v & 255; }
+    AudioFileSink(const std::string &fmt, uint32_t sr_, uint32_t nch_, const std::string &fp)
+        : au(fmt == "AU" || fmt == "au"), sr(sr_), nch(nch_), path(fp + ((fmt == "AU" || fmt == "au") ? ".au" : ".wav"))
+    {
+        f = std::fopen(path.c_str(), "wb");
+        if (!f) throw std::runtime_error("cannot open " + path);
+        header(au ? 0xffffffffu : 0u);
+    }
+    ~AudioFileSink() override { if (f) std::fclose(f); }
+    void header(uint32_t n)
+    {
+        unsigned char h[56];
+        std::fseek(f, 0, SEEK_SET);
+        if (au) {
+            std::memcpy(h, ".snd", 4); be32(h + 4, 24); be32(h + 8, n); be32(h + 12, 6); be32(h + 16, sr); be32(h + 20, nch);
+            std::fwrite(h, 1, 24, f);
+        } else {
+            std::memcpy(h, "RIFX", 4); be32(h + 4, 4 + 24 + 12 + 8 + n); std::memcpy(h + 8, "WAVE", 4);
+            std::memcpy(h + 12, "fmt ", 4); be32(h + 16, 16); be16(h + 20, 3); be16(h + 22, (uint16_t)nch); be32(h + 24, sr);
+            be32(h + 28, sr * 4 * nch); be16(h + 32, (uint16_t)(4 * nch)); be16(h + 34, 32);
+            std::memcpy(h + 36, "fact", 4); be32(h + 40, 4); be32(h + 44, n / (4 * nch));
+            std::memcpy(h + 48, "data", 4); be32(h + 52, n);
+            std::fwrite(h, 1, 56, f);
+        }
+    }
+    void step(const Array<float> &a) override
+    {
+        std::vector<unsigned char> b(a.size() * 4);
+        for (size_t i = 0; i < a.size(); i++) { uint32_t u; std::memcpy(&u, &a[i], 4); be32(b.data() + 4 * i, u); }
+        if (!b.empty() && std::fwrite(b.data(), 1, b.size(), f) != b.size()) throw std::runtime_error("short write");
+        nbytes += b.size();
+    }
+    void done() override { if (f) { header((uint32_t)nbytes); std::fclose(f); f = nullptr; } }
 };
 
 // ---- front-end Pipes: resampler r as (Liquid.chs:115-117), mixDown / mixUp f (Liquid.chs:805-809) ----

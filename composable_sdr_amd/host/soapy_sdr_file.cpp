@@ -1,10 +1,12 @@
 // soapy-sdr's file-input mode (apps/SoapySDR.hs:181-283) on the C-ABI chain:
 //   soapy_sdr_file --filename in.cf32 -n N -c M [--demod DeNo|DeNBFM kf|DeWBFM decim|DeAM] [-a dB] [-m] [-o output] [--chunksize 1024]
-//                  [-s samplerate] [-b bandwidth] [--offset Hz]
+//                  [-s samplerate] [-b bandwidth] [--offset Hz] [--audio AU|WAV]
 // readFromFile -> [mixDown/mixUp (--offset)] -> [resampler (-b)] -> takeNArr -> compact(4*M*1024) -> fused chain (dcBlocker + PFB + demod [+mix]) -> fileSinks
 // named <out>.cf32 / <out>_ch<k>.cf32 (DeNo, SoapySDR.hs:240) or raw .f32 for FM (the reference wraps
 // the same samples in WAV/AU through libsndfile).
+#include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <cstring>
 #include <iostream>
 
@@ -12,7 +14,7 @@
 
 using namespace csdrhost;
 
-struct FrontOpts { double samplerate = 2.56e6, bandwidth = 0.0, offset = 0.0; };
+struct FrontOpts { double samplerate = 2.56e6, bandwidth = 0.0, offset = 0.0; std::string audio; };
 static FrontOpts g_front;
 
 template <class Out> static int run(const std::string &in, const ChainOpts &o, size_t n, const std::string &out, size_t chunk, const char *ext)
@@ -20,8 +22,19 @@ template <class Out> static int run(const std::string &in, const ChainOpts &o, s
     const uint32_t M = o.channels;
     const bool mixed = o.mix && M > 1;
     std::vector<std::shared_ptr<Fold<Array<Out>>>> sinks;
-    if (mixed || M == 1) sinks.push_back(std::make_shared<FileSink<Out>>(out + ext));
-    else for (uint32_t k = 1; k <= M; k++) sinks.push_back(std::make_shared<FileSink<Out>>(out + "_ch" + std::to_string(k) + ext));
+    auto make = [&](const std::string &stem) -> std::shared_ptr<Fold<Array<Out>>> {
+        if constexpr (std::is_same<Out, float>::value) {
+            if (!g_front.audio.empty()) {
+                // getAudioSink decim fmt 1 (SoapySDR.hs:232-234): rate = round outBW `div` decim `div` nch
+                const double bw = g_front.bandwidth != 0.0 ? g_front.bandwidth : g_front.samplerate;
+                const uint32_t sr = (uint32_t)std::llround(bw) / (o.wbfm ? o.decim : 1u) / M;
+                return std::make_shared<AudioFileSink>(g_front.audio, sr, 1u, stem);
+            }
+        }
+        return std::make_shared<FileSink<Out>>(stem + ext);
+    };
+    if (mixed || M == 1) sinks.push_back(make(out));
+    else for (uint32_t k = 1; k <= M; k++) sinks.push_back(make(out + "_ch" + std::to_string(k)));
     auto fold = compact<cf32>((size_t)4 * M * 1024, addPipe(fusedChain<Out>(o), std::static_pointer_cast<Fold<std::vector<Array<Out>>>>(
                                                                                     std::make_shared<Distribute<Out>>(sinks))));
     FILE *f = std::fopen(in.c_str(), "rb");
@@ -70,6 +83,7 @@ int main(int argc, char **argv)
         else if (a == "-s" || a == "--samplerate") g_front.samplerate = std::atof(next());
         else if (a == "-b" || a == "--bandwidth") g_front.bandwidth = std::atof(next());
         else if (a == "--offset") g_front.offset = std::atof(next());
+        else if (a == "--audio") g_front.audio = next();
         else if (a == "--demod") { demod = next(); if (demod == "DeNBFM") { o.fm = true; o.kf = (float)std::atof(next()); } else if (demod == "DeAM") o.am = true; else if (demod == "DeWBFM") { o.wbfm = true; o.decim = (uint32_t)std::atoi(next()); } }
         else { std::cerr << "unknown option " << a << "\n"; return 2; }
     }

@@ -870,3 +870,30 @@ def test_chain_wbfm_matches_oracle(M, agc, mix):
     with pytest.raises(cs.CsdrError):
         ch.process(x[:M * 1023])
     ch.close()
+
+
+def test_cpp_soapy_sdr_file_wbfm_audio_matches_python_replay(tmp_path, monkeypatch):
+    """README's most used mode, offline: -b 200e3 --demod "DeWBFM 4 AU": C++ CLI and Python replay write the same
+    .au bytes (24-byte header with rate round(outBW) div decim div nch = 50000, big-endian floats)."""
+    import os
+    import struct
+    import subprocess
+    monkeypatch.setenv("CSDR_QUIET", "1")
+    from composable_sdr_amd.app import sdr_process
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "composable_sdr_amd", "host", "soapy_sdr_file")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s"])
+    x = synth_cf32(600000, 1, seed=18)
+    src = tmp_path / "in.cf32"
+    x.tofile(src)
+    n = 4096 * 8
+    py = sdr_process(str(src), channels=1, demod="wbfm", decim=4, numsamples=n, outname=str(tmp_path / "py"), chunksize=1024,
+                     samplerate=2.56e6, bandwidth=200e3, audio="AU")
+    r = subprocess.run([exe, "--filename", str(src), "-n", str(n), "-c", "1", "--demod", "DeWBFM", "4", "-s", "2.56e6", "-b", "200e3",
+                        "--audio", "AU", "-o", str(tmp_path / "cc")], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, CSDR_QUIET="1"))
+    assert r.returncode == 0, r.stderr
+    a, b = open(py[0], "rb").read(), open(tmp_path / "cc.au", "rb").read()
+    assert a == b and len(a) == 24 + 4 * (n // 4)
+    assert struct.unpack(">4sIIIII", a[:24]) == (b".snd", 24, 4 * (n // 4), 6, 50000, 1)

@@ -104,3 +104,23 @@ def test_cpp_host_combinators_build_and_pass():
     subprocess.check_call(["make", "-C", host, "-s", "test_host"])
     out = subprocess.run([os.path.join(host, "test_host")], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0 and "host combinators ok" in out.stdout, out.stderr
+
+
+def test_audio_file_sink_layouts(tmp_path):
+    """audioFileSink (Sink.hs:41-74): libsndfile float / big-endian AU and WAV.  AU = 24-byte header + BE floats;
+    WAV = RIFX + fmt(tag 3) + fact + data (libsndfile adds a time-stamped PEAK chunk: not reproducible)."""
+    import struct
+    from composable_sdr_amd.app import audioFileSink
+    x = np.linspace(-1, 1, 1000, dtype=np.float32)
+    s = audioFileSink("AU", 48000, 1000, 1, str(tmp_path / "a"))
+    s.step(x[:300]); s.step(x[300:]); s.done()
+    b = open(s.path, "rb").read()
+    assert s.path.endswith(".au") and struct.unpack(">4sIIIII", b[:24]) == (b".snd", 24, 4000, 6, 48000, 1)
+    assert np.array_equal(np.frombuffer(b[24:], dtype=">f4").astype(np.float32), x)
+    s = audioFileSink("WAV", 44100, 1000, 1, str(tmp_path / "w"))
+    s.step(x); s.done()
+    b = open(s.path, "rb").read()
+    assert s.path.endswith(".wav") and struct.unpack(">4sI4s", b[:12]) == (b"RIFX", len(b) - 8, b"WAVE")
+    assert struct.unpack(">4sIHHIIHH", b[12:36]) == (b"fmt ", 16, 3, 1, 44100, 176400, 4, 32)
+    assert struct.unpack(">4sII", b[36:48]) == (b"fact", 4, 1000) and struct.unpack(">4sI", b[48:56]) == (b"data", 4000)
+    assert np.array_equal(np.frombuffer(b[56:], dtype=">f4").astype(np.float32), x)
