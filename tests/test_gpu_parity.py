@@ -897,3 +897,14 @@ def test_cpp_soapy_sdr_file_wbfm_audio_matches_python_replay(tmp_path, monkeypat
     a, b = open(py[0], "rb").read(), open(tmp_path / "cc.au", "rb").read()
     assert a == b and len(a) == 24 + 4 * (n // 4)
     assert struct.unpack(">4sIIIII", a[:24]) == (b".snd", 24, 4 * (n // 4), 6, 50000, 1)
+
+
+def test_graft_entry_smoke_passes():
+    """the driver's smoke(): one small invocation of the hot path on cuda:0 checked against the oracle"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import __graft_entry__ as g
+    g.smoke()
