@@ -354,6 +354,79 @@ __device__ __forceinline__ float2 wg_sum(float2 v, float2 *red, int tid)
     return r;
 }
 
+// ---- column-layout DC stage of k_run256 (no LDS staging) ----
+// Thread j holds x[256 f + j], f = 0..15.  A run of 16 consecutive samples is exactly one 16-lane DPP row of one frame, so
+// the zero-state scan inside a run is a row scan: s_i = sum_{k<=i} beta^(i-k) x_k by four v_fmac_f32_dpp steps
+// (row_shr 1, 2, 4, 8 with beta^1, ^2, ^4, ^8; a lane without a source keeps its value), and
+// z_i = x_i - alpha s_{i-1} is one more.  Four independent values are interleaved per block: a VGPR written by a VALU
+// instruction must not be read through DPP for 2 wait states, and the compiler cannot see into the asm.
+__device__ __forceinline__ void row_scan4(float &x0, float &x1, float &x2, float &x3, float &s0, float &s1, float &s2, float &s3,
+                                          float b1, float b2, float b4, float b8, float na)
+{
+    asm volatile(
+        "v_mov_b32_e32 %4, %0\n\t"
+        "v_mov_b32_e32 %5, %1\n\t"
+        "v_mov_b32_e32 %6, %2\n\t"
+        "v_mov_b32_e32 %7, %3\n\t"
+        "v_fmac_f32_dpp %4, %4, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %7, %8 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %9 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %9 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %9 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %7, %9 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %10 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %10 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %10 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %7, %10 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %11 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %11 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %11 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %7, %11 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %12 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %5, %12 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %6, %12 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %7, %12 row_shr:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3)
+        : "v"(b1), "v"(b2), "v"(b4), "v"(b8), "v"(na));
+}
+
+// nw[f] = x[256 f + j]: 16 coalesced 8-byte loads per thread (a wave instruction covers 512 contiguous bytes)
+__device__ __forceinline__ void col_load(const float2 *__restrict__ src, float2 (&nw)[16], int j)
+{
+#pragma unroll
+    for (int f = 0; f < 16; f++) nw[f] = src[256 * f + j];
+}
+
+// In: nw = x (column layout).  Out: nw = z = x - alpha * (zero-state scan inside the sample's run), TR[q] = total of
+// run q (q = 16 f + (j >> 4)).  TR: 256 float2 of LDS; the caller synchronises before reading it.
+__device__ __forceinline__ void col_run_scan(float2 (&nw)[16], float2 *TR, const TileArgs &A, int tid)
+{
+    const float b1 = A.bj[1], b2 = A.bj[2], b4 = A.bj[4], b8 = A.bj[8], na = -A.alpha;
+#pragma unroll
+    for (int f = 0; f < 16; f += 2) {
+        float s0, s1, s2, s3;
+        row_scan4(nw[f].x, nw[f].y, nw[f + 1].x, nw[f + 1].y, s0, s1, s2, s3, b1, b2, b4, b8, na);
+        if ((tid & 15) == 15) {
+            TR[16 * f + (tid >> 4)] = make_float2(s0, s1);
+            TR[16 * (f + 1) + (tid >> 4)] = make_float2(s2, s3);
+        }
+    }
+}
+
+// run totals -> carry into every run from the earlier runs of its frame (zero frame carry) in E, frame totals in T
+__device__ __forceinline__ void col_run_carries(const float2 *TR, float2 *E, float2 *T, const TileArgs &A, int tid)
+{
+    float2 s = TR[tid], t;
+    t = dpp2<0x111>(s); s = cfma(t, A.b16[1], s);
+    t = dpp2<0x112>(s); s = cfma(t, A.b16[2], s);
+    t = dpp2<0x114>(s); s = cfma(t, A.b16[4], s);
+    t = dpp2<0x118>(s); s = cfma(t, A.b16[8], s);
+    E[tid] = dpp2<0x111>(s);
+    if ((tid & 15) == 15) T[tid >> 4] = s;
+}
+
 // v after frame 15 of a tile (zero state) from its frame totals; every lane gets the value
 __device__ __forceinline__ void frame_carries(const float2 *T, const TileArgs &A, int tid, float2 &before_mine, float2 &after_tile)
 {

@@ -34,6 +34,9 @@
 #ifndef CSDR_ABLATE
 #define CSDR_ABLATE 0
 #endif
+#ifndef CSDR_COLSCAN
+#define CSDR_COLSCAN 1      // k_run256: DC blocker on the column-layout registers (DPP row scans) instead of the LDS-staged run scan
+#endif
 #include <cstring>
 
 namespace csdr {
@@ -433,7 +436,11 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
     const bool st_ok = !(CSDR_ABLATE & 2) || A.nb == 0xffffffffu;   // timing experiments: no output stores
     const PhaseK &pk = RA.pk;
 
+#if CSDR_COLSCAN
+    col_load(A.x + (size_t)first * 4096, nw, tid);
+#else
     tile_load(x4 + (size_t)first * 2048, 256, raw, tid);
+#endif
     for (unsigned b = first; b < last; b++) {
         // every tile of a run is a full tile (the host hands ragged tails to k_tile256).
         // keep the per-phase LDS address arithmetic inside the iteration: hoisted out of the tile
@@ -452,6 +459,16 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         const int col_off_i = 16 * (j_i >> 4) + 2 * (((j_i & 15) >> 1) ^ (j_i >> 5)) + (j_i & 1);
         if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b * 16 + 9] = __builtin_amdgcn_s_memrealtime();
         RSTAMP(0);
+#if CSDR_COLSCAN
+        // ---- DC blocker, zero-state part, straight on the column-layout registers (no LDS staging): in-run scans by
+        // DPP, run totals through 2 KiB of LDS, then the same run / frame carries as the staged version ----
+        (void)col_off_i;
+        col_run_scan(nw, R, A, tid_i);
+        __syncthreads();
+        col_run_carries(R, E, Tt, A, tid_i);
+        __syncthreads();
+        RSTAMP(1);
+#else
         // ---- stage + scan this tile, prefetch the next one ----
         stage_and_scan(raw, R, E, Tt, A, tid_i);
 #if !(CSDR_ABLATE & 1) && defined(CSDR_EARLY_LOAD)
@@ -460,6 +477,7 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         RSTAMP(1);
 #pragma unroll
         for (int f = 0; f < NB; f++) nw[f] = R[256 * f + col_off_i];
+#endif
         const float kj = -A.alpha * A.bj[j_i & 15];
         const float br = A.b16[tid_i & 15], bf = A.b256[tid_i >> 4];
         float2 vb, ve;
@@ -516,7 +534,11 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         for (int f = 3; f < NB; f++) old[f] = nw[f];                // next tile's window
         __syncthreads();                                            // X complete
         RSTAMP(4);
-#if !(CSDR_ABLATE & 1) && !defined(CSDR_EARLY_LOAD)
+#if CSDR_COLSCAN
+#if !(CSDR_ABLATE & 1)
+        if (b + 1 < last) col_load(A.x + (size_t)(b + 1) * 4096, nw, tid_i);      // straight into the (dead) window registers
+#endif
+#elif !(CSDR_ABLATE & 1) && !defined(CSDR_EARLY_LOAD)
         if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, 256, raw, tid_i);
 #endif
 
