@@ -582,13 +582,7 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         if (FM) {
             if (b == first && w > 0) RA.yfirst[(size_t)w * M256 + tid_i] = v[0];
             float m[NB];
-#pragma unroll
-            for (int f = 0; f < NB; f++) {
-                const float2 rp = f ? v[f - 1] : prev, r = v[f];
-                const float re = fmaf(rp.x, r.x, rp.y * r.y);
-                const float im = fmaf(rp.x, r.y, -(rp.y * r.x));
-                m[f] = scaled_atan2f(im, re, pk);
-            }
+            freqdem16(v, prev, pk, m);
             prev = v[NB - 1];
             if (vec_out) {
                 // transpose the 16 demodulated samples per channel through LDS so that 4 consecutive lanes
