@@ -340,12 +340,15 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
     __shared__ float2 tw_s[M256];
     __shared__ float2 Tt[16];
     __shared__ float2 red[4];
+    __shared__ float taps_s[P * M256];      // taps_s[n][j] = h[(255 - j) + 256 n]: 14 ds_reads off one base per tile
 
     const int tid = threadIdx.x, j = tid;
     const unsigned w = blockIdx.x;
     unsigned first, last;                                                            // tiles [first, last)
     run_range(RA.split, w, first, last);
     tw_s[tid] = A.tw[tid];
+#pragma unroll
+    for (int n = 0; n < P; n++) taps_s[n * M256 + tid] = A.taps[(M256 - 1 - tid) + n * M256];
     LSTAMP(11);
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
     float2 *E = R + E_OFF;
@@ -434,6 +437,17 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
     float2 prev = (w == 0 && owned) ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
     const bool vec_out = ((A.out_stride | A.out_t0) % 4u) == 0;
     const bool st_ok = !(CSDR_ABLATE & 2) || A.nb == 0xffffffffu;   // timing experiments: no output stores
+    // line-coalesced stores: item = tid + 256 it covers piece (item & 3 | 7) of row item >> 2 (F32) / >> 3 (CF32); the
+    // element offsets of my items inside the output, and whether the row is in my channel shard
+    size_t st_off[FM ? 4 : 8];
+    unsigned st_mask = 0;
+#pragma unroll
+    for (int it = 0; it < (FM ? 4 : 8); it++) {
+        const int item = tid + 256 * it, rowk = FM ? item >> 2 : item >> 3, piece = FM ? item & 3 : item & 7;
+        const bool in = st_ok && (uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C;
+        st_off[it] = in ? (size_t)(rowk - A.c0) * A.out_stride + A.out_t0 + (FM ? 4 : 2) * piece : 0;
+        st_mask |= in ? 1u << it : 0u;
+    }
     const PhaseK &pk = RA.pk;
 
 #if CSDR_COLSCAN
@@ -510,7 +524,7 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         {
             float h[P];
 #pragma unroll
-            for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j_i) + n * M256];
+            for (int n = 0; n < P; n++) h[n] = taps_s[n * M256 + j_i];
 #pragma unroll
             for (int f0 = 0; f0 < NB; f0 += 4) {
                 // four frames at a time: consecutive FMAs are independent (a dependent packed chain costs a
@@ -592,12 +606,11 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
 #pragma unroll
                 for (int q = 0; q < 4; q++) M4[tid_i * 5 + q] = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
                 __syncthreads();
-                float *obase = (float *)A.out + A.out_t0 + (size_t)16 * b;
+                float *obase = (float *)A.out + (size_t)16 * b;
 #pragma unroll
                 for (int it = 0; it < 4; it++) {
                     const int item = tid_i + 256 * it, rowk = item >> 2, piece = item & 3;
-                    if (st_ok && (uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
-                        *reinterpret_cast<float4 *>(obase + (size_t)(rowk - A.c0) * A.out_stride + 4 * piece) = M4[rowk * 5 + piece];
+                    if (st_mask & (1u << it)) *reinterpret_cast<float4 *>(obase + st_off[it]) = M4[rowk * 5 + piece];
                 }
             } else if (owned) {
                 float *o = (float *)A.out + row;
@@ -607,13 +620,12 @@ __global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs
         } else if (vec_out) {
             // CF32 rows leave as whole 128-byte lines: 8 consecutive lanes write the 8 x 16-byte pieces of
             // one channel row (a wave instruction = 8 full lines), instead of 64 lanes x 16 B of 64 rows
-            float2 *obase = (float2 *)A.out + A.out_t0 + (size_t)16 * b;
+            float2 *obase = (float2 *)A.out + (size_t)16 * b;
 #pragma unroll
             for (int it = 0; it < 8; it++) {
                 const int item = tid_i + 256 * it, rowk = item >> 3, piece = item & 7;
                 const float2 a0 = R[rowk * RS_Y + 2 * piece], a1 = R[rowk * RS_Y + 2 * piece + 1];
-                if (st_ok && (uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C)
-                    *reinterpret_cast<float4 *>(obase + (size_t)(rowk - A.c0) * A.out_stride + 2 * piece) = make_float4(a0.x, a0.y, a1.x, a1.y);
+                if (st_mask & (1u << it)) *reinterpret_cast<float4 *>(obase + st_off[it]) = make_float4(a0.x, a0.y, a1.x, a1.y);
             }
         } else if (owned) {
             float2 *o = (float2 *)A.out + row;
