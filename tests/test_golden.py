@@ -56,3 +56,67 @@ def test_hip_matches_golden(path):
         assert np.median(d) < 2e-5
         pos += nf * M
         t += nf
+
+
+BLOCKS = os.path.join(os.path.dirname(__file__), "golden", "blocks_v1.npz")
+
+
+def test_oracle_reproduces_block_goldens_bit_exact():
+    """resampler / AM / de-emphasis / decimator / WBFM + AM chains: restatement goldens (unpinned blocks)"""
+    g = np.load(BLOCKS)
+    x, a = g["x"], int(g["split"][0])
+    for name, r in (("rs_0078125", 200e3 / 2.56e6), ("rs_0625", 0.625)):
+        q = O.MsResamp(np.float32(r))
+        assert np.array_equal(np.concatenate([q.execute(x[:a]), q.execute(x[a:])]), g[name])
+    am = O.AmpDem()
+    assert np.array_equal(np.concatenate([am.demodulate_block(x[:a]), am.demodulate_block(x[a:])]), g["am"])
+    xr = g["xr"]
+    bq = O.Butter2(0.025)
+    assert np.array_equal(np.concatenate(bq.coeffs), g["butter2_ba"])
+    assert np.array_equal(np.concatenate([bq.execute_block(xr[:a]), bq.execute_block(xr[a:])]), g["butter2"])
+    fd = O.FirDecim(4)
+    assert np.array_equal(fd.taps, g["firdecim4_taps"])
+    assert np.array_equal(np.concatenate([fd.execute_block(xr[:a // 4 * 4]), fd.execute_block(xr[a // 4 * 4:])]), g["firdecim4"])
+    M, nfs, xc = 8, list(g["nfs"]), g["xc"]
+    wb, amc = O.Chain(M, demod="wbfm", decim=4, deemph_fc=0.025), O.Chain(M, demod="am")
+    pos, t = 0, 0
+    for nf in nfs:
+        c = xc[pos:pos + nf * M]
+        assert np.array_equal(wb.process(c), g["chain_wbfm"][:, t // 4:(t + nf) // 4])
+        assert np.array_equal(amc.process(c), g["chain_am"][:, t:t + nf])
+        pos += nf * M
+        t += nf
+
+
+@pytest.mark.gpu
+def test_hip_matches_block_goldens(monkeypatch):
+    import composable_sdr_amd as cs
+    monkeypatch.setenv("CSDR_QUIET", "1")
+    g = np.load(BLOCKS)
+    x, a = g["x"], int(g["split"][0])
+
+    def run(pipe, chunks):
+        r = pipe._start()
+        try:
+            return np.concatenate([pipe._process(r, c) for c in chunks])
+        finally:
+            pipe._done(r)
+    for name, r in (("rs_0078125", 200e3 / 2.56e6), ("rs_0625", 0.625)):
+        y = run(cs.resampler(float(np.float32(r)), 60.0, max_samples=4096), [x[:a], x[a:]])
+        assert y.size == g[name].size and max_abs_err(y, g[name]) < 2e-6
+    assert max_abs_err(run(cs.amDemodulator(max_samples=4096), [x[:a], x[a:]]), g["am"]) < 2e-6
+    xr = g["xr"]
+    assert max_abs_err(run(cs.iirFilter(2, 0.025, max_samples=4096), [xr[:a], xr[a:]]), g["butter2"]) < 5e-6
+    assert max_abs_err(run(cs.firDecimator(4, max_samples=4096), [xr[:a // 4 * 4], xr[a // 4 * 4:]]), g["firdecim4"]) < 5e-6
+    M, nfs, xc = 8, list(g["nfs"]), g["xc"]
+    wb = cs.Chain(channels=M, demod="wbfm", decim=4, deemph_fc=0.025, max_frames=max(nfs))
+    amc = cs.Chain(channels=M, demod="am", max_frames=max(nfs))
+    pos, t = 0, 0
+    for nf in nfs:
+        c = xc[pos:pos + nf * M]
+        dw = np.abs(wb.process(c).astype(np.float64) - g["chain_wbfm"][:, t // 4:(t + nf) // 4])
+        assert np.median(dw) < 2e-5 * np.abs(g["chain_wbfm"]).max()
+        da = max_abs_err(amc.process(c), g["chain_am"][:, t:t + nf])
+        assert da < 2e-4 * max(1.0, np.abs(g["chain_am"]).max())
+        pos += nf * M
+        t += nf
