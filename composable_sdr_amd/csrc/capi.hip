@@ -796,9 +796,14 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
         // keep the last (p-1) frames of premixed input as the next call's history
         CSDR_HIP(hipMemcpyAsync(h->d_hist_tmp, h->d_u + nx, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
         CSDR_HIP(hipMemcpyAsync(h->d_u, h->d_hist_tmp, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
-        if ((r = launch_dft(h->d_A, h->d_B, h->d_tw, M, nf, s))) return r;
+        // DeNo --mix over all channels: the frame sum happens inside the DFT kernel, Y never goes to HBM
+        const bool fused_mix = !agc && !fm && mixo && C == M && dft_mix_supported(M);
+        if (fused_mix) r = launch_dft_mix(h->d_A, (float2 *)d_out, h->d_tw, M, nf, s);
+        else r = launch_dft(h->d_A, h->d_B, h->d_tw, M, nf, s);
+        if (r) return r;
         h->theta += nx * h->d_theta;
         if (h->tab_len) h->tab_pos = (uint32_t)(((uint64_t)h->tab_pos + nx) % h->tab_len);
+        if (fused_mix) return 0;
         if (!agc && (fm || mixo)) {
             // frame-major tails: no transpose in front of freqdem / mix
             if (mixo) r = launch_mix_frames(h->d_B, d_out, fm, M, nf, h->c0, C, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s);

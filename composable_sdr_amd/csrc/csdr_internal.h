@@ -83,6 +83,9 @@ int launch_pfb_fir(const float2 *u, const float *taps, float2 *X, uint32_t M, ui
                    uint32_t nf, hipStream_t s);
 // forward M-point DFT of every frame: Y[t][k].  tw: e^{-j 2 pi i/M}, i<M.
 int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s);
+// out[t] = sum_k DFT(X[t])[k] in k_mix_frames' summation order, without materialising Y (M = 1024, 4096, all channels)
+bool dft_mix_supported(uint32_t M);
+int launch_dft_mix(const float2 *X, float2 *out, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s);
 // Z[c][t] = Y[t][c0 + c]  for c < C
 int launch_transpose(const float2 *Y, float2 *Z, uint32_t M, uint32_t nf, uint32_t c0, uint32_t C,
                      hipStream_t s);

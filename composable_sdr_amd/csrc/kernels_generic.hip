@@ -334,7 +334,10 @@ __device__ __forceinline__ void g_fft16(v2fg (&v)[16])
 }
 #define GXIDX(i) (((i) >> 2) + 4 * ((i) & 3))
 
-template <int R3>   // N = 256 * R3
+// MIX: instead of writing Y[nf][N], fold every frame over its N channels in k_mix_frames' order (thread t adds
+// channels t, t+256, ... ascending, then the same tree over the 256 threads) and write one sample per frame:
+// --mix over all channels without the 16 B/sample round trip of Y through HBM (bit-identical to the two-kernel path).
+template <int R3, bool MIX>   // N = 256 * R3
 __global__ __launch_bounds__(256) void k_fft_r16(const float2 *__restrict__ X, float2 *__restrict__ Y,
                                                  const float2 *__restrict__ tw, uint32_t nf)
 {
@@ -376,12 +379,21 @@ __global__ __launch_bounds__(256) void k_fft_r16(const float2 *__restrict__ X, f
     }
     __syncthreads();
     // ---- pass 3: radix R3 over n3 for (frame, k1 + 16 k2), straight to global ----
+    float2 part[F];                                            // MIX: my channels' partial sum per frame
     if (R3 == 16) {
         const bool ok = f0 < nf;
 #pragma unroll
         for (int n3 = 0; n3 < 16; n3++) { const float2 x = bufB[t * 16 + n3]; v[n3] = (v2fg){x.x, x.y}; }
         g_fft16(v);
-        if (ok) {
+        if (MIX) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k3 = 0; k3 < 16; k3++) {                   // ascending channel order: v[i] holds k3 = GXIDX(i)
+                const int i = 4 * (k3 & 3) + (k3 >> 2);
+                acc.x += v[i].x; acc.y += v[i].y;
+            }
+            part[0] = acc;
+        } else if (ok) {
 #pragma unroll
             for (int i = 0; i < 16; i++) Y[f0 * N + t + 256 * GXIDX(i)] = make_float2(v[i].x, v[i].y);
         }
@@ -392,11 +404,31 @@ __global__ __launch_bounds__(256) void k_fft_r16(const float2 *__restrict__ X, f
 #pragma unroll
             for (int n3 = 0; n3 < 4; n3++) { const float2 x = bufB[fr * N + t * 4 + n3]; a[n3] = (v2fg){x.x, x.y}; }
             g_bfly4(a[0], a[1], a[2], a[3]);
-            if (f0 + fr < nf) {
+            if (MIX) {
+                float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int k3 = 0; k3 < 4; k3++) { acc.x += a[k3].x; acc.y += a[k3].y; }
+                part[fr] = acc;
+            } else if (f0 + fr < nf) {
 #pragma unroll
                 for (int k3 = 0; k3 < 4; k3++) Y[(f0 + fr) * N + t + 256 * k3] = make_float2(a[k3].x, a[k3].y);
             }
         }
+    }
+    if (MIX) {
+        __syncthreads();                                        // bufB consumed
+        float2 *red = bufB;                                     // [F][256]
+#pragma unroll
+        for (int fr = 0; fr < F; fr++) red[fr * 256 + t] = part[fr];
+        __syncthreads();
+        for (int d = 128; d >= 1; d >>= 1) {
+            if (t < d) {
+#pragma unroll
+                for (int fr = 0; fr < F; fr++) { red[fr * 256 + t].x += red[fr * 256 + t + d].x; red[fr * 256 + t].y += red[fr * 256 + t + d].y; }
+            }
+            __syncthreads();
+        }
+        if (t < F && f0 + t < nf) Y[f0 + t] = red[t * 256];    // Y is the mixed output [nf] here
     }
 }
 
@@ -408,9 +440,9 @@ int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_
         return 0;
     }
     if (M == 1024) {
-        hipLaunchKernelGGL(k_fft_r16<4>, dim3((nf + 3) / 4), dim3(256), 0, s, X, Y, tw, nf);
+        hipLaunchKernelGGL((k_fft_r16<4, false>), dim3((nf + 3) / 4), dim3(256), 0, s, X, Y, tw, nf);
     } else if (M == 4096) {
-        hipLaunchKernelGGL(k_fft_r16<16>, dim3(nf), dim3(256), 0, s, X, Y, tw, nf);
+        hipLaunchKernelGGL((k_fft_r16<16, false>), dim3(nf), dim3(256), 0, s, X, Y, tw, nf);
     } else if ((M & (M - 1)) == 0 && M <= 8192) {
         uint32_t lg = 0; while ((1u << lg) < M) lg++;
         unsigned th = M / 2 < 64 ? 64 : (M / 2 > 256 ? 256 : M / 2);
@@ -419,6 +451,18 @@ int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_
         const uint64_t total = (uint64_t)M * nf;
         hipLaunchKernelGGL(k_dft_direct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, Y, tw, M, total);
     }
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+// DFT of every frame folded over all M channels: out[t] = sum_k Y[t][k] (DeNo --mix, Trans.hs:119-122), M = 1024 / 4096
+bool dft_mix_supported(uint32_t M) { return M == 1024 || M == 4096; }
+int launch_dft_mix(const float2 *X, float2 *out, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s)
+{
+    if (!nf) return 0;
+    if (M == 1024) hipLaunchKernelGGL((k_fft_r16<4, true>), dim3((nf + 3) / 4), dim3(256), 0, s, X, out, tw, nf);
+    else if (M == 4096) hipLaunchKernelGGL((k_fft_r16<16, true>), dim3(nf), dim3(256), 0, s, X, out, tw, nf);
+    else { set_error("dft_mix: unsupported M=%u", M); return -1; }
     CSDR_HIP(hipGetLastError());
     return 0;
 }
