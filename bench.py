@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # same guide: measured float4-copy ceiling (SURVEY 8d asks for both fractions)
 
 
 def parse():
@@ -159,6 +160,7 @@ def main():
         "hbm_roofline_frac_whole_step": round(value * 1e6 * alg_bytes_per_sample / 1e9 / (HBM_PEAK_GBS * world), 4),
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                     "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4) if achieved else None,
                      "traffic": traffic, "launch_ms": round(kavg_ms, 4), "launches": klaunches,
                      "alg_bytes_per_sample": alg_bytes_per_sample, "samples_per_launch": nx},
     }

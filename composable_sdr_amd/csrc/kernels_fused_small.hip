@@ -57,9 +57,11 @@ __global__ __launch_bounds__(256, 3) void k_run64(SmallArgs SA)
     __shared__ float2 yprev[2][MS];         // last Y frame of the previous tile (double buffered)
     __shared__ float2 Tt[16];
     __shared__ float2 red[4];
+    __shared__ float taps_s[P * MS];        // taps_s[n][j] = h[(63 - j) + 64 n]
 
     const int tid = threadIdx.x;
     const unsigned w = blockIdx.x;
+    for (int i = tid; i < P * MS; i += 256) taps_s[i] = A.taps[(MS - 1 - (i % MS)) + (i / MS) * MS];
     const unsigned first = w * SA.S, last = min(first + SA.S, A.nb);
     const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
     if (tid < 16 * R2) tw_s[tid] = A.tw[tid];
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 3) void k_run64(SmallArgs SA)
         {
             float h[P];
 #pragma unroll
-            for (int n = 0; n < P; n++) h[n] = A.taps[(MS - 1 - j_i) + n * MS];
+            for (int n = 0; n < P; n++) h[n] = taps_s[n * MS + j_i];
 #pragma unroll
             for (int f = 0; f < 16; f++) {
                 v2f acc = {0.f, 0.f};
