@@ -125,6 +125,7 @@ struct csdr_chain {
     FusedPlan *fused = nullptr;
     SmallPlan *small = nullptr;
     DcTilePlan *dctile = nullptr;   // generic path with the DC blocker: single-pass scan kernel
+    uint32_t n_cus = 256;            // compute units of the device (run count of the fused M = 1024 kernel)
     AgcTailPlan *agc_tail = nullptr; // AGC on: time-parallel verified tail (unless CSDR_FLAG_AGC_SEQUENTIAL)
     // DeAM: the chain runs as DeNo into d_amz, then the ampmodem peak detector (kernels_am.hip) [+ mix]
     bool am = false, am_mix = false;
@@ -645,6 +646,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     csdr_chain *h = new (std::nothrow) csdr_chain();
     if (!h) return CSDR_ERR_NOMEM;
     h->cfg = *cfg; h->device = dev; h->M = M; h->C = C; h->c0 = c0;
+    { int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); h->n_cus = (uint32_t)cus; }
     const uint32_t m = cfg->pfb_m ? cfg->pfb_m : 7;
     const float As = cfg->pfb_as > 0.f ? cfg->pfb_as : 80.0f;
     h->p = 2 * m;
@@ -711,7 +713,8 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         }
     } else {
         h->path = "generic";
-        h->timed_kernel = M > 1 ? "k_pfb_fir" : "k_dc_apply";
+        h->timed_kernel = M > 1 ? ((pfb1024_supported(M, h->p) && !(cfg->mix && cfg->agc_threshold_db == 0.0f) && !getenv("CSDR_NO_PFB1024")) ? "k_pfb1024" : "k_pfb_fir") : "k_dc_apply";
+        if (pfb1024_supported(M, h->p) && !(cfg->mix && cfg->agc_threshold_db == 0.0f) && !getenv("CSDR_NO_PFB1024")) h->path = "generic+pfb1024";
         if (M > 1) {
             if ((r = dev_alloc(&h->d_u, (size_t)(h->p - 1) * M + h->max_nx)) || (r = dev_alloc(&h->d_hist_tmp, (size_t)(h->p - 1) * M))) return fail(r);
         }
@@ -790,12 +793,38 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
         if (h->dctile) r = dctile_process(h->dctile, d_in, u_new, nx, true, nco, h->d_nco_tab, s);
         else r = launch_dc_mix(d_in, u_new, nx, h->cfg.dc_block != 0, h->dc, h->d_dcstate, h->d_scratch, true, nco, h->d_nco_tab, s);
         if (r) return r;
+        // M = 1024: FIR + DFT + transpose [+ freqdem] in one kernel (no X / Y round trips through HBM); the frame-major
+        // mix tails without AGC still want Y in HBM and keep the three-kernel route
+        const bool fused1024 = pfb1024_supported(M, h->p) && !(mixo && !agc) && !getenv("CSDR_NO_PFB1024");
         if ((r = h->timer.begin(s))) return r;
-        if ((r = launch_pfb_fir(u_new, h->d_taps, h->d_A, M, h->p, nf, s))) return r;
+        if (fused1024) {
+            const bool fm_here = fm && !agc;                     // with the AGC on the tail does the freqdem
+            void *o = fm_here ? d_out : (void *)Z;
+            r = launch_pfb1024(u_new, h->d_taps, h->d_tw, o, fm_here, nf, h->c0, C, h->fm_ref, fm_here ? h->d_rp[h->rp_cur] : nullptr,
+                               fm_here ? h->d_rp[h->rp_cur ^ 1] : nullptr, h->d_B, h->n_cus, s);
+            if (!r && fm_here) h->rp_cur ^= 1;
+        } else r = launch_pfb_fir(u_new, h->d_taps, h->d_A, M, h->p, nf, s);
+        if (r) return r;
         if ((r = h->timer.end(s))) return r;
         // keep the last (p-1) frames of premixed input as the next call's history
         CSDR_HIP(hipMemcpyAsync(h->d_hist_tmp, h->d_u + nx, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
         CSDR_HIP(hipMemcpyAsync(h->d_u, h->d_hist_tmp, sizeof(float2) * hist, hipMemcpyDeviceToDevice, s));
+        if (fused1024) {
+            h->theta += nx * h->d_theta;
+            if (h->tab_len) h->tab_pos = (uint32_t)(((uint64_t)h->tab_pos + nx) % h->tab_len);
+            if (fm && !agc) return 0;
+            if (agc && h->agc_tail) return chain_agc_tail(h, Z, nf, d_out, s);
+            if (agc) {
+                if ((r = launch_agc(Z, C, nf, h->d_agc, h->agc, s))) return r;
+                if (fm) {
+                    float *F = mixo ? (float *)h->d_B : (float *)d_out;
+                    if ((r = launch_fm(Z, F, C, nf, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s))) return r;
+                    h->rp_cur ^= 1;
+                    if (mixo && (r = launch_mix(F, (float *)d_out, C, nf, s))) return r;
+                } else if (mixo && (r = launch_mix((const float *)Z, (float *)d_out, C, 2 * nf, s))) return r;
+            }
+            return 0;
+        }
         // DeNo --mix over all channels: the frame sum happens inside the DFT kernel, Y never goes to HBM
         const bool fused_mix = !agc && !fm && mixo && C == M && dft_mix_supported(M);
         if (fused_mix) r = launch_dft_mix(h->d_A, (float2 *)d_out, h->d_tw, M, nf, s);

@@ -86,6 +86,11 @@ int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_
 // out[t] = sum_k DFT(X[t])[k] in k_mix_frames' summation order, without materialising Y (M = 1024, 4096, all channels)
 bool dft_mix_supported(uint32_t M);
 int launch_dft_mix(const float2 *X, float2 *out, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s);
+// fused FIR + DFT + transpose [+ freqdem] for M = 1024 (kernels_pfb1024.hip): u_new as for launch_pfb_fir; out = channel-major
+// [C][nf] CF32, or F32 with fm; scratch: 2 * min(max_runs, nf/32) * 1024 float2
+bool pfb1024_supported(uint32_t M, uint32_t p);
+int launch_pfb1024(const float2 *u_new, const float *taps, const float2 *tw, void *out, bool fm, uint32_t nf, uint32_t c0, uint32_t C,
+                   float ref, const float2 *rp_in, float2 *rp_out, float2 *scratch, uint32_t max_runs, hipStream_t s);
 // Z[c][t] = Y[t][c0 + c]  for c < C
 int launch_transpose(const float2 *Y, float2 *Z, uint32_t M, uint32_t nf, uint32_t c0, uint32_t C,
                      hipStream_t s);

@@ -908,3 +908,47 @@ def test_graft_entry_smoke_passes():
         sys.path.insert(0, root)
     import __graft_entry__ as g
     g.smoke()
+
+
+# --------------------------------------------------------------------------- fused FIR + DFT kernel for M = 1024
+
+
+@pytest.mark.parametrize("demod,agc,shard", [("fm", 0.0, None), ("none", 0.0, None), ("fm", 8.0, None), ("fm", 0.0, (300, 200)), ("am", 0.0, None)])
+def test_pfb1024_fused_kernel_matches_three_kernel_route_and_oracle(demod, agc, shard, monkeypatch):
+    """M = 1024: k_pfb1024 (FIR + DFT + transpose + freqdem in one kernel) against the k_pfb_fir / k_fft_r16 / k_transpose_fm
+    route (CSDR_NO_PFB1024) on ragged chunks, and against the oracle.  Same arithmetic per output sample (FIR tap order,
+    DFT index scheme, freqdem routine): CF32 agrees to rounding of the FMA grouping, FM modulo 1/kf."""
+    M = 1024
+    frames = [64, 8, 37, 200, 3, 128]
+    nf = sum(frames)
+    x = synth_cf32(M * nf, M, seed=31)
+    kw = dict(channels=M, demod=demod, kf=0.3, agc=agc, max_frames=max(frames))
+    if shard:
+        kw.update(chan_first=shard[0], chan_count=shard[1])
+    a = cs.Chain(**kw)
+    monkeypatch.setenv("CSDR_NO_PFB1024", "1")
+    b = cs.Chain(**kw)
+    monkeypatch.delenv("CSDR_NO_PFB1024")
+    orc = O.Chain(M, demod=demod, kf=0.3, agc_db=agc) if not shard else O.Chain(M, demod=demod, kf=0.3)
+    ga, gb, wo, pos = [], [], [], 0
+    for f in frames:
+        xa = x[pos * M:(pos + f) * M]
+        ga.append(a.process(xa)); gb.append(b.process(xa)); wo.append(orc.process(xa)); pos += f
+    ga, gb, wo = np.concatenate(ga, axis=1), np.concatenate(gb, axis=1), np.concatenate(wo, axis=1)
+    if shard:
+        wo = wo[shard[0]:shard[0] + shard[1]]
+    assert ga.shape == gb.shape == wo.shape
+    if demod == "none":
+        assert rel_rms(ga, gb) < 1e-6 and rel_rms(ga, wo) < 1e-5
+    elif demod == "am":
+        assert max_abs_err(ga, gb) < 1e-4 * np.abs(gb).max() and max_abs_err(ga, wo) < 2e-4 * max(1.0, np.abs(wo).max())
+    else:
+        d1 = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / 0.3))
+        d2 = np.abs(wrap_pm(ga.astype(np.float64) - wo, 1.0 / 0.3))
+        print(f"pfb1024 {demod} agc={agc} shard={shard}: vs 3-kernel median {np.median(d1):.2e} p99.9 {np.quantile(d1, 0.999):.2e}; vs oracle median {np.median(d2):.2e}")
+        if agc:
+            assert int(np.sum((ga == 0) != (gb == 0))) <= 2 * M
+            assert np.median(d1) < 2e-5 and np.median(d2) < 2e-5
+        else:
+            assert np.median(d1) < 1e-6 and np.quantile(d1[1::4], 0.999) < 2e-5 and np.median(d2) < 2e-5
+    a.close(); b.close()
