@@ -124,6 +124,7 @@ struct csdr_chain {
     float2 *d_in_stage = nullptr; void *d_out_stage = nullptr;
     FusedPlan *fused = nullptr;
     SmallPlan *small = nullptr;
+    BigPlan *big = nullptr;          // M = 1024 run kernel
     DcTilePlan *dctile = nullptr;   // generic path with the DC blocker: single-pass scan kernel
     uint32_t n_cus = 256;            // compute units of the device (run count of the fused M = 1024 kernel)
     AgcTailPlan *agc_tail = nullptr; // AGC on: time-parallel verified tail (unless CSDR_FLAG_AGC_SEQUENTIAL)
@@ -615,6 +616,7 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
     }
     if (h->fused) { int r = fused_reset(h->fused, s); if (r) return r; }
     if (h->small) { int r = small_reset(h->small, s); if (r) return r; }
+    if (h->big) { int r = big_reset(h->big, s); if (r) return r; }
     if (h->dctile) { int r = dctile_reset(h->dctile, s); if (r) return r; }
     return 0;
 }
@@ -689,7 +691,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     // With the AGC on, the fused kernel stops at the channel-major CF32 samples and the
     // exactly-sequential per-channel AGC tail (one lane per channel) + freqdem + mix follow.
     const bool want_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC);
-    h->use_fused = want_fused && (fused_supported(M, h->p) || small_supported(M, h->p));
+    h->use_fused = want_fused && (fused_supported(M, h->p) || small_supported(M, h->p) || (big_supported(M, h->p) && !getenv("CSDR_NO_RUN1024")));
     if (h->use_fused) {
         const bool agc_on = cfg->agc_threshold_db != 0.0f;
         FusedConfig fc{};
@@ -701,6 +703,10 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             if ((r = small_create(fc, &h->small))) return fail(r);
             h->path = std::string("fused-") + small_name(h->small) + (agc_on ? "+agc" : "");
             h->timed_kernel = small_name(h->small);
+        } else if (big_supported(M, h->p)) {
+            if ((r = big_create(fc, &h->big))) return fail(r);
+            h->path = std::string("fused-") + big_name(h->big) + (agc_on ? "+agc" : "");
+            h->timed_kernel = big_name(h->big);
         } else {
             if ((r = fused_create(fc, &h->fused))) return fail(r);
             h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (agc_on ? "+agc" : "");
@@ -921,6 +927,7 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         FusedCall fcall{};
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         if (h->small) { if ((r = small_process(h->small, fcall, s, &h->timer))) return r; }
+        else if (h->big) { if ((r = big_process(h->big, fcall, s, &h->timer))) return r; }
         else if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
         h->theta += n_in * h->d_theta;
         if (agc_on && h->agc_tail) {
@@ -989,6 +996,7 @@ int csdr_chain_seek_frames(csdr_chain *h, uint64_t frames)
     if (h->tab_len) h->tab_pos = (uint32_t)(n % h->tab_len);
     if (h->fused) fused_seek(h->fused, frames);
     if (h->small) small_seek(h->small, frames);
+    if (h->big) big_seek(h->big, frames);
     return CSDR_OK;
 }
 
@@ -1043,6 +1051,7 @@ int csdr_chain_destroy(csdr_chain *h)
     (void)hipDeviceSynchronize();
     if (h->fused) fused_destroy(h->fused);
     if (h->small) small_destroy(h->small);
+    if (h->big) big_destroy(h->big);
     if (h->dctile) dctile_destroy(h->dctile);
     if (h->agc_tail) agc_tail_destroy(h->agc_tail);
     h->timer.destroy();

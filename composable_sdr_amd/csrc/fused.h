@@ -45,6 +45,17 @@ const char *small_name(const SmallPlan *plan);
 void small_destroy(SmallPlan *plan);
 
 
+// M = 1024 run kernel (kernels_pfb1024.hip, DC = true): same call interface
+struct BigPlan;
+bool big_supported(uint32_t M, uint32_t p);
+int  big_create(const FusedConfig &cfg, BigPlan **out);
+int  big_reset(BigPlan *plan, hipStream_t s);
+int  big_process(BigPlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
+void big_seek(BigPlan *plan, uint64_t frames);
+const char *big_name(const BigPlan *plan);
+void big_destroy(BigPlan *plan);
+
+
 // single-pass DC blocker + NCO mix for whole chunks of the generic path (kernels_dc_tile.hip)
 struct DcTilePlan;
 int  dctile_create(const DcParams &dc, uint64_t max_samples, DcTilePlan **out);

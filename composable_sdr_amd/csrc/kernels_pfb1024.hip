@@ -20,6 +20,9 @@
 #include "csdr_internal.h"
 #include "fm_common.h"
 #include "fft16_generic.h"
+#include "fused_common.h"
+#include "fused.h"
+#include <cmath>
 
 namespace csdr {
 
@@ -37,15 +40,45 @@ struct Pfb1024Args {
     float2 *yfirst, *ylast;     // [nruns][1024]
     uint32_t nf, nb, nruns, c0, C;
     float ref;
+    // DC = true (k_run1024): u is the RAW input of this call (no history prefix); DC blocker + NCO pre-mix happen here
+    const float2 *wpre;         // [2][1024] conj(nco phasor) of branch j for even / odd global frames
+    const float2 *vend_in; float2 *vend_out;      // DC blocker state v1
+    const float2 *uhist_in; float2 *uhist_out;    // [13][1024] pre-mixed, DC-blocked window before / after the call
+    uint32_t parity0;
+    float alpha, l2beta;
+    float bp[4];                // beta^1, ^2, ^4, ^8       (in-run DPP scan)
+    float dp[4];                // beta^16, ^32, ^64, ^128   (scan over the 64 runs of a frame, row part)
+    float dm;                   // beta^1024                 (frame to frame)
 };
 
-template <bool FM>
+template <int NV> __device__ __forceinline__ void shift_window_n(float2 (&old)[13], const float2 (&nw)[PT])
+{
+#pragma unroll
+    for (int i = 0; i < 13; i++) old[i] = (i + NV < 13) ? old[i + NV] : nw[i + NV - 13];
+}
+__device__ __forceinline__ void shift_window(float2 (&old)[13], const float2 (&nw)[PT], int nv)
+{
+    switch (nv) {
+    case 1: shift_window_n<1>(old, nw); break;
+    case 2: shift_window_n<2>(old, nw); break;
+    case 3: shift_window_n<3>(old, nw); break;
+    case 4: shift_window_n<4>(old, nw); break;
+    case 5: shift_window_n<5>(old, nw); break;
+    case 6: shift_window_n<6>(old, nw); break;
+    case 7: shift_window_n<7>(old, nw); break;
+    default: break;
+    }
+}
+
+template <bool FM, bool DC>
 __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
 {
     __shared__ float2 bufA[PT * 16 * PAS];      // 69 632 B
     __shared__ float2 bufB[PT * PM];            // 65 536 B
     __shared__ float2 tw1[16 * 64];             // pass-1 twiddles W1024^(m k1) at [k1][m]
     __shared__ float2 tw2[16 * 4];              // pass-2 twiddles W1024^(16 n3 k2) at [k2][n3]
+    __shared__ float2 Tt[PT];                   // DC: frame totals
+    __shared__ float2 red[16];
     const int tid = threadIdx.x, j = tid;
     { const int k1 = tid >> 6, m = tid & 63; tw1[tid] = A.tw[(m * k1) & 1023]; }
     if (tid < 64) { const int k2 = tid >> 2, n3 = tid & 3; tw2[tid] = A.tw[(16 * n3 * k2) & 1023]; }
@@ -53,29 +86,137 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
     const uint32_t first = (uint32_t)((uint64_t)w * A.nb / A.nruns), last = (uint32_t)((uint64_t)(w + 1) * A.nb / A.nruns);
     if (first >= last) return;
 
+    const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
+    float2 prev = (FM && w == 0 && owned) ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
     float2 old[13];
-    {
+    float2 c = make_float2(0.f, 0.f);           // DC: blocker state at the start of the run (then kept in carry_s)
+    uint32_t tile_begin = first;                // DC, run >= 1: two halo tiles refill the window (no output)
+    __shared__ float2 carry_s;                  // DC: blocker state before the next tile
+    if (!DC) {
         const int64_t fa = (int64_t)first * PT;
 #pragma unroll
         for (int i = 0; i < 13; i++) old[i] = A.u[(fa - 13 + i) * PM + j];          // reaches into the history for run 0
+    } else if (w == 0) {
+#pragma unroll
+        for (int i = 0; i < 13; i++) old[i] = A.uhist_in[i * PM + j];
+        c = A.vend_in[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 13; i++) old[i] = make_float2(0.f, 0.f);
+        // read-only warm-up: DC state before tile first-2 from the three tiles (24 576 samples) in front of it
+        // (beta^24576 = 4.6e-6 of the older state is dropped, like k_run256)
+        tile_begin = first - 2;
+        float wg[PT];
+#pragma unroll
+        for (int f = 0; f < PT; f++) wg[f] = exp2f(A.l2beta * (float)(PT * PM - 1 - (PM * f + tid)));
+        const float btile = exp2f(A.l2beta * (float)(PT * PM));
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll 1
+        for (uint32_t t = tile_begin - 3; t < tile_begin; t++) {
+            float2 p = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int f = 0; f < PT; f++) p = cfma(A.u[((size_t)t * PT + f) * PM + j], wg[f], p);
+            acc = cfma(acc, btile, p);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { acc.x += __shfl_xor(acc.x, d); acc.y += __shfl_xor(acc.y, d); }
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; i++) { c.x += red[i].x; c.y += red[i].y; }
     }
-    const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
-    float2 prev = (FM && w == 0 && owned) ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
 
     float2 nw[PT];
     {
-        const uint32_t t0 = first * PT;
+        const uint32_t t0 = tile_begin * PT;
 #pragma unroll
         for (int f = 0; f < PT; f++) nw[f] = t0 + f < A.nf ? A.u[(size_t)(t0 + f) * PM + j] : make_float2(0.f, 0.f);
     }
-    __syncthreads();                                                // twiddle tables
-    for (uint32_t b = first; b < last; b++) {
+    if (DC && tid == 0) carry_s = c;
+    __syncthreads();                                                // twiddle tables, carry_s
+    for (uint32_t b = tile_begin; b < last; b++) {
         // keep the per-phase address arithmetic inside the iteration (hoisted out of the tile loop it pins dozens of VGPRs)
         int tid_i = tid;
         asm volatile("" : "+v"(tid_i));
         const int j_i = tid_i;
         const uint32_t t0 = b * PT;
         const int nvalid = (int)min((uint32_t)PT, A.nf - t0);
+        if (DC) {
+            // ---- DC blocker (zero-state part) on the column-layout registers: in-run scans by DPP, run totals to LDS ----
+            float2 *TR = bufA, *E = bufA + 512;
+#pragma unroll
+            for (int f = 0; f < PT; f += 2) {
+                float s0, s1, s2, s3;
+                row_scan4(nw[f].x, nw[f].y, nw[f + 1].x, nw[f + 1].y, s0, s1, s2, s3, A.bp[0], A.bp[1], A.bp[2], A.bp[3], -A.alpha);
+                if ((tid_i & 15) == 15) {
+                    TR[64 * f + (tid_i >> 4)] = make_float2(s0, s1);
+                    TR[64 * (f + 1) + (tid_i >> 4)] = make_float2(s2, s3);
+                }
+            }
+            __syncthreads();
+            // ---- wave f scans the 64 run totals of frame f: four DPP row steps, then the three row-to-row carries ----
+            float2 e0 = make_float2(0.f, 0.f);
+            if (tid_i < 512) {
+                const int l = tid_i & 63;
+                const float wrow = exp2f(A.l2beta * 16.0f * (float)((tid_i & 15) + 1));   // beta^(16 ((r & 15) + 1))
+                float2 sv = TR[tid_i], t;
+                t = dpp2<0x111>(sv); sv = cfma(t, A.dp[0], sv);
+                t = dpp2<0x112>(sv); sv = cfma(t, A.dp[1], sv);
+                t = dpp2<0x114>(sv); sv = cfma(t, A.dp[2], sv);
+                t = dpp2<0x118>(sv); sv = cfma(t, A.dp[3], sv);
+#pragma unroll
+                for (int rho = 1; rho < 4; rho++) {
+                    const float2 v = make_float2(__shfl(sv.x, 16 * rho - 1), __shfl(sv.y, 16 * rho - 1));
+                    if ((l >> 4) == rho) sv = cfma(v, wrow, sv);
+                }
+                e0 = make_float2(__shfl_up(sv.x, 1), __shfl_up(sv.y, 1));
+                if (l == 0) e0 = make_float2(0.f, 0.f);
+                if (l == 63) Tt[tid_i >> 6] = sv;
+            }
+            __syncthreads();
+            // ---- frame carries: state before frame f = vb_f + beta^(1024 f) c; after the tile: ve + beta^8192 c ----
+            {
+                const int fme = (tid_i >> 6) & 7;
+                float2 vb = make_float2(0.f, 0.f), ve = make_float2(0.f, 0.f);
+                float dn = 1.0f;                                    // beta^(1024 nvalid): a ragged last tile stops the state there
+#pragma unroll
+                for (int f = 0; f < PT; f++) {
+                    if (f == fme) vb = ve;
+                    if (f < nvalid) { ve = cfma(ve, A.dm, Tt[f]); dn *= A.dm; }
+                }
+                const float2 cc = carry_s;
+                if (tid_i < 512) {
+                    const float br = exp2f(A.l2beta * 16.0f * (float)(tid_i & 63));           // beta^(16 r), r = run inside the frame
+                    const float bf = exp2f(A.l2beta * 1024.0f * (float)fme);                 // beta^(1024 f)
+                    E[tid_i] = cfma(cfma(cc, bf, vb), br, e0);
+                }
+                __syncthreads();                                    // carry_s read by everyone
+                if (tid_i == 0) carry_s = cfma(cc, dn, ve);
+            }
+            __syncthreads();
+            // ---- finish the DC blocker, apply the NCO pre-mix ----
+            {
+                const float kj = -A.alpha * exp2f(A.l2beta * (float)(tid_i & 15));
+                const float2 Wa = A.wpre[(A.parity0 & 1) * PM + j_i], Wb = A.wpre[((A.parity0 & 1) ^ 1) * PM + j_i];
+#pragma unroll
+                for (int f = 0; f < PT; f++) {
+                    const float2 y = cfma(E[64 * f + (j_i >> 4)], kj, nw[f]);
+                    nw[f] = cmul(y, (f & 1) ? Wb : Wa);
+                }
+            }
+        }
+        if (DC && b < first) {
+            // halo tile: only the window moves
+#pragma unroll
+            for (int i = 0; i < 13; i++) old[i] = (i + PT < 13) ? old[i + PT] : nw[i + PT - 13];
+            {
+                const uint32_t t1 = t0 + PT;
+#pragma unroll
+                for (int f = 0; f < PT; f++) nw[f] = t1 + f < A.nf ? A.u[(size_t)(t1 + f) * PM + j_i] : make_float2(0.f, 0.f);
+            }
+            __syncthreads();                                        // E consumed before the next tile's run totals
+            continue;
+        }
         // ---- polyphase FIR, oldest tap first; four frames at a time (independent accumulators).  The 14 taps are
         // re-read per tile (L2-resident, 56 KiB for the whole bank): held across the tile loop they would spill ----
         float h[PP];
@@ -96,15 +237,11 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
 #pragma unroll
             for (int q = 0; q < 4; q++) bufB[(f0 + q) * PM + j_i] = make_float2(acc[q].x, acc[q].y);
         }
-        // next tile's window: the last 13 of (old | nw)
+        // next tile's window: the last 13 of (old | nw); a ragged last tile only moves by its valid frames
+        if (nvalid == PT) {
 #pragma unroll
-        for (int i = 0; i < 13; i++) old[i] = (i + PT < 13) ? old[i + PT] : nw[i + PT - 13];
-        // the next tile's samples fly in during the DFT and the tail
-        if (b + 1 < last) {
-            const uint32_t t1 = t0 + PT;
-#pragma unroll
-            for (int f = 0; f < PT; f++) nw[f] = t1 + f < A.nf ? A.u[(size_t)(t1 + f) * PM + j_i] : make_float2(0.f, 0.f);
-        }
+            for (int i = 0; i < 13; i++) old[i] = (i + PT < 13) ? old[i + PT] : nw[i + PT - 13];
+        } else shift_window(old, nw, nvalid);
         __syncthreads();                                            // X complete (in bufB)
 
         v2fg v[16];
@@ -136,6 +273,18 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
             }
         }
         __syncthreads();
+        // the next tile's samples fly in during pass 3 and the tail (issued here, after the two radix-16 passes, so that
+        // they do not sit in registers next to the butterflies)
+        if (b + 1 < last) {
+            const uint32_t t1 = t0 + PT;
+            if (t1 + PT <= A.nf) {
+#pragma unroll
+                for (int f = 0; f < PT; f++) nw[f] = A.u[(size_t)(t1 + f) * PM + j_i];
+            } else {
+#pragma unroll
+                for (int f = 0; f < PT; f++) nw[f] = t1 + f < A.nf ? A.u[(size_t)(t1 + f) * PM + j_i] : make_float2(0.f, 0.f);
+            }
+        }
         // ---- pass 3: radix 4 over n3 for (frame, k1 + 16 k2): thread (fh, tq) does frames fh and fh + 4 ----
         {
             const int tq = tid_i & 255, fh = tid_i >> 8;
@@ -218,6 +367,11 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
         A.ylast[(size_t)w * PM + tid] = prev;
         if (w + 1 == A.nruns && owned) A.rp_out[tid - A.c0] = prev;
     }
+    if (DC && w + 1 == A.nruns) {
+        if (tid == 0) A.vend_out[0] = carry_s;
+#pragma unroll
+        for (int i = 0; i < 13; i++) A.uhist_out[i * PM + tid] = old[i];
+    }
 }
 
 // first freqdem sample of every run w >= 1
@@ -249,10 +403,130 @@ int launch_pfb1024(const float2 *u_new, const float *taps, const float2 *tw, voi
     if (nruns > A.nb / 4) nruns = A.nb / 4;                    // at least 4 tiles per run
     if (nruns < 1) nruns = 1;
     A.nruns = nruns; A.yfirst = scratch; A.ylast = scratch + (size_t)nruns * PM;
-    if (fm) hipLaunchKernelGGL(k_pfb1024<true>, dim3(nruns), dim3(1024), 0, s, A);
-    else hipLaunchKernelGGL(k_pfb1024<false>, dim3(nruns), dim3(1024), 0, s, A);
+    if (fm) hipLaunchKernelGGL((k_pfb1024<true, false>), dim3(nruns), dim3(1024), 0, s, A);
+    else hipLaunchKernelGGL((k_pfb1024<false, false>), dim3(nruns), dim3(1024), 0, s, A);
     if (fm && nruns > 1) hipLaunchKernelGGL(k_pfb1024_fixup, dim3(nruns - 1), dim3(1024), 0, s, A);
     CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// k_run1024: the same kernel with the DC blocker and the NCO pre-mix fused in (DC = true) -- the whole chain of
+// assembleFold for -c 1024 in one launch per chunk, same call interface as the M = 256 / 64 run kernels (fused.h)
+// ---------------------------------------------------------------------------------------------
+struct BigPlan {
+    FusedConfig cfg;
+    uint32_t cus = 256;
+    uint64_t frames_done = 0;
+    float *d_taps = nullptr;
+    float2 *d_tw = nullptr, *d_wpre = nullptr;
+    float2 *d_uhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
+    float2 *d_scratch = nullptr;     // yfirst | ylast
+    void *d_premix = nullptr;
+    int cur = 0;
+};
+
+bool big_supported(uint32_t M, uint32_t p) { return M == (uint32_t)PM && p == (uint32_t)PP; }
+
+void big_destroy(BigPlan *p)
+{
+    if (!p) return;
+    void *ptrs[] = {p->d_taps, p->d_tw, p->d_wpre, p->d_uhist[0], p->d_uhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0], p->d_rp[1],
+                    p->d_scratch, p->d_premix};
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    delete p;
+}
+
+int big_create(const FusedConfig &cfg, BigPlan **out)
+{
+    BigPlan *p = new BigPlan();
+    p->cfg = cfg;
+    auto fail = [&](int r) { big_destroy(p); return r; };
+    {
+        int dev = 0, cus = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        p->cus = (uint32_t)cus;
+    }
+#define ALLOC(ptr, bytes) do { hipError_t e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 1); if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__)); } while (0)
+    ALLOC(p->d_taps, sizeof(float) * PM * PP);
+    ALLOC(p->d_tw, sizeof(float2) * PM);
+    ALLOC(p->d_wpre, sizeof(float2) * 2 * PM);
+    for (int i = 0; i < 2; i++) {
+        ALLOC(p->d_uhist[i], sizeof(float2) * 13 * PM);
+        ALLOC(p->d_vend[i], sizeof(float2));
+        ALLOC(p->d_rp[i], sizeof(float2) * cfg.C);
+    }
+    ALLOC(p->d_scratch, sizeof(float2) * 2 * (size_t)p->cus * PM);
+    if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
+#undef ALLOC
+    CSDR_HIP(hipMemcpy(p->d_taps, cfg.taps, sizeof(float) * PM * PP, hipMemcpyHostToDevice));
+    std::vector<float2> tw(PM), wpre(2 * PM);
+    for (int i = 0; i < PM; i++) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)i / (double)PM;
+        tw[i] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (uint32_t i = 0; i < 2 * (uint32_t)PM; i++) {           // the NCO phase sequence has period 2M for a power-of-two M
+        float c, sn;
+        nco_phasor(i * cfg.d_theta, &c, &sn);
+        wpre[i] = make_float2(c, -sn);
+    }
+    CSDR_HIP(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
+    CSDR_HIP(hipMemcpy(p->d_wpre, wpre.data(), sizeof(float2) * wpre.size(), hipMemcpyHostToDevice));
+    *out = p;
+    return 0;
+}
+
+int big_reset(BigPlan *p, hipStream_t s)
+{
+    p->cur = 0; p->frames_done = 0;
+    for (int i = 0; i < 2; i++) {
+        CSDR_HIP(hipMemsetAsync(p->d_uhist[i], 0, sizeof(float2) * 13 * PM, s));
+        CSDR_HIP(hipMemsetAsync(p->d_vend[i], 0, sizeof(float2), s));
+        CSDR_HIP(hipMemsetAsync(p->d_rp[i], 0, sizeof(float2) * p->cfg.C, s));
+    }
+    return 0;
+}
+
+void big_seek(BigPlan *p, uint64_t frames) { p->frames_done = frames; }
+const char *big_name(const BigPlan *p) { return p->cfg.fm ? "k_run1024<FM>" : "k_run1024<CF32>"; }
+
+int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *timer)
+{
+    const FusedConfig &c = p->cfg;
+    const uint32_t nf = call.nf;
+    if (!nf) return 0;
+    int r;
+    Pfb1024Args A{};
+    A.u = call.d_in; A.taps = p->d_taps; A.tw = p->d_tw; A.wpre = p->d_wpre;
+    A.out = c.mix ? p->d_premix : call.d_out;
+    A.rp_in = p->d_rp[p->cur]; A.rp_out = p->d_rp[p->cur ^ 1];
+    A.vend_in = p->d_vend[p->cur]; A.vend_out = p->d_vend[p->cur ^ 1];
+    A.uhist_in = p->d_uhist[p->cur]; A.uhist_out = p->d_uhist[p->cur ^ 1];
+    A.nf = nf; A.nb = (nf + PT - 1) / PT; A.c0 = c.c0; A.C = c.C; A.ref = c.fm_ref;
+    A.parity0 = (uint32_t)(p->frames_done & 1);
+    const double beta = c.dc_block ? (double)c.dc.beta : 0.0;
+    A.alpha = c.dc_block ? (float)(1.0 - beta) : 0.0f;
+    A.l2beta = c.dc_block ? (float)std::log2(beta) : -1000.0f;
+    for (int k = 0; k < 4; k++) { A.bp[k] = (float)std::pow(beta, (double)(1 << k)); A.dp[k] = (float)std::pow(beta, 16.0 * (1 << k)); }
+    A.dm = (float)std::pow(beta, 1024.0);
+    // one run per CU, at least 8 tiles per run (a run >= 1 spends 3 read-only + 2 halo tiles on its start state)
+    uint32_t nruns = p->cus;
+    if (nruns > A.nb / 8) nruns = A.nb / 8;
+    if (nruns < 1) nruns = 1;
+    A.nruns = nruns; A.yfirst = p->d_scratch; A.ylast = p->d_scratch + (size_t)nruns * PM;
+    if (timer && (r = timer->begin(s))) return r;
+    if (c.fm) hipLaunchKernelGGL((k_pfb1024<true, true>), dim3(nruns), dim3(1024), 0, s, A);
+    else hipLaunchKernelGGL((k_pfb1024<false, true>), dim3(nruns), dim3(1024), 0, s, A);
+    if (timer && (r = timer->end(s))) return r;
+    if (c.fm && nruns > 1) hipLaunchKernelGGL(k_pfb1024_fixup, dim3(nruns - 1), dim3(1024), 0, s, A);
+    CSDR_HIP(hipGetLastError());
+    p->cur ^= 1;
+    p->frames_done += nf;
+    if (c.mix) {
+        if ((r = launch_mix((const float *)p->d_premix, (float *)call.d_out, c.C, c.fm ? nf : 2 * nf, s))) return r;
+    }
     return 0;
 }
 

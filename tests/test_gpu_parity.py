@@ -919,22 +919,29 @@ def test_pfb1024_fused_kernel_matches_three_kernel_route_and_oracle(demod, agc, 
     route (CSDR_NO_PFB1024) on ragged chunks, and against the oracle.  Same arithmetic per output sample (FIR tap order,
     DFT index scheme, freqdem routine): CF32 agrees to rounding of the FMA grouping, FM modulo 1/kf."""
     M = 1024
-    frames = [64, 8, 37, 200, 3, 128]
+    frames = [64, 8, 37, 200, 3, 128, 1000]              # the last one is long enough for runs with warm-up and halo tiles
     nf = sum(frames)
     x = synth_cf32(M * nf, M, seed=31)
     kw = dict(channels=M, demod=demod, kf=0.3, agc=agc, max_frames=max(frames))
     if shard:
         kw.update(chan_first=shard[0], chan_count=shard[1])
-    a = cs.Chain(**kw)
+    a = cs.Chain(**kw)                                   # k_run1024: DC blocker + pre-mix + FIR + DFT + tail in one kernel
+    monkeypatch.setenv("CSDR_NO_RUN1024", "1")
+    a2 = cs.Chain(**kw)                                  # k_dc_tile + k_pfb1024
     monkeypatch.setenv("CSDR_NO_PFB1024", "1")
-    b = cs.Chain(**kw)
+    b = cs.Chain(**kw)                                   # k_dc_tile + k_pfb_fir + k_fft_r16 + k_transpose(_fm)
     monkeypatch.delenv("CSDR_NO_PFB1024")
+    monkeypatch.delenv("CSDR_NO_RUN1024")
+    assert "k_run1024" in a.path and "pfb1024" in a2.path and "pfb1024" not in b.path and "run1024" not in b.path
     orc = O.Chain(M, demod=demod, kf=0.3, agc_db=agc) if not shard else O.Chain(M, demod=demod, kf=0.3)
-    ga, gb, wo, pos = [], [], [], 0
+    ga, ga2, gb, wo, pos = [], [], [], [], 0
     for f in frames:
         xa = x[pos * M:(pos + f) * M]
-        ga.append(a.process(xa)); gb.append(b.process(xa)); wo.append(orc.process(xa)); pos += f
-    ga, gb, wo = np.concatenate(ga, axis=1), np.concatenate(gb, axis=1), np.concatenate(wo, axis=1)
+        ga.append(a.process(xa)); ga2.append(a2.process(xa)); gb.append(b.process(xa)); wo.append(orc.process(xa)); pos += f
+    ga, ga2, gb, wo = [np.concatenate(v, axis=1) for v in (ga, ga2, gb, wo)]
+    # the back half alone (same DC kernel in front) reproduces the three-kernel route bit for bit
+    if not agc:
+        assert np.array_equal(ga2.view(np.uint32), gb.view(np.uint32))
     if shard:
         wo = wo[shard[0]:shard[0] + shard[1]]
     assert ga.shape == gb.shape == wo.shape
@@ -950,5 +957,5 @@ def test_pfb1024_fused_kernel_matches_three_kernel_route_and_oracle(demod, agc, 
             assert int(np.sum((ga == 0) != (gb == 0))) <= 2 * M
             assert np.median(d1) < 2e-5 and np.median(d2) < 2e-5
         else:
-            assert np.median(d1) < 1e-6 and np.quantile(d1[1::4], 0.999) < 2e-5 and np.median(d2) < 2e-5
-    a.close(); b.close()
+            assert np.median(d1) < 2e-6 and np.quantile(d1[1::4], 0.999) < 2e-5 and np.median(d2) < 2e-5
+    a.close(); a2.close(); b.close()
