@@ -144,10 +144,13 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
         if (DC) {
             // ---- DC blocker (zero-state part) on the column-layout registers: in-run scans by DPP, run totals to LDS ----
             float2 *TR = bufA, *E = bufA + 512;
+            // the DPP operands must be VGPRs; materialise them inside the iteration (hoisted they get spilled)
+            float b1 = A.bp[0], b2 = A.bp[1], b4 = A.bp[2], b8 = A.bp[3], na = -A.alpha;
+            asm volatile("" : "+v"(b1), "+v"(b2), "+v"(b4), "+v"(b8), "+v"(na));
 #pragma unroll
             for (int f = 0; f < PT; f += 2) {
                 float s0, s1, s2, s3;
-                row_scan4(nw[f].x, nw[f].y, nw[f + 1].x, nw[f + 1].y, s0, s1, s2, s3, A.bp[0], A.bp[1], A.bp[2], A.bp[3], -A.alpha);
+                row_scan4(nw[f].x, nw[f].y, nw[f + 1].x, nw[f + 1].y, s0, s1, s2, s3, b1, b2, b4, b8, na);
                 if ((tid_i & 15) == 15) {
                     TR[64 * f + (tid_i >> 4)] = make_float2(s0, s1);
                     TR[64 * (f + 1) + (tid_i >> 4)] = make_float2(s2, s3);
