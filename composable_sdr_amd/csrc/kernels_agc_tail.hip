@@ -56,11 +56,17 @@ __device__ __forceinline__ float2 agc_tail_step(float2 x, AgcSeg &q, const AgcPa
     q.g = fminf(q.g, 1e6f);
     const bool ex = q.g < p.g_thr;                    // rssi > threshold
     const uint32_t S = (uint32_t)q.mode;              // AgcSeg.mode carries S inside this file
-    uint32_t t = __builtin_amdgcn_ubfe(ex ? S_TEX : S_TNO, 3u * S, 3u);
-    t = (t == 5u) ? 8u + p.timeout : t;
-    const uint32_t r9 = (ex && S >= 10u) ? 3u : S - 1u;
-    const uint32_t Sn = (S >= 9u) ? r9 : t;
-    q.mode = (int32_t)Sn;
+    // most samples leave the squelch where it is (SIGNALHI with the threshold exceeded, ENABLED without): when that
+    // holds for the whole wave the transition tables are skipped
+    const bool steady = (S == 3u && ex) || (S == 1u && !ex);
+    uint32_t Sn = S;
+    if (__builtin_amdgcn_ballot_w64(!steady) != 0ull) {
+        uint32_t t = __builtin_amdgcn_ubfe(ex ? S_TEX : S_TNO, 3u * S, 3u);
+        t = (t == 5u) ? 8u + p.timeout : t;
+        const uint32_t r9 = (ex && S >= 10u) ? 3u : S - 1u;
+        Sn = (S >= 9u) ? r9 : t;
+        q.mode = (int32_t)Sn;
+    }
     if (Sn != 3u) y = make_float2(0.f, 0.f);          // reference mute rule (Liquid.chs:703-704)
     return y;
 }
