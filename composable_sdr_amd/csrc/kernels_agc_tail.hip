@@ -119,109 +119,122 @@ __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, Agc
     else { oa = make_float4(y[0].x, y[0].y, y[1].x, y[1].y); ob = make_float4(y[2].x, y[2].y, y[3].x, y[3].y); }
 }
 
-// One lane per (channel, segment); 64 streams per wave.  Each block of 16 samples goes
+// One lane per NS (channel, segment) streams; a wave owns 64 * NS consecutive segments of ONE channel (grid = channels x
+// segment groups), so every address is the uniform row plus a lane-derived segment.  Each block of 16 samples goes
 //   global --(8 lanes per 128-byte line)--> registers --> LDS (one line per stream) --> its lane, four samples at a
-//   time; the outputs are written back over the stream's own consumed input pieces and leave the same
-//   cooperative way.  8 KiB of LDS and ~100 VGPRs per wave: the dependent AGC chain (~14 VALU + log2 + exp2 per
-//   sample) needs many waves per SIMD, not a fat one.
-template <bool FM>
-__global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A)   // <= 128 VGPRs: 4 waves per SIMD
+//   time; the outputs are written back over the stream's own consumed input pieces and leave the same cooperative
+//   way.  The dependent AGC chain (~14 VALU + log2 + exp2 per sample) leaves a wave stalled most of the time
+//   (VALU 37 % busy at 2.7 waves per SIMD, waits on memory 3 %); NS = 2 lets a lane interleave two independent streams,
+//   but measured slower than NS = 1 with more waves (CSDR_AGC_NS), so NS = 1 is what runs.
+template <bool FM, int NS>
+__global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A, uint32_t groups)   // <= 128 VGPRs: 4 waves per SIMD
 {
-    __shared__ float4 buf[64 * 8];
+    __shared__ float4 buf[NS][64 * 8];
     const int lane = threadIdx.x;
-    const uint32_t total = A.C * A.nseg;
-    const uint32_t gid0 = blockIdx.x * 64u;
-    const uint32_t gid = gid0 + lane;
-    const bool mine = gid < total;
-    const uint32_t c = mine ? gid / A.nseg : 0, sg = mine ? gid % A.nseg : 0;
-    const uint32_t start = sg * A.L, end = mine ? min(A.nf, start + A.L) : 0u;
-    const int32_t t00 = (int32_t)start - (int32_t)A.W;          // first sample of block 0 (may be negative)
+    const uint32_t c = blockIdx.x / groups, sbase = (blockIdx.x % groups) * 64u * NS;   // uniform: channel, first segment
+    const size_t row = (size_t)c * A.nf;
     const uint32_t nblk = (A.W + A.L) / 16u, kreal = A.W / 16u;
-
-    // helper streams of this lane: instruction m of a cooperative access handles stream 8m + (lane >> 3):
-    // row offset (in samples) and segment start of each; hseg = 0xffffffff: no such stream
-    uint32_t hrow[8], hseg[8];
-#pragma unroll
-    for (int m = 0; m < 8; m++) {
-        const uint32_t g = gid0 + 8 * m + (lane >> 3);
-        const bool ok = g < total;
-        const uint32_t cc = ok ? g / A.nseg : 0, ss = ok ? g % A.nseg : 0;
-        hrow[m] = cc * A.nf;                                   // C*nf < 2^32 samples (checked on the host)
-        hseg[m] = ok ? ss * A.L : 0xffffffffu;
-    }
     const int pc = lane & 7;
 
-    AgcSeg q;
-    {
-        const AgcState s0 = A.st_in[c];
-        q.g = s0.g; q.y2 = s0.y2; q.mode = (int32_t)s_encode(s0.mode, s0.timer); q.timer = 0;
-        const float2 r0 = FM ? A.rp_in[c] : make_float2(0.f, 0.f);
-        q.rx = r0.x; q.ry = r0.y; q.pad0 = q.pad1 = 0;
-    }
-
-    float4 ld[8];
-    auto coop_load = [&](uint32_t k) {
+    AgcSeg q[NS];
+    uint32_t sg[NS], endv[NS];
+    bool mine[NS];
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hseg[m] != 0xffffffffu) {
-                const int32_t t = (int32_t)hseg[m] - (int32_t)A.W + (int32_t)(16 * k) + 2 * pc;     // first of the piece's two samples
-                const uint32_t e = min(A.nf, hseg[m] + A.L);
-                if (t >= 0 && (uint32_t)t + 1 < e) {
-                    const size_t idx = (size_t)hrow[m] + (uint32_t)t;
-                    const float2 *ptr = A.Z + idx;
-                    if ((idx & 1) == 0) v = *reinterpret_cast<const float4 *>(ptr);
-                    else { const float2 a = ptr[0], b = ptr[1]; v = make_float4(a.x, a.y, b.x, b.y); }
-                } else if (t >= 0 && (uint32_t)t < e) {
-                    const float2 a = A.Z[(size_t)hrow[m] + (uint32_t)t];
-                    v = make_float4(a.x, a.y, 0.f, 0.f);
-                }
-            }
-            ld[m] = v;
-        }
-    };
+    for (int u = 0; u < NS; u++) {
+        sg[u] = sbase + 64u * u + lane;
+        mine[u] = sg[u] < A.nseg;
+        endv[u] = mine[u] ? min(A.nf, sg[u] * A.L + A.L) : 0u;
+        const AgcState s0 = A.st_in[c];
+        q[u].g = s0.g; q[u].y2 = s0.y2; q[u].mode = (int32_t)s_encode(s0.mode, s0.timer); q[u].timer = 0;
+        const float2 r0 = FM ? A.rp_in[c] : make_float2(0.f, 0.f);
+        q[u].rx = r0.x; q[u].ry = r0.y; q[u].pad0 = q[u].pad1 = 0;
+    }
 
     for (uint32_t k = 0; k < nblk; k++) {
         // no software prefetch: the loaded lines would pin 32 VGPRs through the whole block; the other waves of the
         // SIMD cover the load latency instead
-        coop_load(k);
-        __syncthreads();                                        // previous block's buffer consumed
+        __syncthreads();                                        // previous block's buffers consumed
 #pragma unroll
-        for (int m = 0; m < 8; m++) buf[slot8(8 * m + (lane >> 3), pc)] = ld[m];
+        for (int u = 0; u < NS; u++) {
+            float4 ld[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                // instruction m of the cooperative access handles stream 8m + (lane >> 3) of set u
+                const uint32_t ss = sbase + 64u * u + 8 * m + (lane >> 3);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ss < A.nseg) {
+                    const int32_t t = (int32_t)(ss * A.L) - (int32_t)A.W + (int32_t)(16 * k) + 2 * pc;   // first of the piece's two samples
+                    const uint32_t e = min(A.nf, ss * A.L + A.L);
+                    if (t >= 0 && (uint32_t)t + 1 < e) {
+                        const size_t idx = row + (uint32_t)t;
+                        const float2 *ptr = A.Z + idx;
+                        if ((idx & 1) == 0) v = *reinterpret_cast<const float4 *>(ptr);
+                        else { const float2 a = ptr[0], b = ptr[1]; v = make_float4(a.x, a.y, b.x, b.y); }
+                    } else if (t >= 0 && (uint32_t)t < e) {
+                        const float2 a = A.Z[row + (uint32_t)t];
+                        v = make_float4(a.x, a.y, 0.f, 0.f);
+                    }
+                }
+                ld[m] = v;
+            }
+#pragma unroll
+            for (int m = 0; m < 8; m++) buf[u][slot8(8 * m + (lane >> 3), pc)] = ld[m];
+        }
         __syncthreads();
 
-        const int32_t t0 = t00 + (int32_t)(16 * k);
-        if (mine && k == kreal) A.seg_start[gid] = q;           // state at the segment start, after the warm-up
-        const bool live = t0 >= 0 && (uint32_t)t0 < end;
-        const bool full = (uint32_t)t0 + 16 <= end;
-        if (live && k < kreal) {
+        int32_t t0[NS];
+        bool live[NS], full = true, anylive = false;
+#pragma unroll
+        for (int u = 0; u < NS; u++) {
+            t0[u] = (int32_t)(sg[u] * A.L) - (int32_t)A.W + (int32_t)(16 * k);
+            if (mine[u] && k == kreal) A.seg_start[(size_t)c * A.nseg + sg[u]] = q[u];   // state at the segment start, after the warm-up
+            live[u] = t0[u] >= 0 && (uint32_t)t0[u] < endv[u];
+            full = full && (!live[u] || (uint32_t)t0[u] + 16 <= endv[u]);
+            anylive = anylive || live[u];
+        }
+        if (anylive && k < kreal) {
             // warm-up block (always whole): only the state matters -- no freqdem, nothing stored
 #pragma unroll 1
             for (int h = 0; h < 4; h++) {
-                const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
-                float4 oa, ob;
-                agc_quad<false, false>(va, vb, q, A.p, A.ref, 0u, 0u, oa, ob);
-                if (FM) { q.rx = ob.z; q.ry = ob.w; }           // r' = the last (possibly muted) AGC output
+#pragma unroll
+                for (int u = 0; u < NS; u++) {
+                    if (live[u]) {
+                        const float4 va = buf[u][slot8(lane, 2 * h)], vb = buf[u][slot8(lane, 2 * h + 1)];
+                        float4 oa, ob;
+                        agc_quad<false, false>(va, vb, q[u], A.p, A.ref, 0u, 0u, oa, ob);
+                        if (FM) { q[u].rx = ob.z; q[u].ry = ob.w; }     // r' = the last (possibly muted) AGC output
+                    }
+                }
             }
-        } else if (live) {
+        } else if (anylive) {
             if (full) {
 #pragma unroll 1
                 for (int h = 0; h < 4; h++) {
-                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
-                    float4 oa, ob;
-                    agc_quad<FM, false>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, end, oa, ob);
-                    // in place: output piece h (F32) / pieces 2h, 2h+1 (CF32) over input pieces already consumed
-                    if (FM) buf[slot8(lane, h)] = oa;
-                    else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
+#pragma unroll
+                    for (int u = 0; u < NS; u++) {
+                        if (live[u]) {
+                            const float4 va = buf[u][slot8(lane, 2 * h)], vb = buf[u][slot8(lane, 2 * h + 1)];
+                            float4 oa, ob;
+                            agc_quad<FM, false>(va, vb, q[u], A.p, A.ref, (uint32_t)t0[u] + 4 * h, endv[u], oa, ob);
+                            // in place: output piece h (F32) / pieces 2h, 2h+1 (CF32) over input pieces already consumed
+                            if (FM) buf[u][slot8(lane, h)] = oa;
+                            else { buf[u][slot8(lane, 2 * h)] = oa; buf[u][slot8(lane, 2 * h + 1)] = ob; }
+                        }
+                    }
                 }
             } else {
 #pragma unroll 1
                 for (int h = 0; h < 4; h++) {
-                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
-                    float4 oa, ob;
-                    agc_quad<FM, true>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, end, oa, ob);
-                    if (FM) buf[slot8(lane, h)] = oa;
-                    else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
+#pragma unroll
+                    for (int u = 0; u < NS; u++) {
+                        if (live[u]) {
+                            const float4 va = buf[u][slot8(lane, 2 * h)], vb = buf[u][slot8(lane, 2 * h + 1)];
+                            float4 oa, ob;
+                            agc_quad<FM, true>(va, vb, q[u], A.p, A.ref, (uint32_t)t0[u] + 4 * h, endv[u], oa, ob);
+                            if (FM) buf[u][slot8(lane, h)] = oa;
+                            else { buf[u][slot8(lane, 2 * h)] = oa; buf[u][slot8(lane, 2 * h + 1)] = ob; }
+                        }
+                    }
                 }
             }
         }
@@ -229,47 +242,51 @@ __global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A)   // <= 128 VGPR
             // outputs leave as whole lines
             __syncthreads();
             const uint32_t tb = 16 * (k - kreal);
-            if (FM) {
-                float *outp = (float *)A.out;
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
-                    const int j = 16 * m + (lane >> 2), p4 = lane & 3;
-                    const uint32_t g = gid0 + j;
-                    if (g < total) {
-                        const uint32_t cc = g / A.nseg, ss = g - cc * A.nseg;
-                        const uint32_t t = ss * A.L + tb + 4 * p4, e = min(A.nf, ss * A.L + A.L);
-                        const float4 v = buf[slot8(j, p4)];
-                        const size_t idx = (size_t)cc * A.nf + t;
-                        float *dst = outp + idx;
-                        if (t + 4 <= e && (idx & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
-                        else {
-                            if (t < e) dst[0] = v.x;
-                            if (t + 1 < e) dst[1] = v.y;
-                            if (t + 2 < e) dst[2] = v.z;
-                            if (t + 3 < e) dst[3] = v.w;
+            for (int u = 0; u < NS; u++) {
+                if (FM) {
+                    float *outp = (float *)A.out;
+#pragma unroll
+                    for (int m = 0; m < 4; m++) {
+                        const int j = 16 * m + (lane >> 2), p4 = lane & 3;
+                        const uint32_t ss = sbase + 64u * u + j;
+                        if (ss < A.nseg) {
+                            const uint32_t t = ss * A.L + tb + 4 * p4, e = min(A.nf, ss * A.L + A.L);
+                            const float4 v = buf[u][slot8(j, p4)];
+                            const size_t idx = row + t;
+                            float *dst = outp + idx;
+                            if (t + 4 <= e && (idx & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
+                            else {
+                                if (t < e) dst[0] = v.x;
+                                if (t + 1 < e) dst[1] = v.y;
+                                if (t + 2 < e) dst[2] = v.z;
+                                if (t + 3 < e) dst[3] = v.w;
+                            }
                         }
                     }
-                }
-            } else {
-                float2 *outp = (float2 *)A.out;
+                } else {
+                    float2 *outp = (float2 *)A.out;
 #pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    if (hseg[m] != 0xffffffffu) {
-                        const uint32_t t = hseg[m] + tb + 2 * pc, e = min(A.nf, hseg[m] + A.L);
-                        const float4 v = buf[slot8(8 * m + (lane >> 3), pc)];
-                        const size_t idx = (size_t)hrow[m] + t;
-                        float2 *dst = outp + idx;
-                        if (t + 2 <= e && (idx & 1) == 0) *reinterpret_cast<float4 *>(dst) = v;
-                        else {
-                            if (t < e) dst[0] = make_float2(v.x, v.y);
-                            if (t + 1 < e) dst[1] = make_float2(v.z, v.w);
+                    for (int m = 0; m < 8; m++) {
+                        const uint32_t ss = sbase + 64u * u + 8 * m + (lane >> 3);
+                        if (ss < A.nseg) {
+                            const uint32_t t = ss * A.L + tb + 2 * pc, e = min(A.nf, ss * A.L + A.L);
+                            const float4 v = buf[u][slot8(8 * m + (lane >> 3), pc)];
+                            const size_t idx = row + t;
+                            float2 *dst = outp + idx;
+                            if (t + 2 <= e && (idx & 1) == 0) *reinterpret_cast<float4 *>(dst) = v;
+                            else {
+                                if (t < e) dst[0] = make_float2(v.x, v.y);
+                                if (t + 1 < e) dst[1] = make_float2(v.z, v.w);
+                            }
                         }
                     }
                 }
             }
         }
     }
-    if (mine) A.seg_end[gid] = q;
+#pragma unroll
+    for (int u = 0; u < NS; u++) if (mine[u]) A.seg_end[(size_t)c * A.nseg + sg[u]] = q[u];
 }
 
 // verification + exact fall-back, one wave per channel.  All boundaries are checked in parallel against the
@@ -383,10 +400,18 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     TailArgs A{};
     A.Z = Z; A.out = out; A.st_in = st; A.rp_in = rp_in; A.seg_start = p->d_start; A.seg_end = p->d_end;
     A.C = p->C; A.nf = nf; A.L = L; A.W = p->W; A.nseg = nseg; A.p = prm; A.ref = fm_ref;
-    const uint32_t total = p->C * nseg;
-    const dim3 grid((total + 63) / 64), block(64);
-    if (fm) hipLaunchKernelGGL(k_agc_spec<true>, grid, block, 0, s, A);
-    else hipLaunchKernelGGL(k_agc_spec<false>, grid, block, 0, s, A);
+    // streams per lane: 2 was measured slower (1.53 vs 1.04 ms per 67 M samples: fewer waves, no gain from the second chain)
+    static const int ns_env = getenv("CSDR_AGC_NS") ? atoi(getenv("CSDR_AGC_NS")) : 1;
+    const uint32_t NS = ns_env == 2 ? 2u : 1u;
+    const uint32_t groups = (nseg + 64 * NS - 1) / (64 * NS);
+    const dim3 grid(p->C * groups), block(64);
+    if (NS == 1) {
+        if (fm) hipLaunchKernelGGL((k_agc_spec<true, 1>), grid, block, 0, s, A, groups);
+        else hipLaunchKernelGGL((k_agc_spec<false, 1>), grid, block, 0, s, A, groups);
+    } else {
+        if (fm) hipLaunchKernelGGL((k_agc_spec<true, 2>), grid, block, 0, s, A, groups);
+        else hipLaunchKernelGGL((k_agc_spec<false, 2>), grid, block, 0, s, A, groups);
+    }
     // the fix-up reads st_in through the segment records only, so st can be overwritten in place
     if (fm) hipLaunchKernelGGL(k_agc_fix<true>, dim3(p->C), dim3(64), 0, s, A, st, rp_out, p->d_stats);
     else hipLaunchKernelGGL(k_agc_fix<false>, dim3(p->C), dim3(64), 0, s, A, st, rp_out, p->d_stats);
