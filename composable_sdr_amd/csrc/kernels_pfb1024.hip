@@ -49,6 +49,7 @@ struct Pfb1024Args {
     float bp[4];                // beta^1, ^2, ^4, ^8       (in-run DPP scan)
     float dp[4];                // beta^16, ^32, ^64, ^128   (scan over the 64 runs of a frame, row part)
     float dm;                   // beta^1024                 (frame to frame)
+    PhaseK pk;                  // ref-scaled atan2 polynomial of the run kernels (k_run1024's freqdem)
 };
 
 template <int NV> __device__ __forceinline__ void shift_window_n(float2 (&old)[13], const float2 (&nw)[PT])
@@ -141,6 +142,13 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
         const int j_i = tid_i;
         const uint32_t t0 = b * PT;
         const int nvalid = (int)min((uint32_t)PT, A.nf - t0);
+        // the 14 taps (and the two pre-mix phasors) are re-read per tile (L2-resident; held across the tile loop they
+        // would spill): issued first, so that their latency hides behind the DC stage
+        float h[PP];
+#pragma unroll
+        for (int n = 0; n < PP; n++) h[n] = A.taps[(PM - 1 - j_i) + n * PM];
+        float2 Wa = make_float2(1.f, 0.f), Wb = Wa;
+        if (DC) { Wa = A.wpre[(A.parity0 & 1) * PM + j_i]; Wb = A.wpre[((A.parity0 & 1) ^ 1) * PM + j_i]; }
         if (DC) {
             // ---- DC blocker (zero-state part) on the column-layout registers: in-run scans by DPP, run totals to LDS ----
             float2 *TR = bufA, *E = bufA + 512;
@@ -200,7 +208,6 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
             // ---- finish the DC blocker, apply the NCO pre-mix ----
             {
                 const float kj = -A.alpha * exp2f(A.l2beta * (float)(tid_i & 15));
-                const float2 Wa = A.wpre[(A.parity0 & 1) * PM + j_i], Wb = A.wpre[((A.parity0 & 1) ^ 1) * PM + j_i];
 #pragma unroll
                 for (int f = 0; f < PT; f++) {
                     const float2 y = cfma(E[64 * f + (j_i >> 4)], kj, nw[f]);
@@ -220,11 +227,7 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
             __syncthreads();                                        // E consumed before the next tile's run totals
             continue;
         }
-        // ---- polyphase FIR, oldest tap first; four frames at a time (independent accumulators).  The 14 taps are
-        // re-read per tile (L2-resident, 56 KiB for the whole bank): held across the tile loop they would spill ----
-        float h[PP];
-#pragma unroll
-        for (int n = 0; n < PP; n++) h[n] = A.taps[(PM - 1 - j_i) + n * PM];
+        // ---- polyphase FIR, oldest tap first; four frames at a time (independent accumulators) ----
 #pragma unroll
         for (int f0 = 0; f0 < PT; f0 += 4) {
             v2fg acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
@@ -323,7 +326,11 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
                     const int nv = nvalid - g;
                     float m[4];
 #pragma unroll
-                    for (int f = 0; f < 4; f++) m[f] = fm_sample_rn(f ? y[f - 1] : prev, y[f], A.ref);
+                    for (int f = 0; f < 4; f++) {
+                        const float2 rp = f ? y[f - 1] : prev, r = y[f];
+                        // k_pfb1024 keeps the any-M route's routine (bit-identical outputs); k_run1024 the run kernels' lean one
+                        m[f] = DC ? scaled_atan2f(fmaf(rp.x, r.y, -(rp.y * r.x)), fmaf(rp.x, r.x, rp.y * r.y), A.pk) : fm_sample_rn(rp, r, A.ref);
+                    }
 #pragma unroll
                     for (int f = 0; f < 4; f++) if (f < nv) prev = y[f];
                     if (vec) {
@@ -514,6 +521,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     A.l2beta = c.dc_block ? (float)std::log2(beta) : -1000.0f;
     for (int k = 0; k < 4; k++) { A.bp[k] = (float)std::pow(beta, (double)(1 << k)); A.dp[k] = (float)std::pow(beta, 16.0 * (1 << k)); }
     A.dm = (float)std::pow(beta, 1024.0);
+    A.pk = phase_consts(c.fm_ref);
     // one run per CU, at least 8 tiles per run (a run >= 1 spends 3 read-only + 2 halo tiles on its start state)
     uint32_t nruns = p->cus;
     if (nruns > A.nb / 8) nruns = A.nb / 8;
