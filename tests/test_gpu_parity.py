@@ -959,3 +959,89 @@ def test_pfb1024_fused_kernel_matches_three_kernel_route_and_oracle(demod, agc, 
         else:
             assert np.median(d1) < 2e-6 and np.quantile(d1[1::4], 0.999) < 2e-5 and np.median(d2) < 2e-5
     a.close(); a2.close(); b.close()
+
+
+# --------------------------------------------------------------------------- full-size properties of the cfg4 / cfg5 shapes
+
+
+def test_full_size_cfg4_shape_1024ch_fm_properties(monkeypatch):
+    """configs[3] shape on one GPU (1024 ch, 65 536 frames = 67 M samples per chunk, k_run1024):
+    (1) one chunk == 8 chunks (DC state, FIR window, freqdem r' and the run splits carry over),
+    (2) the fused kernel agrees with the four-kernel any-M route on the whole chunk,
+    (3) a tone at a channel centre lands in that channel only (>= 75 dB), gain ~ M."""
+    import torch
+    from synth import channel_centre, synth_cf32_torch
+    M, nf = 1024, 65536
+    dev = torch.device("cuda", 0)
+    x = synth_cf32_torch(M * nf, M, dev, seed=5)
+
+    def run(xx, demod, parts=1):
+        ch = cs.Chain(channels=M, demod=demod, max_frames=nf // parts)
+        width = 1 if demod == "fm" else 2
+        outs = []
+        for i in range(parts):
+            o = torch.empty(M * (nf // parts) * width, dtype=torch.float32, device=dev)
+            ch.process_device(xx.data_ptr() + i * (M * nf // parts) * 8, M * nf // parts, o.data_ptr(), 0)
+            outs.append(o.view(M, nf // parts, width))
+        torch.cuda.synchronize()
+        path = ch.path
+        ch.close()
+        return torch.cat(outs, dim=1), path
+
+    one, path = run(x, "fm")
+    assert "k_run1024" in path
+    many, _ = run(x, "fm", parts=8)
+    d = (torch.remainder(one - many + 0.5 / 0.3, 1 / 0.3) - 0.5 / 0.3).abs().view(M, nf)
+    tone = torch.arange(M, device=dev) % 4 == 1
+    print("cfg4 shape one-vs-8 chunks FM: tone-channel max", float(d[tone].max()), "median all", float(d.median()))
+    assert float(d[tone].max()) < 1e-5 and float(d.median()) < 5e-6
+    monkeypatch.setenv("CSDR_NO_RUN1024", "1")
+    monkeypatch.setenv("CSDR_NO_PFB1024", "1")
+    gen, gpath = run(x, "fm")
+    monkeypatch.delenv("CSDR_NO_RUN1024"); monkeypatch.delenv("CSDR_NO_PFB1024")
+    assert "generic" in gpath and "pfb1024" not in gpath
+    d = (torch.remainder(one - gen + 0.5 / 0.3, 1 / 0.3) - 0.5 / 0.3).abs().view(M, nf)
+    print("cfg4 shape fused-vs-generic FM: tone-channel max", float(d[tone].max()), "median all", float(d.median()))
+    assert float(d[tone].max()) < 1e-5 and float(d.median()) < 5e-6
+    del one, many, gen, d
+
+    k = 531
+    n = torch.arange(M * nf, device=dev, dtype=torch.float64)
+    ph = torch.remainder(channel_centre(k, M) * n, 2 * np.pi).to(torch.float32)
+    tone_x = torch.stack([torch.cos(ph), torch.sin(ph)], dim=1).contiguous()
+    del n, ph
+    yt, _ = run(tone_x, "none")
+    p = torch.sqrt((yt[:, 100:, :] ** 2).sum(-1)).mean(1)
+    others = torch.cat([p[:k], p[k + 1:]])
+    iso = 20 * torch.log10(p[k] / (others.max() + 1e-30))
+    print("cfg4 shape tone: channel", int(p.argmax()), "isolation dB", float(iso), "gain/M", float(p[k]) / M)
+    assert int(p.argmax()) == k and float(iso) > 75 and abs(float(p[k]) / M - 1) < 0.02
+
+
+def test_full_size_cfg5_shape_4096ch_mix_linearity():
+    """configs[4] shape on one GPU (4096 ch, 16 384 frames, DeNo --mix, sum inside the DFT kernel): the mixed output is
+    linear in the input and chunk-invariant."""
+    import torch
+    from synth import synth_cf32_torch
+    M, nf = 4096, 16384
+    dev = torch.device("cuda", 0)
+    x1 = synth_cf32_torch(M * nf, M, dev, seed=7)
+    x2 = synth_cf32_torch(M * nf, M, dev, seed=8)
+
+    def run(xx, parts=1):
+        ch = cs.Chain(channels=M, demod="none", mix=True, max_frames=nf // parts)
+        outs = []
+        for i in range(parts):
+            o = torch.empty((nf // parts) * 2, dtype=torch.float32, device=dev)
+            ch.process_device(xx.data_ptr() + i * (M * nf // parts) * 8, M * nf // parts, o.data_ptr(), 0)
+            outs.append(o)
+        torch.cuda.synchronize()
+        ch.close()
+        return torch.cat(outs)
+
+    y1, y2, y12 = run(x1), run(x2), run(x1 + 2 * x2)
+    scale = float(y12.abs().max())
+    err = float((y12 - (y1 + 2 * y2)).abs().max())
+    inv = float((run(x1, parts=4) - y1).abs().max())
+    print("cfg5 shape mix: linearity err", err, "chunk-invariance err", inv, "of", scale)
+    assert err < 1e-4 * scale and inv < 1e-4 * scale
