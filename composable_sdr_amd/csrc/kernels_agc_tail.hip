@@ -23,6 +23,12 @@
 #include "csdr_internal.h"
 #include "fm_common.h"
 #include <cstdlib>
+#ifndef CSDR_AGC_PREFETCH
+#define CSDR_AGC_PREFETCH 0
+#endif
+#ifndef CSDR_AGC_ABLATE
+#define CSDR_AGC_ABLATE 0      // timing experiments only: 1 no log/exp, 2 every block reloads the same (cached) lines, 4 no stores
+#endif
 
 namespace csdr {
 
@@ -51,7 +57,7 @@ __device__ __forceinline__ float2 agc_tail_step(float2 x, AgcSeg &q, const AgcPa
     float2 y = make_float2(x.x * q.g, x.y * q.g);
     const float y2 = fmaf(y.x, y.x, y.y * y.y);          // explicit: must round the same in every kernel
     q.y2 = fmaf(1.0f - p.alpha, q.y2, p.alpha * y2);
-    const float upd = __builtin_amdgcn_exp2f((-0.5f * p.alpha) * __builtin_amdgcn_logf(q.y2));
+    const float upd = (CSDR_AGC_ABLATE & 1) ? 0.999f + 1e-3f * q.y2 : __builtin_amdgcn_exp2f((-0.5f * p.alpha) * __builtin_amdgcn_logf(q.y2));
     q.g = (q.y2 > 1e-6f) ? q.g * upd : q.g;
     q.g = fminf(q.g, 1e6f);
     const bool ex = q.g < p.g_thr;                    // rssi > threshold
@@ -126,7 +132,7 @@ __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, Agc
 //   way.  The dependent AGC chain (~14 VALU + log2 + exp2 per sample) leaves a wave stalled most of the time
 //   (VALU 37 % busy at 2.7 waves per SIMD, waits on memory 3 %); NS = 2 lets a lane interleave two independent streams,
 //   but measured slower than NS = 1 with more waves (CSDR_AGC_NS), so NS = 1 is what runs.
-template <bool FM, int NS>
+template <bool FM, int NS, bool PAIRS>
 __global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A, uint32_t groups)   // <= 128 VGPRs: 4 waves per SIMD
 {
     __shared__ float4 buf[NS][64 * 8];
@@ -150,37 +156,45 @@ __global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A, uint32_t groups)
         q[u].rx = r0.x; q[u].ry = r0.y; q[u].pad0 = q[u].pad1 = 0;
     }
 
+    // block k of set u: instruction m of the cooperative access handles stream 8m + (lane >> 3).  Branch-free (clamped
+    // address, invalid halves zeroed afterwards) so that the eight loads are in flight together: with a branch per
+    // load the compiler waits for each one before the next and the block pays eight memory latencies in a row.
+    const size_t total = (size_t)A.C * A.nf;
+    auto load_block = [&](uint32_t k, int u, float4 (&ld)[8]) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const uint32_t ss = sbase + 64u * u + 8 * m + (lane >> 3);
+            const int32_t t = (int32_t)(ss * A.L) - (int32_t)A.W + (int32_t)(16 * ((CSDR_AGC_ABLATE & 2) ? (k >= kreal ? kreal : 0u) : k)) + 2 * pc;   // first of the piece's two samples
+            const uint32_t e = min(A.nf, ss * A.L + A.L);
+            const bool ok0 = ss < A.nseg && t >= 0 && (uint32_t)t < e, ok1 = ss < A.nseg && t >= 0 && (uint32_t)t + 1 < e;
+            const size_t idx = row + (uint32_t)max(t, 0);
+            float4 v;
+            if (PAIRS) v = *reinterpret_cast<const float4 *>(A.Z + min(idx, total - 2));
+            else { const float2 a = A.Z[min(idx, total - 1)], b = A.Z[min(idx + 1, total - 1)]; v = make_float4(a.x, a.y, b.x, b.y); }
+            ld[m] = make_float4(ok0 ? v.x : 0.f, ok0 ? v.y : 0.f, ok1 ? v.z : 0.f, ok1 ? v.w : 0.f);
+        }
+    };
+
+    float4 ld[NS][8];
+    if (CSDR_AGC_PREFETCH) {
+#pragma unroll
+        for (int u = 0; u < NS; u++) load_block(0, u, ld[u]);
+    }
     for (uint32_t k = 0; k < nblk; k++) {
-        // no software prefetch: the loaded lines would pin 32 VGPRs through the whole block; the other waves of the
-        // SIMD cover the load latency instead
+        // CSDR_AGC_PREFETCH: block k + 1 is in flight (32 VGPRs) while block k is worked on; otherwise the other
+        // waves of the SIMD are what covers the load latency
         __syncthreads();                                        // previous block's buffers consumed
 #pragma unroll
         for (int u = 0; u < NS; u++) {
-            float4 ld[8];
+            if (!CSDR_AGC_PREFETCH) load_block(k, u, ld[u]);
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                // instruction m of the cooperative access handles stream 8m + (lane >> 3) of set u
-                const uint32_t ss = sbase + 64u * u + 8 * m + (lane >> 3);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ss < A.nseg) {
-                    const int32_t t = (int32_t)(ss * A.L) - (int32_t)A.W + (int32_t)(16 * k) + 2 * pc;   // first of the piece's two samples
-                    const uint32_t e = min(A.nf, ss * A.L + A.L);
-                    if (t >= 0 && (uint32_t)t + 1 < e) {
-                        const size_t idx = row + (uint32_t)t;
-                        const float2 *ptr = A.Z + idx;
-                        if ((idx & 1) == 0) v = *reinterpret_cast<const float4 *>(ptr);
-                        else { const float2 a = ptr[0], b = ptr[1]; v = make_float4(a.x, a.y, b.x, b.y); }
-                    } else if (t >= 0 && (uint32_t)t < e) {
-                        const float2 a = A.Z[row + (uint32_t)t];
-                        v = make_float4(a.x, a.y, 0.f, 0.f);
-                    }
-                }
-                ld[m] = v;
-            }
-#pragma unroll
-            for (int m = 0; m < 8; m++) buf[u][slot8(8 * m + (lane >> 3), pc)] = ld[m];
+            for (int m = 0; m < 8; m++) buf[u][slot8(8 * m + (lane >> 3), pc)] = ld[u][m];
         }
         __syncthreads();
+        if (CSDR_AGC_PREFETCH && k + 1 < nblk) {
+#pragma unroll
+            for (int u = 0; u < NS; u++) load_block(k + 1, u, ld[u]);
+        }
 
         int32_t t0[NS];
         bool live[NS], full = true, anylive = false;
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A, uint32_t groups)
                 }
             }
         }
-        if (k >= kreal) {
+        if (k >= kreal && !((CSDR_AGC_ABLATE & 4) && A.nf != 0xffffffffu)) {
             // outputs leave as whole lines
             __syncthreads();
             const uint32_t tb = 16 * (k - kreal);
@@ -400,17 +414,17 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     TailArgs A{};
     A.Z = Z; A.out = out; A.st_in = st; A.rp_in = rp_in; A.seg_start = p->d_start; A.seg_end = p->d_end;
     A.C = p->C; A.nf = nf; A.L = L; A.W = p->W; A.nseg = nseg; A.p = prm; A.ref = fm_ref;
-    // streams per lane: 2 was measured slower (1.53 vs 1.04 ms per 67 M samples: fewer waves, no gain from the second chain)
-    static const int ns_env = getenv("CSDR_AGC_NS") ? atoi(getenv("CSDR_AGC_NS")) : 1;
-    const uint32_t NS = ns_env == 2 ? 2u : 1u;
-    const uint32_t groups = (nseg + 64 * NS - 1) / (64 * NS);
+    // PAIRS: nf even, so every row starts on a 16-byte boundary and ends on one (t is always even): a piece is one
+    // 16-byte load that never reaches past the buffer
+    const bool pairs = (nf & 1u) == 0 && (uint64_t)p->C * nf >= 2;
+    const uint32_t groups = (nseg + 63u) / 64u;
     const dim3 grid(p->C * groups), block(64);
-    if (NS == 1) {
-        if (fm) hipLaunchKernelGGL((k_agc_spec<true, 1>), grid, block, 0, s, A, groups);
-        else hipLaunchKernelGGL((k_agc_spec<false, 1>), grid, block, 0, s, A, groups);
+    if (pairs) {
+        if (fm) hipLaunchKernelGGL((k_agc_spec<true, 1, true>), grid, block, 0, s, A, groups);
+        else hipLaunchKernelGGL((k_agc_spec<false, 1, true>), grid, block, 0, s, A, groups);
     } else {
-        if (fm) hipLaunchKernelGGL((k_agc_spec<true, 2>), grid, block, 0, s, A, groups);
-        else hipLaunchKernelGGL((k_agc_spec<false, 2>), grid, block, 0, s, A, groups);
+        if (fm) hipLaunchKernelGGL((k_agc_spec<true, 1, false>), grid, block, 0, s, A, groups);
+        else hipLaunchKernelGGL((k_agc_spec<false, 1, false>), grid, block, 0, s, A, groups);
     }
     // the fix-up reads st_in through the segment records only, so st can be overwritten in place
     if (fm) hipLaunchKernelGGL(k_agc_fix<true>, dim3(p->C), dim3(64), 0, s, A, st, rp_out, p->d_stats);
