@@ -28,13 +28,20 @@ __global__ __launch_bounds__(AM_T) void k_am(const float2 *__restrict__ Z, float
     const uint32_t c = blockIdx.y, chunk = blockIdx.x;
     const int64_t t0 = (int64_t)chunk * AM_REAL - AM_REAL;          // first staged sample (negative for chunk 0)
     const float2 *row = Z + (size_t)c * nf;
+    // clamped, unconditional loads first (all sixteen in flight), the range test afterwards: a load under a branch
+    // would be waited for on its own
+    float2 y[AM_PER];
+#pragma unroll
+    for (int i = 0; i < AM_PER; i++) {
+        const int64_t t = t0 + tid + AM_T * i;
+        y[i] = row[t < 0 ? 0 : (t < (int64_t)nf ? t : (int64_t)nf - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < AM_PER; i++) {
         const int s = tid + AM_T * i;
         const int64_t t = t0 + s;
-        float v = 0.f;
-        if (t >= 0 && t < (int64_t)nf) { const float2 y = row[t]; v = hypotf(y.x, y.y); }
-        ts[17 * (s >> 4) + (s & 15)] = v;
+        const float v = hypotf(y[i].x, y[i].y);
+        ts[17 * (s >> 4) + (s & 15)] = (t >= 0 && t < (int64_t)nf) ? v : 0.f;
     }
     __syncthreads();
     // zero-state scan of my 16 samples

@@ -350,7 +350,13 @@ __global__ __launch_bounds__(256) void k_fft_r16(const float2 *__restrict__ X, f
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int k2 = GXIDX(i);
-            if (k2 && n3) { const float2 w = tw[16 * n3 * k2]; v[i] = g_cmul(v[i], (v2fg){w.x, w.y}); }
+            if (k2) {
+                // unconditional load + select: a load under the lane-varying `n3 != 0` would be waited for on its
+                // own, fifteen round trips in a row (the n3 = 0 lanes keep their value untouched, as before)
+                const float2 w = tw[16 * n3 * k2];
+                const v2fg r = g_cmul(v[i], (v2fg){w.x, w.y});
+                v[i] = n3 ? r : v[i];
+            }
             bufB[fr * N + (k1 + 16 * k2) * R3 + n3] = make_float2(v[i].x, v[i].y);
         }
     }
