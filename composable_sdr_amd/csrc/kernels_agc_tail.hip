@@ -129,9 +129,8 @@ __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, Agc
 // segment groups), so every address is the uniform row plus a lane-derived segment.  Each block of 16 samples goes
 //   global --(8 lanes per 128-byte line)--> registers --> LDS (one line per stream) --> its lane, four samples at a
 //   time; the outputs are written back over the stream's own consumed input pieces and leave the same cooperative
-//   way.  The dependent AGC chain (~14 VALU + log2 + exp2 per sample) leaves a wave stalled most of the time
-//   (VALU 37 % busy at 2.7 waves per SIMD, waits on memory 3 %); NS = 2 lets a lane interleave two independent streams,
-//   but measured slower than NS = 1 with more waves (CSDR_AGC_NS), so NS = 1 is what runs.
+//   way.  With the loads branch-free the kernel moves 5.1 TB/s (each sample is read (W + L) / L times); NS = 2
+//   (two independent streams per lane) is kept in the template but only NS = 1 is instantiated: it measured slower.
 template <bool FM, int NS, bool PAIRS>
 __global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A, uint32_t groups)   // <= 128 VGPRs: 4 waves per SIMD
 {
