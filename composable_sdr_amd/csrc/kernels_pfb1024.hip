@@ -34,6 +34,7 @@ constexpr int PAS = 17 * 4;                     // padded stride between k1 rows
 struct Pfb1024Args {
     const float2 *u;            // first NEW sample; 13 * 1024 samples of history in front
     const float *taps;          // h[(1023 - j) + 1024 n]
+    const float4 *taps_t;       // DC = true: the same taps gathered per branch, [1024][16] floats (14 used): four 16-byte loads from one address
     const float2 *tw;           // e^{-j 2 pi i / 1024}
     void *out;                  // [C][nf] F32 (FM) or CF32
     const float2 *rp_in; float2 *rp_out;        // [C] freqdem r'
@@ -135,6 +136,8 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
     }
     if (DC && tid == 0) carry_s = c;
     __syncthreads();                                                // twiddle tables, carry_s
+    // (decay factors inside the loop use the bare v_exp_f32: results below 2^-126 flush to zero, which is what a
+    // factor that small amounts to anyway, and the library exp2f's denormal handling costs ~6 instructions a call)
     for (uint32_t b = tile_begin; b < last; b++) {
         // keep the per-phase address arithmetic inside the iteration (hoisted out of the tile loop it pins dozens of VGPRs)
         int tid_i = tid;
@@ -145,8 +148,15 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
         // the 14 taps (and the two pre-mix phasors) are re-read per tile (L2-resident; held across the tile loop they
         // would spill): issued first, so that their latency hides behind the DC stage
         float h[PP];
+        if (DC) {
+            const float4 *tp = A.taps_t + 4 * j_i;
+            const float4 ha = tp[0], hb = tp[1], hc = tp[2], hd = tp[3];
+            h[0] = ha.x; h[1] = ha.y; h[2] = ha.z; h[3] = ha.w; h[4] = hb.x; h[5] = hb.y; h[6] = hb.z; h[7] = hb.w;
+            h[8] = hc.x; h[9] = hc.y; h[10] = hc.z; h[11] = hc.w; h[12] = hd.x; h[13] = hd.y;
+        } else {
 #pragma unroll
-        for (int n = 0; n < PP; n++) h[n] = A.taps[(PM - 1 - j_i) + n * PM];
+            for (int n = 0; n < PP; n++) h[n] = A.taps[(PM - 1 - j_i) + n * PM];
+        }
         float2 Wa = make_float2(1.f, 0.f), Wb = Wa;
         if (DC) { Wa = A.wpre[(A.parity0 & 1) * PM + j_i]; Wb = A.wpre[((A.parity0 & 1) ^ 1) * PM + j_i]; }
         if (DC) {
@@ -169,7 +179,7 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
             float2 e0 = make_float2(0.f, 0.f);
             if (tid_i < 512) {
                 const int l = tid_i & 63;
-                const float wrow = exp2f(A.l2beta * 16.0f * (float)((tid_i & 15) + 1));   // beta^(16 ((r & 15) + 1))
+                const float wrow = __builtin_amdgcn_exp2f(A.l2beta * 16.0f * (float)((tid_i & 15) + 1));   // beta^(16 ((r & 15) + 1))
                 float2 sv = TR[tid_i], t;
                 t = dpp2<0x111>(sv); sv = cfma(t, A.dp[0], sv);
                 t = dpp2<0x112>(sv); sv = cfma(t, A.dp[1], sv);
@@ -197,8 +207,8 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
                 }
                 const float2 cc = carry_s;
                 if (tid_i < 512) {
-                    const float br = exp2f(A.l2beta * 16.0f * (float)(tid_i & 63));           // beta^(16 r), r = run inside the frame
-                    const float bf = exp2f(A.l2beta * 1024.0f * (float)fme);                 // beta^(1024 f)
+                    const float br = __builtin_amdgcn_exp2f(A.l2beta * 16.0f * (float)(tid_i & 63));           // beta^(16 r), r = run inside the frame
+                    const float bf = __builtin_amdgcn_exp2f(A.l2beta * 1024.0f * (float)fme);                 // beta^(1024 f)
                     E[tid_i] = cfma(cfma(cc, bf, vb), br, e0);
                 }
                 __syncthreads();                                    // carry_s read by everyone
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
             __syncthreads();
             // ---- finish the DC blocker, apply the NCO pre-mix ----
             {
-                const float kj = -A.alpha * exp2f(A.l2beta * (float)(tid_i & 15));
+                const float kj = -A.alpha * __builtin_amdgcn_exp2f(A.l2beta * (float)(tid_i & 15));
 #pragma unroll
                 for (int f = 0; f < PT; f++) {
                     const float2 y = cfma(E[64 * f + (j_i >> 4)], kj, nw[f]);
@@ -274,7 +284,11 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const int k2 = GXIDX(i);
-                if (k2 && n3) { const float2 tq = tw2[k2 * 4 + n3]; v[i] = g_cmul(v[i], (v2fg){tq.x, tq.y}); }
+                if (k2) {                                           // read + select: a read under the lane-varying n3 test is waited for on its own
+                    const float2 tq = tw2[k2 * 4 + n3];
+                    const v2fg r = g_cmul(v[i], (v2fg){tq.x, tq.y});
+                    v[i] = n3 ? r : v[i];
+                }
                 bufB[fr * PM + (k1 + 16 * k2) * 4 + n3] = make_float2(v[i].x, v[i].y);
             }
         }
@@ -430,6 +444,7 @@ struct BigPlan {
     uint32_t cus = 256;
     uint64_t frames_done = 0;
     float *d_taps = nullptr;
+    float4 *d_taps_t = nullptr;
     float2 *d_tw = nullptr, *d_wpre = nullptr;
     float2 *d_uhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
     float2 *d_scratch = nullptr;     // yfirst | ylast
@@ -442,7 +457,7 @@ bool big_supported(uint32_t M, uint32_t p) { return M == (uint32_t)PM && p == (u
 void big_destroy(BigPlan *p)
 {
     if (!p) return;
-    void *ptrs[] = {p->d_taps, p->d_tw, p->d_wpre, p->d_uhist[0], p->d_uhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0], p->d_rp[1],
+    void *ptrs[] = {p->d_taps, p->d_taps_t, p->d_tw, p->d_wpre, p->d_uhist[0], p->d_uhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0], p->d_rp[1],
                     p->d_scratch, p->d_premix};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
@@ -461,6 +476,7 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
     }
 #define ALLOC(ptr, bytes) do { hipError_t e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 1); if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__)); } while (0)
     ALLOC(p->d_taps, sizeof(float) * PM * PP);
+    ALLOC(p->d_taps_t, sizeof(float) * PM * 16);
     ALLOC(p->d_tw, sizeof(float2) * PM);
     ALLOC(p->d_wpre, sizeof(float2) * 2 * PM);
     for (int i = 0; i < 2; i++) {
@@ -472,6 +488,11 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
 #undef ALLOC
     CSDR_HIP(hipMemcpy(p->d_taps, cfg.taps, sizeof(float) * PM * PP, hipMemcpyHostToDevice));
+    {
+        std::vector<float> tt((size_t)PM * 16, 0.f);
+        for (int j = 0; j < PM; j++) for (int n = 0; n < PP; n++) tt[(size_t)j * 16 + n] = cfg.taps[(PM - 1 - j) + n * PM];
+        CSDR_HIP(hipMemcpy(p->d_taps_t, tt.data(), sizeof(float) * tt.size(), hipMemcpyHostToDevice));
+    }
     std::vector<float2> tw(PM), wpre(2 * PM);
     for (int i = 0; i < PM; i++) {
         const double a = -2.0 * 3.14159265358979323846 * (double)i / (double)PM;
@@ -509,7 +530,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     if (!nf) return 0;
     int r;
     Pfb1024Args A{};
-    A.u = call.d_in; A.taps = p->d_taps; A.tw = p->d_tw; A.wpre = p->d_wpre;
+    A.u = call.d_in; A.taps = p->d_taps; A.taps_t = p->d_taps_t; A.tw = p->d_tw; A.wpre = p->d_wpre;
     A.out = c.mix ? p->d_premix : call.d_out;
     A.rp_in = p->d_rp[p->cur]; A.rp_out = p->d_rp[p->cur ^ 1];
     A.vend_in = p->d_vend[p->cur]; A.vend_out = p->d_vend[p->cur ^ 1];
