@@ -93,7 +93,7 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
     float2 old[13];
     float2 c = make_float2(0.f, 0.f);           // DC: blocker state at the start of the run (then kept in carry_s)
     uint32_t tile_begin = first;                // DC, run >= 1: two halo tiles refill the window (no output)
-    __shared__ float2 carry_s;                  // DC: blocker state before the next tile
+    __shared__ float2 carry_s[2];               // DC: blocker state before the tile, ping-pong by tile parity (saves a barrier)
     if (!DC) {
         const int64_t fa = (int64_t)first * PT;
 #pragma unroll
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
 #pragma unroll
         for (int f = 0; f < PT; f++) nw[f] = t0 + f < A.nf ? A.u[(size_t)(t0 + f) * PM + j] : make_float2(0.f, 0.f);
     }
-    if (DC && tid == 0) carry_s = c;
+    if (DC && tid == 0) carry_s[0] = c;
     __syncthreads();                                                // twiddle tables, carry_s
     // (decay factors inside the loop use the bare v_exp_f32: results below 2^-126 flush to zero, which is what a
     // factor that small amounts to anyway, and the library exp2f's denormal handling costs ~6 instructions a call)
@@ -205,14 +205,14 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
                     if (f == fme) vb = ve;
                     if (f < nvalid) { ve = cfma(ve, A.dm, Tt[f]); dn *= A.dm; }
                 }
-                const float2 cc = carry_s;
+                const int par = (int)((b - tile_begin) & 1u);
+                const float2 cc = carry_s[par];
                 if (tid_i < 512) {
                     const float br = __builtin_amdgcn_exp2f(A.l2beta * 16.0f * (float)(tid_i & 63));           // beta^(16 r), r = run inside the frame
                     const float bf = __builtin_amdgcn_exp2f(A.l2beta * 1024.0f * (float)fme);                 // beta^(1024 f)
                     E[tid_i] = cfma(cfma(cc, bf, vb), br, e0);
                 }
-                __syncthreads();                                    // carry_s read by everyone
-                if (tid_i == 0) carry_s = cfma(cc, dn, ve);
+                if (tid_i == 0) carry_s[par ^ 1] = cfma(cc, dn, ve);
             }
             __syncthreads();
             // ---- finish the DC blocker, apply the NCO pre-mix ----
@@ -385,14 +385,17 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
                 for (int f = 0; f < PT; f++) if (f < nvalid) o[f] = Yl[f * PM + tid_i];
             }
         }
-        __syncthreads();                                            // Y consumed before the next tile's X
+        // Y (bufA) and Mt (bufB) consumed before the next tile overwrites them.  The vectorised FM tail has already
+        // passed a barrier after its last read of bufA, and with the DC stage in front bufB is not written again before
+        // three more barriers.
+        if (!(DC && FM && nvalid == PT && (A.nf & 3) == 0)) __syncthreads();
     }
     if (FM) {
         A.ylast[(size_t)w * PM + tid] = prev;
         if (w + 1 == A.nruns && owned) A.rp_out[tid - A.c0] = prev;
     }
     if (DC && w + 1 == A.nruns) {
-        if (tid == 0) A.vend_out[0] = carry_s;
+        if (tid == 0) A.vend_out[0] = carry_s[(last - tile_begin) & 1u];
 #pragma unroll
         for (int i = 0; i < 13; i++) A.uhist_out[i * PM + tid] = old[i];
     }
