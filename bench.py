@@ -64,9 +64,32 @@ def cpu_baseline(M, demod, kf, agc, x_host, seconds, mix=False):
         if time.perf_counter() - t0 >= seconds:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(done / dt / 1e6, 3), "unit": "MS/s", "cores": 1, "kind": "port",
-            "sample": f"{done // chunk} chunks of 4096 frames x {M} ch ({done / 1e6:.1f} MS) of the same synthetic stream, "
-                      f"oracle/csdr_oracle.c single thread, {dt:.1f} s"}
+    res = {"value": round(done / dt / 1e6, 3), "unit": "MS/s", "cores": 1, "kind": "port",
+           "sample": f"{done // chunk} chunks of 4096 frames x {M} ch ({done / 1e6:.1f} MS) of the same synthetic stream, "
+                     f"oracle/csdr_oracle.c single thread, {dt:.1f} s"}
+    # the same restatement on all host cores -- one independent chain per core, each on its own
+    # stretch of the stream (the reference itself is single-threaded; this is the fair-hardware figure)
+    import threading
+    ncores = os.cpu_count() or 1
+    if ncores > 1 and nchunks >= 1:
+        chains = [O.Chain(M, dc_block=True, agc_db=agc, demod=demod, kf=kf, mix=mix) for _ in range(ncores)]
+        counts = [0] * ncores
+        budget = max(2.0, seconds / 3)
+        t1 = time.perf_counter()
+
+        def work(k):
+            i = k % nchunks
+            while time.perf_counter() - t1 < budget:
+                chains[k].process(x_host[i * chunk:(i + 1) * chunk])    # ctypes releases the GIL
+                counts[k] += chunk
+                i = (i + 1) % nchunks
+        th = [threading.Thread(target=work, args=(k,)) for k in range(ncores)]
+        for t in th: t.start()
+        for t in th: t.join()
+        dt2 = time.perf_counter() - t1
+        res["all_cores"] = {"value": round(sum(counts) / dt2 / 1e6, 3), "unit": "MS/s", "cores": ncores,
+                            "sample": f"{ncores} independent chains, one thread each, {sum(counts) / 1e6:.1f} MS in {dt2:.1f} s"}
+    return res
 
 
 def main():
