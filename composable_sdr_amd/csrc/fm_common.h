@@ -17,9 +17,12 @@ __device__ __forceinline__ float atan2f_rn(float y, float x)
 {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    // mn / mx, with 0/0 -> 0 and inf/inf -> 1: those are the two cases in which mn * rcp(mx) is 0 * inf = NaN
+    // (finite / inf is already 0).  Written as selects on the product: with the tests on mx in front the compiler
+    // builds exec-masked branches around the rcp, two per sample, on the critical path of the AGC tail.
     float a = mn * __builtin_amdgcn_rcpf(mx);
-    a = (mx == 0.0f) ? 0.0f : a;
-    a = (mx == INFINITY) ? ((mn == INFINITY) ? 1.0f : 0.0f) : a;
+    const float t = (mx == 0.0f) ? 0.0f : 1.0f;
+    a = (a == a) ? a : t;
     const float z = a * a;
     float p = 2.456645248e-03f;
     p = fmaf(p, z, -1.440101303e-02f);

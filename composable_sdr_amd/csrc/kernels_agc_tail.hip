@@ -24,10 +24,10 @@
 #include "fm_common.h"
 #include <cstdlib>
 #ifndef CSDR_AGC_PREFETCH
-#define CSDR_AGC_PREFETCH 0
+#define CSDR_AGC_PREFETCH 0          // 1: block k + 1 is fetched while block k is worked on (measured slower, see k_agc_spec)
 #endif
 #ifndef CSDR_AGC_ABLATE
-#define CSDR_AGC_ABLATE 0      // timing experiments only: 1 no log/exp, 2 every block reloads the same (cached) lines, 4 no stores
+#define CSDR_AGC_ABLATE 0      // timing experiments only: 1 no log/exp, 2 every block reloads the same (cached) lines, 4 no stores, 16 no compute
 #endif
 
 namespace csdr {
@@ -52,27 +52,32 @@ __device__ __forceinline__ void s_decode(uint32_t S, uint32_t timeout, int32_t &
     mode = S > 8u ? 5 : (S == 8u ? 6 : (int32_t)S);
     timer = S > 8u ? S - 8u : timeout;
 }
-__device__ __forceinline__ float2 agc_tail_step(float2 x, AgcSeg &q, const AgcParams &p)
+// the float path of one sample: updates g and y2', returns the un-muted output and whether the threshold is exceeded
+__device__ __forceinline__ float2 agc_gain_step(float2 x, AgcSeg &q, const AgcParams &p, bool &ex)
 {
-    float2 y = make_float2(x.x * q.g, x.y * q.g);
+    const float2 y = make_float2(x.x * q.g, x.y * q.g);
     const float y2 = fmaf(y.x, y.x, y.y * y.y);          // explicit: must round the same in every kernel
     q.y2 = fmaf(1.0f - p.alpha, q.y2, p.alpha * y2);
     const float upd = (CSDR_AGC_ABLATE & 1) ? 0.999f + 1e-3f * q.y2 : __builtin_amdgcn_exp2f((-0.5f * p.alpha) * __builtin_amdgcn_logf(q.y2));
     q.g = (q.y2 > 1e-6f) ? q.g * upd : q.g;
     q.g = fminf(q.g, 1e6f);
-    const bool ex = q.g < p.g_thr;                    // rssi > threshold
-    const uint32_t S = (uint32_t)q.mode;              // AgcSeg.mode carries S inside this file
-    // most samples leave the squelch where it is (SIGNALHI with the threshold exceeded, ENABLED without): when that
-    // holds for the whole wave the transition tables are skipped
-    const bool steady = (S == 3u && ex) || (S == 1u && !ex);
-    uint32_t Sn = S;
-    if (__builtin_amdgcn_ballot_w64(!steady) != 0ull) {
-        uint32_t t = __builtin_amdgcn_ubfe(ex ? S_TEX : S_TNO, 3u * S, 3u);
-        t = (t == 5u) ? 8u + p.timeout : t;
-        const uint32_t r9 = (ex && S >= 10u) ? 3u : S - 1u;
-        Sn = (S >= 9u) ? r9 : t;
-        q.mode = (int32_t)Sn;
-    }
+    ex = q.g < p.g_thr;                               // rssi > threshold
+    return y;
+}
+// squelch state after a sample
+__device__ __forceinline__ uint32_t squelch_next(uint32_t S, bool ex, const AgcParams &p)
+{
+    uint32_t t = __builtin_amdgcn_ubfe(ex ? S_TEX : S_TNO, 3u * S, 3u);
+    t = (t == 5u) ? 8u + p.timeout : t;
+    const uint32_t r9 = (ex && S >= 10u) ? 3u : S - 1u;
+    return (S >= 9u) ? r9 : t;
+}
+__device__ __forceinline__ float2 agc_tail_step(float2 x, AgcSeg &q, const AgcParams &p)
+{
+    bool ex;
+    float2 y = agc_gain_step(x, q, p, ex);
+    const uint32_t Sn = squelch_next((uint32_t)q.mode, ex, p);   // AgcSeg.mode carries S inside this file
+    q.mode = (int32_t)Sn;
     if (Sn != 3u) y = make_float2(0.f, 0.f);          // reference mute rule (Liquid.chs:703-704)
     return y;
 }
@@ -106,6 +111,10 @@ struct TailArgs {
 __device__ __forceinline__ int slot8(int j, int pc) { return 8 * j + (pc ^ ((j ^ (j >> 3)) & 7)); }
 
 // four consecutive samples of one stream: AGC (+ freqdem); GUARD: only samples t < end exist
+// The g recurrence does not depend on the squelch state, and most samples leave the squelch where it is (SIGNALHI
+// with the threshold exceeded, ENABLED without).  A whole quad therefore runs the four gain steps first and decides
+// ONCE, for the wave, whether any lane's state moves: if not, the transition tables are skipped (one branch per
+// four samples on the dependent chain instead of four); the freqdem of the four samples follows as independent work.
 template <bool FM, bool GUARD>
 __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, AgcSeg &q, const AgcParams &p, float ref,
                                          uint32_t t, uint32_t end, float4 &oa, float4 &ob)
@@ -113,12 +122,38 @@ __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, Agc
     float2 y[4];
     float m[4] = {0.f, 0.f, 0.f, 0.f};
     const float2 x[4] = {make_float2(va.x, va.y), make_float2(va.z, va.w), make_float2(vb.x, vb.y), make_float2(vb.z, vb.w)};
+    if (GUARD) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        y[i] = make_float2(0.f, 0.f);
-        if (!GUARD || t + i < end) {
-            y[i] = agc_tail_step(x[i], q, p);
-            if (FM) { m[i] = fm_tail_sample(make_float2(q.rx, q.ry), y[i], ref); q.rx = y[i].x; q.ry = y[i].y; }
+        for (int i = 0; i < 4; i++) {
+            y[i] = make_float2(0.f, 0.f);
+            if (t + i < end) {
+                y[i] = agc_tail_step(x[i], q, p);
+                if (FM) { m[i] = fm_tail_sample(make_float2(q.rx, q.ry), y[i], ref); q.rx = y[i].x; q.ry = y[i].y; }
+            }
+        }
+    } else {
+        bool ex[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) y[i] = agc_gain_step(x[i], q, p, ex[i]);
+        uint32_t S = (uint32_t)q.mode;
+        const bool all_ex = ex[0] && ex[1] && ex[2] && ex[3], none_ex = !(ex[0] || ex[1] || ex[2] || ex[3]);
+        const bool steady = (S == 3u && all_ex) || (S == 1u && none_ex);
+        if (__builtin_amdgcn_ballot_w64(!steady) == 0ull) {
+            const bool open = S == 3u;                          // the state holds through the quad
+#pragma unroll
+            for (int i = 0; i < 4; i++) y[i] = open ? y[i] : make_float2(0.f, 0.f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                S = squelch_next(S, ex[i], p);
+                if (S != 3u) y[i] = make_float2(0.f, 0.f);      // reference mute rule (Liquid.chs:703-704)
+            }
+            q.mode = (int32_t)S;
+        }
+        if (FM) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) m[i] = fm_tail_sample(i ? y[i - 1] : make_float2(q.rx, q.ry), y[i], ref);
+            q.rx = y[3].x; q.ry = y[3].y;
         }
     }
     if (FM) oa = make_float4(m[0], m[1], m[2], m[3]);
@@ -131,8 +166,17 @@ __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, Agc
 //   time; the outputs are written back over the stream's own consumed input pieces and leave the same cooperative
 //   way.  With the loads branch-free the kernel moves 5.1 TB/s (each sample is read (W + L) / L times); NS = 2
 //   (two independent streams per lane) is kept in the template but only NS = 1 is instantiated: it measured slower.
+// The workgroup IS one wave: LDS accesses of one wave execute in order, so all that is needed between the
+// cooperative and the per-stream use of `buf` is that the compiler keeps the order.  __syncthreads() would also
+// wait for every outstanding global access (vmcnt(0)) -- i.e. for the previous block's stores to reach memory.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool FM, int NS, bool PAIRS>
-__global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A, uint32_t groups)   // <= 128 VGPRs: 4 waves per SIMD
+__global__ __launch_bounds__(64, 3) void k_agc_spec(TailArgs A, uint32_t groups)   // <= 168 VGPRs: 3 waves per SIMD
 {
     __shared__ float4 buf[NS][64 * 8];
     const int lane = threadIdx.x;
@@ -174,26 +218,41 @@ __global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A, uint32_t groups)
         }
     };
 
-    float4 ld[NS][8];
-    if (CSDR_AGC_PREFETCH) {
+    // Interior blocks -- all 64 streams of the wave exist and the block lies inside every stream's range (all but the
+    // first W samples of a row and its ragged end) -- need no range tests at all: one uniform base pointer and a
+    // 32-bit lane offset per piece.  The general path's clamps, masks and 64-bit addresses cost as many VALU
+    // instructions per block as the sixteen warm-up steps themselves.
+    const bool wave_full = NS == 1 && PAIRS && sbase + 64u <= A.nseg;
+    const int64_t t_first = (int64_t)sbase * A.L - (int64_t)A.W;                    // stream 0's sample at k = 0
+    const int64_t t_lastend = (int64_t)(sbase + 63u) * A.L - (int64_t)A.W + 15;     // stream 63's last sample at k = 0
+    const char *wbase = reinterpret_cast<const char *>(A.Z + row) + t_first * 8;    // uniform; dereferenced on interior blocks only
+    const uint32_t voff0 = ((uint32_t)(lane >> 3) * A.L + 2u * (uint32_t)pc) * 8u;  // bytes: my piece of stream lane >> 3
+    const uint32_t mstep = 64u * A.L;                                               // bytes: eight streams further
+
+    static_assert(NS == 1, "the block pipeline below holds one stream set per lane");
+    auto is_inner = [&](uint32_t k) { return wave_full && t_first + 16 * (int64_t)k >= 0 && t_lastend + 16 * (int64_t)k < (int64_t)A.nf; };
+    // block k's eight pieces -> registers (not waited for here on interior blocks: nothing touches the data)
+    auto fetch = [&](uint32_t k, float4 (&ld)[8]) {
+        if (is_inner(k)) {
 #pragma unroll
-        for (int u = 0; u < NS; u++) load_block(0, u, ld[u]);
-    }
+            for (int m = 0; m < 8; m++)
+                ld[m] = *reinterpret_cast<const float4 *>(wbase + (voff0 + (uint32_t)m * mstep + 128u * ((CSDR_AGC_ABLATE & 2) ? (k >= kreal ? kreal : 0u) : k)));
+        } else load_block(k, 0, ld);
+    };
+
+    // CSDR_AGC_PREFETCH = 1 fetches block k + 1 while block k is worked on (32 more VGPRs).  Measured per 67 M samples
+    // (L = 384 / 768 / 1024): 489 / 471 / 494 us with, 493 / 441 / 459 us without -- left off.  Ablations at L = 1024
+    // (one wave per SIMD): data path alone 333 us, arithmetic alone 339 us, neither 90 us, both 436-485 us.
+    float4 ld[8];
+    if (CSDR_AGC_PREFETCH) fetch(0, ld);
     for (uint32_t k = 0; k < nblk; k++) {
-        // CSDR_AGC_PREFETCH: block k + 1 is in flight (32 VGPRs) while block k is worked on; otherwise the other
-        // waves of the SIMD are what covers the load latency
-        __syncthreads();                                        // previous block's buffers consumed
+        const bool inner = is_inner(k);
+        if (!CSDR_AGC_PREFETCH) fetch(k, ld);
+        wave_sync();                                        // previous block's buffers consumed
 #pragma unroll
-        for (int u = 0; u < NS; u++) {
-            if (!CSDR_AGC_PREFETCH) load_block(k, u, ld[u]);
-#pragma unroll
-            for (int m = 0; m < 8; m++) buf[u][slot8(8 * m + (lane >> 3), pc)] = ld[u][m];
-        }
-        __syncthreads();
-        if (CSDR_AGC_PREFETCH && k + 1 < nblk) {
-#pragma unroll
-            for (int u = 0; u < NS; u++) load_block(k + 1, u, ld[u]);
-        }
+        for (int m = 0; m < 8; m++) buf[0][slot8(8 * m + (lane >> 3), pc)] = ld[m];
+        wave_sync();
+        if (CSDR_AGC_PREFETCH && k + 1 < nblk) fetch(k + 1, ld);
 
         int32_t t0[NS];
         bool live[NS], full = true, anylive = false;
@@ -201,11 +260,12 @@ __global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A, uint32_t groups)
         for (int u = 0; u < NS; u++) {
             t0[u] = (int32_t)(sg[u] * A.L) - (int32_t)A.W + (int32_t)(16 * k);
             if (mine[u] && k == kreal) A.seg_start[(size_t)c * A.nseg + sg[u]] = q[u];   // state at the segment start, after the warm-up
-            live[u] = t0[u] >= 0 && (uint32_t)t0[u] < endv[u];
-            full = full && (!live[u] || (uint32_t)t0[u] + 16 <= endv[u]);
+            live[u] = inner || (t0[u] >= 0 && (uint32_t)t0[u] < endv[u]);
+            full = full && (inner || !live[u] || (uint32_t)t0[u] + 16 <= endv[u]);
             anylive = anylive || live[u];
         }
-        if (anylive && k < kreal) {
+        if ((CSDR_AGC_ABLATE & 16)) {
+        } else if (anylive && k < kreal) {
             // warm-up block (always whole): only the state matters -- no freqdem, nothing stored
 #pragma unroll 1
             for (int h = 0; h < 4; h++) {
@@ -253,8 +313,24 @@ __global__ __launch_bounds__(64, 4) void k_agc_spec(TailArgs A, uint32_t groups)
         }
         if (k >= kreal && !((CSDR_AGC_ABLATE & 4) && A.nf != 0xffffffffu)) {
             // outputs leave as whole lines
-            __syncthreads();
+            wave_sync();
             const uint32_t tb = 16 * (k - kreal);
+            if (inner && (!FM || (row & 3) == 0)) {
+                // interior block, 16-byte aligned rows: the same uniform-base addressing as the loads
+                if (FM) {
+                    char *obase = reinterpret_cast<char *>((float *)A.out + row + (size_t)sbase * A.L + tb);
+                    const uint32_t off = ((uint32_t)(lane >> 2) * A.L + 4u * (uint32_t)(lane & 3)) * 4u;
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
+                        *reinterpret_cast<float4 *>(obase + (off + (uint32_t)m * mstep)) = buf[0][slot8(16 * m + (lane >> 2), lane & 3)];
+                } else {
+                    char *obase = reinterpret_cast<char *>((float2 *)A.out + row + (size_t)sbase * A.L + tb);
+#pragma unroll
+                    for (int m = 0; m < 8; m++)
+                        *reinterpret_cast<float4 *>(obase + (voff0 + (uint32_t)m * mstep)) = buf[0][slot8(8 * m + (lane >> 3), pc)];
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < NS; u++) {
                 if (FM) {
@@ -349,7 +425,7 @@ struct AgcTailPlan {
     AgcSeg *d_start = nullptr, *d_end = nullptr;
     AgcState *d_st_tmp = nullptr;
     unsigned *d_stats = nullptr;
-    uint32_t lanes_target = 131072;      // 2 waves per SIMD
+    uint32_t lanes_target = 98304;       // 1.5 waves per SIMD
 };
 
 int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
@@ -364,9 +440,11 @@ int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        uint32_t wps = 3;                                   // waves per SIMD the segment length aims for
-        if (const char *e = getenv("CSDR_AGC_WAVES")) wps = (uint32_t)atol(e);
-        p->lanes_target = (uint32_t)cus * 4u * 64u * (wps ? wps : 1u);
+        // streams the segment length aims for: 1.5 waves per SIMD.  More, shorter segments re-read more warm-up
+        // (the kernel turns bandwidth-bound: L = 384 at 2.75 waves per SIMD 0.49 ms per 67 M samples), fewer leave a
+        // lone wave per SIMD to its ~350-cycle dependent step (L = 1024: 0.46 ms); L = 768 at 1.4: 0.44 ms
+        p->lanes_target = (uint32_t)cus * 4u * 64u * 3u / 2u;
+        if (const char *e = getenv("CSDR_AGC_WAVES")) { const uint32_t wps = (uint32_t)atol(e); p->lanes_target = (uint32_t)cus * 4u * 64u * (wps ? wps : 1u); }
     }
     p->max_seg = (max_nf + 15u) / 16u + 1;                      // L >= 16
     const size_t n = (size_t)C * p->max_seg;
@@ -404,8 +482,8 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
 {
     if (!nf || !p->C) return 0;
     if ((uint64_t)p->C * nf >= (1ull << 32)) { set_error("agc tail: C*nf = %llu samples exceeds 2^32", (unsigned long long)p->C * nf); return CSDR_ERR_SIZE; }
-    // segment length: the configured L, stretched when that would give more lanes than the machine holds at
-    // 2 waves per SIMD (longer segments waste less on the warm-up)
+    // segment length: the configured L, doubled while that gives more streams than the target (longer segments
+    // waste less on the warm-up)
     uint32_t L = p->L;
     while ((uint64_t)p->C * ((nf + L - 1) / L) > p->lanes_target && L < (1u << 20)) L *= 2;
     const uint32_t nseg = (nf + L - 1) / L;
