@@ -22,6 +22,7 @@
 #include "../../include/csdr.h"
 #include "csdr_internal.h"
 #include "fm_common.h"
+#include "agc_common.h"
 #include <cstdlib>
 #ifndef CSDR_AGC_PREFETCH
 #define CSDR_AGC_PREFETCH 0          // 1: block k + 1 is fetched while block k is worked on (measured slower, see k_agc_spec)
@@ -36,8 +37,8 @@ namespace {
 
 struct AgcSeg { float g, y2; int32_t mode; uint32_t timer; float rx, ry; uint32_t pad0, pad1; };   // 32 B
 
-// agc_crcf_execute + squelch update + the reference's mute rule.  The float path is agc_step's of
-// kernels_generic.hip operation for operation (both kernels must round the same way); the squelch state machine
+// agc_crcf_execute + squelch update + the reference's mute rule.  The float path is agc_common.h's, shared with
+// agc_step of kernels_generic.hip (both kernels must round the same way); the squelch state machine
 // (agc_crcf_squelch_update_mode, modes 1..6 + timer) is folded into ONE integer S so that a step costs ~12
 // integer instructions instead of ~27:
 //   S = 1 ENABLED, 2 RISE, 3 SIGNALHI, 4 FALL, 8 TIMEOUT, 8+k SIGNALLO with k samples left on the timer
@@ -52,16 +53,12 @@ __device__ __forceinline__ void s_decode(uint32_t S, uint32_t timeout, int32_t &
     mode = S > 8u ? 5 : (S == 8u ? 6 : (int32_t)S);
     timer = S > 8u ? S - 8u : timeout;
 }
-// the float path of one sample: updates g and y2', returns the un-muted output and whether the threshold is exceeded
-__device__ __forceinline__ float2 agc_gain_step(float2 x, AgcSeg &q, const AgcParams &p, bool &ex)
+// the float path of one sample (agc_common.h): updates g and y2', returns the un-muted output
+__device__ __forceinline__ float2 agc_gain_step(float2 x, AgcSeg &q, const AgcParams &p)
 {
     const float2 y = make_float2(x.x * q.g, x.y * q.g);
-    const float y2 = fmaf(y.x, y.x, y.y * y.y);          // explicit: must round the same in every kernel
-    q.y2 = fmaf(1.0f - p.alpha, q.y2, p.alpha * y2);
-    const float upd = (CSDR_AGC_ABLATE & 1) ? 0.999f + 1e-3f * q.y2 : __builtin_amdgcn_exp2f((-0.5f * p.alpha) * __builtin_amdgcn_logf(q.y2));
-    q.g = (q.y2 > 1e-6f) ? q.g * upd : q.g;
-    q.g = fminf(q.g, 1e6f);
-    ex = q.g < p.g_thr;                               // rssi > threshold
+    if (CSDR_AGC_ABLATE & 1) { q.y2 = fmaf(1.0f - p.alpha, q.y2, agc_energy(x, p.alpha) * (q.g * q.g)); q.g = __builtin_amdgcn_fmed3f(q.g * (1.0f - 1e-3f * (q.y2 - 1.0f)), 0.0f, 1e6f); }
+    else agc_gain_update(agc_energy(x, p.alpha), q.g, q.y2, p.alpha);
     return y;
 }
 // squelch state after a sample
@@ -74,9 +71,8 @@ __device__ __forceinline__ uint32_t squelch_next(uint32_t S, bool ex, const AgcP
 }
 __device__ __forceinline__ float2 agc_tail_step(float2 x, AgcSeg &q, const AgcParams &p)
 {
-    bool ex;
-    float2 y = agc_gain_step(x, q, p, ex);
-    const uint32_t Sn = squelch_next((uint32_t)q.mode, ex, p);   // AgcSeg.mode carries S inside this file
+    float2 y = agc_gain_step(x, q, p);
+    const uint32_t Sn = squelch_next((uint32_t)q.mode, q.g < p.g_thr, p);   // AgcSeg.mode carries S inside this file
     q.mode = (int32_t)Sn;
     if (Sn != 3u) y = make_float2(0.f, 0.f);          // reference mute rule (Liquid.chs:703-704)
     return y;
@@ -132,11 +128,18 @@ __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, Agc
             }
         }
     } else {
-        bool ex[4];
+        // "threshold exceeded by all / by none of the four" from the running max / min of g (v_med3 with +-inf): the
+        // per-sample compares would each hand a mask to the scalar unit, and the wave waits for every such hand-over
+        float gs[4], gmx = -INFINITY, gmn = INFINITY;
 #pragma unroll
-        for (int i = 0; i < 4; i++) y[i] = agc_gain_step(x[i], q, p, ex[i]);
+        for (int i = 0; i < 4; i++) {
+            y[i] = agc_gain_step(x[i], q, p);
+            gs[i] = q.g;
+            gmx = __builtin_amdgcn_fmed3f(q.g, gmx, INFINITY);
+            gmn = __builtin_amdgcn_fmed3f(q.g, gmn, -INFINITY);
+        }
         uint32_t S = (uint32_t)q.mode;
-        const bool all_ex = ex[0] && ex[1] && ex[2] && ex[3], none_ex = !(ex[0] || ex[1] || ex[2] || ex[3]);
+        const bool all_ex = gmx < p.g_thr, none_ex = !(gmn < p.g_thr);
         const bool steady = (S == 3u && all_ex) || (S == 1u && none_ex);
         if (__builtin_amdgcn_ballot_w64(!steady) == 0ull) {
             const bool open = S == 3u;                          // the state holds through the quad
@@ -145,7 +148,7 @@ __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, Agc
         } else {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                S = squelch_next(S, ex[i], p);
+                S = squelch_next(S, gs[i] < p.g_thr, p);
                 if (S != 3u) y[i] = make_float2(0.f, 0.f);      // reference mute rule (Liquid.chs:703-704)
             }
             q.mode = (int32_t)S;

@@ -4,6 +4,7 @@
 // and for the sequential AGC tail.  Wave = 64 lanes throughout.
 #include "csdr_internal.h"
 #include "fm_common.h"
+#include "agc_common.h"
 #include "fft16_generic.h"
 
 namespace csdr {
@@ -499,15 +500,9 @@ int launch_agc_init(AgcState *st, uint32_t C, hipStream_t s)
 
 __device__ __forceinline__ float2 agc_step(float2 x, AgcState &q, const AgcParams &p)
 {
-    // agc_crcf_execute: y = x*g ; y2' <- (1-alpha) y2' + alpha |y|^2 ; g <- g * exp(-alpha/2 * ln y2') ;
-    // the dependent chain is what bounds this kernel, so the gain update uses the hardware
-    // log2/exp2 (1 ulp) instead of libm's expf/logf: g*2^(-alpha/2 * log2 y2') is the same function.
+    // agc_crcf_execute: y = x*g ; y2' <- (1-alpha) y2' + alpha |y|^2 ; g <- g * exp(-alpha/2 * ln y2')
     float2 y = make_float2(x.x * q.g, x.y * q.g);
-    const float y2 = fmaf(y.x, y.x, y.y * y.y);          // explicit: must round the same in every kernel
-    q.y2 = fmaf(1.0f - p.alpha, q.y2, p.alpha * y2);
-    const float upd = __builtin_amdgcn_exp2f((-0.5f * p.alpha) * __builtin_amdgcn_logf(q.y2));
-    q.g = (q.y2 > 1e-6f) ? q.g * upd : q.g;
-    q.g = fminf(q.g, 1e6f);
+    agc_gain_update(agc_energy(x, p.alpha), q.g, q.y2, p.alpha);     // agc_common.h: the shared, chain-shortened float path
     const bool ex = q.g < p.g_thr;                    // rssi > threshold
     // squelch state machine (agc_crcf_squelch_update_mode), modes 1..6
     int m = q.mode;
