@@ -16,17 +16,15 @@
 //                true state.  The result is therefore bit-identical to the one-lane-per-channel kernel
 //                (k_agc + k_fm in kernels_generic.hip) whatever the signal does; only the speed depends on it.
 //
-// Memory: a wave owns 64 streams.  Their next 128-byte lines are fetched cooperatively (8 lanes per line, so a
-// load instruction covers 8 whole lines), transposed through LDS to one line per lane, and the outputs go back
-// the same way (CF32: 8 lanes per 128-byte line, F32: 4 lanes per 64 bytes).
+// Memory: a workgroup owns 64 streams and has two waves.  The mover fetches the streams' next 128-byte lines
+// cooperatively (8 lanes per line, so a load instruction covers 8 whole lines), transposes them through an LDS ring
+// to one line per lane for the worker, and sends the outputs back the same way (CF32: 8 lanes per 128-byte line,
+// F32: 4 lanes per 64 bytes); the worker only ever touches LDS.
 #include "../../include/csdr.h"
 #include "csdr_internal.h"
 #include "fm_common.h"
 #include "agc_common.h"
 #include <cstdlib>
-#ifndef CSDR_AGC_PREFETCH
-#define CSDR_AGC_PREFETCH 0          // 1: block k + 1 is fetched while block k is worked on (measured slower, see k_agc_spec)
-#endif
 #ifndef CSDR_AGC_ABLATE
 #define CSDR_AGC_ABLATE 0      // timing experiments only: 1 no log/exp, 2 every block reloads the same (cached) lines, 4 no stores, 16 no compute
 #endif
@@ -163,54 +161,43 @@ __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, Agc
     else { oa = make_float4(y[0].x, y[0].y, y[1].x, y[1].y); ob = make_float4(y[2].x, y[2].y, y[3].x, y[3].y); }
 }
 
-// One lane per NS (channel, segment) streams; a wave owns 64 * NS consecutive segments of ONE channel (grid = channels x
-// segment groups), so every address is the uniform row plus a lane-derived segment.  Each block of 16 samples goes
-//   global --(8 lanes per 128-byte line)--> registers --> LDS (one line per stream) --> its lane, four samples at a
-//   time; the outputs are written back over the stream's own consumed input pieces and leave the same cooperative
-//   way.  With the loads branch-free the kernel moves 5.1 TB/s (each sample is read (W + L) / L times); NS = 2
-//   (two independent streams per lane) is kept in the template but only NS = 1 is instantiated: it measured slower.
-// The workgroup IS one wave: LDS accesses of one wave execute in order, so all that is needed between the
-// cooperative and the per-stream use of `buf` is that the compiler keeps the order.  __syncthreads() would also
-// wait for every outstanding global access (vmcnt(0)) -- i.e. for the previous block's stores to reach memory.
-__device__ __forceinline__ void wave_sync()
+// One lane per (channel, segment) stream; a workgroup is 64 consecutive segments of ONE channel (grid = channels x
+// segment groups, so every address is the uniform row plus a lane-derived segment) served by TWO waves:
+//   * the worker (wave 0) runs the recurrence: block k of 16 samples per stream comes out of an LDS ring slot one line
+//     per lane, four samples at a time, and the outputs go back over the stream's own consumed input pieces;
+//   * the mover (wave 1) does everything that waits for memory: while block k is worked on it writes block k + 1
+//     (fetched during the previous iteration, 8 lanes per 128-byte line) into the next ring slot, issues the loads of
+//     block k + 2 and stores the outputs of block k - 1 as whole lines.
+// One LDS-only barrier per block (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() would drain the loads in
+// flight).  With a single wave doing load -> LDS -> arithmetic -> LDS -> store one after the other nothing overlapped:
+// at the segment lengths that keep the warm-up re-reads low there are too few streams for the other waves of a SIMD
+// to cover for it (0.44 ms per 67 M samples however the arithmetic was trimmed; data path alone 0.36, arithmetic
+// alone 0.33).
+__device__ __forceinline__ void lds_barrier()
 {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool FM, int NS, bool PAIRS>
-__global__ __launch_bounds__(64, 3) void k_agc_spec(TailArgs A, uint32_t groups)   // <= 168 VGPRs: 3 waves per SIMD
+template <bool FM, bool PAIRS>
+__global__ __launch_bounds__(128, 2) void k_agc_spec(TailArgs A, uint32_t groups)   // <= 256 VGPRs
 {
-    __shared__ float4 buf[NS][64 * 8];
-    const int lane = threadIdx.x;
-    const uint32_t c = blockIdx.x / groups, sbase = (blockIdx.x % groups) * 64u * NS;   // uniform: channel, first segment
+    __shared__ float4 ring[3][64 * 8];
+    const int lane = threadIdx.x & 63;
+    const bool mover = threadIdx.x >= 64;                       // wave-uniform
+    const uint32_t c = blockIdx.x / groups, sbase = (blockIdx.x % groups) * 64u;   // uniform: channel, first segment
     const size_t row = (size_t)c * A.nf;
     const uint32_t nblk = (A.W + A.L) / 16u, kreal = A.W / 16u;
     const int pc = lane & 7;
 
-    AgcSeg q[NS];
-    uint32_t sg[NS], endv[NS];
-    bool mine[NS];
-#pragma unroll
-    for (int u = 0; u < NS; u++) {
-        sg[u] = sbase + 64u * u + lane;
-        mine[u] = sg[u] < A.nseg;
-        endv[u] = mine[u] ? min(A.nf, sg[u] * A.L + A.L) : 0u;
-        const AgcState s0 = A.st_in[c];
-        q[u].g = s0.g; q[u].y2 = s0.y2; q[u].mode = (int32_t)s_encode(s0.mode, s0.timer); q[u].timer = 0;
-        const float2 r0 = FM ? A.rp_in[c] : make_float2(0.f, 0.f);
-        q[u].rx = r0.x; q[u].ry = r0.y; q[u].pad0 = q[u].pad1 = 0;
-    }
-
-    // block k of set u: instruction m of the cooperative access handles stream 8m + (lane >> 3).  Branch-free (clamped
+    // block k: instruction m of the cooperative access handles stream 8m + (lane >> 3).  Branch-free (clamped
     // address, invalid halves zeroed afterwards) so that the eight loads are in flight together: with a branch per
     // load the compiler waits for each one before the next and the block pays eight memory latencies in a row.
     const size_t total = (size_t)A.C * A.nf;
-    auto load_block = [&](uint32_t k, int u, float4 (&ld)[8]) {
+    auto load_block = [&](uint32_t k, float4 (&ld)[8]) {
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-            const uint32_t ss = sbase + 64u * u + 8 * m + (lane >> 3);
-            const int32_t t = (int32_t)(ss * A.L) - (int32_t)A.W + (int32_t)(16 * ((CSDR_AGC_ABLATE & 2) ? (k >= kreal ? kreal : 0u) : k)) + 2 * pc;   // first of the piece's two samples
+            const uint32_t ss = sbase + 8 * m + (lane >> 3);
+            const int32_t t = (int32_t)(ss * A.L) - (int32_t)A.W + (int32_t)(16 * k) + 2 * pc;   // first of the piece's two samples
             const uint32_t e = min(A.nf, ss * A.L + A.L);
             const bool ok0 = ss < A.nseg && t >= 0 && (uint32_t)t < e, ok1 = ss < A.nseg && t >= 0 && (uint32_t)t + 1 < e;
             const size_t idx = row + (uint32_t)max(t, 0);
@@ -221,164 +208,161 @@ __global__ __launch_bounds__(64, 3) void k_agc_spec(TailArgs A, uint32_t groups)
         }
     };
 
-    // Interior blocks -- all 64 streams of the wave exist and the block lies inside every stream's range (all but the
+    // Interior blocks -- all 64 streams of the group exist and the block lies inside every stream's range (all but the
     // first W samples of a row and its ragged end) -- need no range tests at all: one uniform base pointer and a
     // 32-bit lane offset per piece.  The general path's clamps, masks and 64-bit addresses cost as many VALU
-    // instructions per block as the sixteen warm-up steps themselves.
-    const bool wave_full = NS == 1 && PAIRS && sbase + 64u <= A.nseg;
+    // instructions per block as sixteen warm-up steps.
+    const bool group_full = PAIRS && sbase + 64u <= A.nseg;
     const int64_t t_first = (int64_t)sbase * A.L - (int64_t)A.W;                    // stream 0's sample at k = 0
     const int64_t t_lastend = (int64_t)(sbase + 63u) * A.L - (int64_t)A.W + 15;     // stream 63's last sample at k = 0
     const char *wbase = reinterpret_cast<const char *>(A.Z + row) + t_first * 8;    // uniform; dereferenced on interior blocks only
     const uint32_t voff0 = ((uint32_t)(lane >> 3) * A.L + 2u * (uint32_t)pc) * 8u;  // bytes: my piece of stream lane >> 3
     const uint32_t mstep = 64u * A.L;                                               // bytes: eight streams further
-
-    static_assert(NS == 1, "the block pipeline below holds one stream set per lane");
-    auto is_inner = [&](uint32_t k) { return wave_full && t_first + 16 * (int64_t)k >= 0 && t_lastend + 16 * (int64_t)k < (int64_t)A.nf; };
+    auto is_inner = [&](uint32_t k) { return group_full && t_first + 16 * (int64_t)k >= 0 && t_lastend + 16 * (int64_t)k < (int64_t)A.nf; };
     // block k's eight pieces -> registers (not waited for here on interior blocks: nothing touches the data)
     auto fetch = [&](uint32_t k, float4 (&ld)[8]) {
         if (is_inner(k)) {
 #pragma unroll
-            for (int m = 0; m < 8; m++)
-                ld[m] = *reinterpret_cast<const float4 *>(wbase + (voff0 + (uint32_t)m * mstep + 128u * ((CSDR_AGC_ABLATE & 2) ? (k >= kreal ? kreal : 0u) : k)));
-        } else load_block(k, 0, ld);
+            for (int m = 0; m < 8; m++) ld[m] = *reinterpret_cast<const float4 *>(wbase + (voff0 + (uint32_t)m * mstep + 128u * ((CSDR_AGC_ABLATE & 2) ? (k >= kreal ? kreal : 0u) : k)));
+        } else load_block(k, ld);
     };
 
-    // CSDR_AGC_PREFETCH = 1 fetches block k + 1 while block k is worked on (32 more VGPRs).  Measured per 67 M samples
-    // (L = 384 / 768 / 1024): 489 / 471 / 494 us with, 493 / 441 / 459 us without -- left off.  Ablations at L = 1024
-    // (one wave per SIMD): data path alone 333 us, arithmetic alone 339 us, neither 90 us, both 436-485 us.
-    float4 ld[8];
-    if (CSDR_AGC_PREFETCH) fetch(0, ld);
-    for (uint32_t k = 0; k < nblk; k++) {
-        const bool inner = is_inner(k);
-        if (!CSDR_AGC_PREFETCH) fetch(k, ld);
-        wave_sync();                                        // previous block's buffers consumed
+    // outputs of block k (>= kreal) leave as whole lines
+    auto store_block = [&](uint32_t k, const float4 *buf) {
+        if ((CSDR_AGC_ABLATE & 4) && A.nf != 0xffffffffu) return;
+        const uint32_t tb = 16 * (k - kreal);
+        if (is_inner(k) && (!FM || (row & 3) == 0)) {
+            // interior block, 16-byte aligned rows: the same uniform-base addressing as the loads
+            if (FM) {
+                char *obase = reinterpret_cast<char *>((float *)A.out + row + (size_t)sbase * A.L + tb);
+                const uint32_t off = ((uint32_t)(lane >> 2) * A.L + 4u * (uint32_t)(lane & 3)) * 4u;
 #pragma unroll
-        for (int m = 0; m < 8; m++) buf[0][slot8(8 * m + (lane >> 3), pc)] = ld[m];
-        wave_sync();
-        if (CSDR_AGC_PREFETCH && k + 1 < nblk) fetch(k + 1, ld);
-
-        int32_t t0[NS];
-        bool live[NS], full = true, anylive = false;
+                for (int m = 0; m < 4; m++)
+                    *reinterpret_cast<float4 *>(obase + (off + (uint32_t)m * mstep)) = buf[slot8(16 * m + (lane >> 2), lane & 3)];
+            } else {
+                char *obase = reinterpret_cast<char *>((float2 *)A.out + row + (size_t)sbase * A.L + tb);
 #pragma unroll
-        for (int u = 0; u < NS; u++) {
-            t0[u] = (int32_t)(sg[u] * A.L) - (int32_t)A.W + (int32_t)(16 * k);
-            if (mine[u] && k == kreal) A.seg_start[(size_t)c * A.nseg + sg[u]] = q[u];   // state at the segment start, after the warm-up
-            live[u] = inner || (t0[u] >= 0 && (uint32_t)t0[u] < endv[u]);
-            full = full && (inner || !live[u] || (uint32_t)t0[u] + 16 <= endv[u]);
-            anylive = anylive || live[u];
+                for (int m = 0; m < 8; m++)
+                    *reinterpret_cast<float4 *>(obase + (voff0 + (uint32_t)m * mstep)) = buf[slot8(8 * m + (lane >> 3), pc)];
+            }
+            return;
         }
-        if ((CSDR_AGC_ABLATE & 16)) {
-        } else if (anylive && k < kreal) {
+        if (FM) {
+            float *outp = (float *)A.out;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int j = 16 * m + (lane >> 2), p4 = lane & 3;
+                const uint32_t ss = sbase + j;
+                if (ss < A.nseg) {
+                    const uint32_t t = ss * A.L + tb + 4 * p4, e = min(A.nf, ss * A.L + A.L);
+                    const float4 v = buf[slot8(j, p4)];
+                    const size_t idx = row + t;
+                    float *dst = outp + idx;
+                    if (t + 4 <= e && (idx & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
+                    else {
+                        if (t < e) dst[0] = v.x;
+                        if (t + 1 < e) dst[1] = v.y;
+                        if (t + 2 < e) dst[2] = v.z;
+                        if (t + 3 < e) dst[3] = v.w;
+                    }
+                }
+            }
+        } else {
+            float2 *outp = (float2 *)A.out;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const uint32_t ss = sbase + 8 * m + (lane >> 3);
+                if (ss < A.nseg) {
+                    const uint32_t t = ss * A.L + tb + 2 * pc, e = min(A.nf, ss * A.L + A.L);
+                    const float4 v = buf[slot8(8 * m + (lane >> 3), pc)];
+                    const size_t idx = row + t;
+                    float2 *dst = outp + idx;
+                    if (t + 2 <= e && (idx & 1) == 0) *reinterpret_cast<float4 *>(dst) = v;
+                    else {
+                        if (t < e) dst[0] = make_float2(v.x, v.y);
+                        if (t + 1 < e) dst[1] = make_float2(v.z, v.w);
+                    }
+                }
+            }
+        }
+    };
+
+    // the worker's stream
+    const uint32_t sg = sbase + lane;
+    const bool mine = sg < A.nseg;
+    const uint32_t endv = mine ? min(A.nf, sg * A.L + A.L) : 0u;
+    AgcSeg q;
+    {
+        const AgcState s0 = A.st_in[c];
+        q.g = s0.g; q.y2 = s0.y2; q.mode = (int32_t)s_encode(s0.mode, s0.timer); q.timer = 0;
+        const float2 r0 = FM ? A.rp_in[c] : make_float2(0.f, 0.f);
+        q.rx = r0.x; q.ry = r0.y; q.pad0 = q.pad1 = 0;
+    }
+    auto work_block = [&](uint32_t k, float4 *buf) {
+        const int32_t t0 = (int32_t)(sg * A.L) - (int32_t)A.W + (int32_t)(16 * k);
+        if (mine && k == kreal) A.seg_start[(size_t)c * A.nseg + sg] = q;       // state at the segment start, after the warm-up
+        const bool inner = is_inner(k);
+        const bool live = inner || (t0 >= 0 && (uint32_t)t0 < endv);
+        const bool full = inner || !live || (uint32_t)t0 + 16 <= endv;
+        if ((CSDR_AGC_ABLATE & 16)) return;
+        if (k < kreal) {
             // warm-up block (always whole): only the state matters -- no freqdem, nothing stored
+            if (live) {
+#pragma unroll 1
+                for (int h = 0; h < 4; h++) {
+                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
+                    float4 oa, ob;
+                    agc_quad<false, false>(va, vb, q, A.p, A.ref, 0u, 0u, oa, ob);
+                    if (FM) { q.rx = ob.z; q.ry = ob.w; }       // r' = the last (possibly muted) AGC output
+                }
+            }
+        } else if (__builtin_amdgcn_ballot_w64(!full) == 0ull) {
+            if (live) {
+#pragma unroll 1
+                for (int h = 0; h < 4; h++) {
+                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
+                    float4 oa, ob;
+                    agc_quad<FM, false>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, endv, oa, ob);
+                    // in place: output piece h (F32) / pieces 2h, 2h+1 (CF32) over input pieces already consumed
+                    if (FM) buf[slot8(lane, h)] = oa;
+                    else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
+                }
+            }
+        } else if (live) {
 #pragma unroll 1
             for (int h = 0; h < 4; h++) {
-#pragma unroll
-                for (int u = 0; u < NS; u++) {
-                    if (live[u]) {
-                        const float4 va = buf[u][slot8(lane, 2 * h)], vb = buf[u][slot8(lane, 2 * h + 1)];
-                        float4 oa, ob;
-                        agc_quad<false, false>(va, vb, q[u], A.p, A.ref, 0u, 0u, oa, ob);
-                        if (FM) { q[u].rx = ob.z; q[u].ry = ob.w; }     // r' = the last (possibly muted) AGC output
-                    }
-                }
-            }
-        } else if (anylive) {
-            if (full) {
-#pragma unroll 1
-                for (int h = 0; h < 4; h++) {
-#pragma unroll
-                    for (int u = 0; u < NS; u++) {
-                        if (live[u]) {
-                            const float4 va = buf[u][slot8(lane, 2 * h)], vb = buf[u][slot8(lane, 2 * h + 1)];
-                            float4 oa, ob;
-                            agc_quad<FM, false>(va, vb, q[u], A.p, A.ref, (uint32_t)t0[u] + 4 * h, endv[u], oa, ob);
-                            // in place: output piece h (F32) / pieces 2h, 2h+1 (CF32) over input pieces already consumed
-                            if (FM) buf[u][slot8(lane, h)] = oa;
-                            else { buf[u][slot8(lane, 2 * h)] = oa; buf[u][slot8(lane, 2 * h + 1)] = ob; }
-                        }
-                    }
-                }
-            } else {
-#pragma unroll 1
-                for (int h = 0; h < 4; h++) {
-#pragma unroll
-                    for (int u = 0; u < NS; u++) {
-                        if (live[u]) {
-                            const float4 va = buf[u][slot8(lane, 2 * h)], vb = buf[u][slot8(lane, 2 * h + 1)];
-                            float4 oa, ob;
-                            agc_quad<FM, true>(va, vb, q[u], A.p, A.ref, (uint32_t)t0[u] + 4 * h, endv[u], oa, ob);
-                            if (FM) buf[u][slot8(lane, h)] = oa;
-                            else { buf[u][slot8(lane, 2 * h)] = oa; buf[u][slot8(lane, 2 * h + 1)] = ob; }
-                        }
-                    }
-                }
+                const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
+                float4 oa, ob;
+                agc_quad<FM, true>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, endv, oa, ob);
+                if (FM) buf[slot8(lane, h)] = oa;
+                else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
             }
         }
-        if (k >= kreal && !((CSDR_AGC_ABLATE & 4) && A.nf != 0xffffffffu)) {
-            // outputs leave as whole lines
-            wave_sync();
-            const uint32_t tb = 16 * (k - kreal);
-            if (inner && (!FM || (row & 3) == 0)) {
-                // interior block, 16-byte aligned rows: the same uniform-base addressing as the loads
-                if (FM) {
-                    char *obase = reinterpret_cast<char *>((float *)A.out + row + (size_t)sbase * A.L + tb);
-                    const uint32_t off = ((uint32_t)(lane >> 2) * A.L + 4u * (uint32_t)(lane & 3)) * 4u;
+    };
+
+    // iteration `it`: the mover fills slot it % 3 with block it and empties slot (it - 2) % 3, the worker is on
+    // block it - 1 in slot (it - 1) % 3.  The mover keeps TWO blocks in flight (it + 1 and it + 2, two register sets
+    // used alternately -- hence the loop runs in pairs): with one, an iteration lasted a memory round trip.
+    float4 lda[8], ldb[8];
+    uint32_t s_in = 0, s_wk = 2, s_out = 1;                     // it % 3, (it - 1) % 3, (it - 2) % 3
+    if (mover) { fetch(0, lda); if (1 < nblk) fetch(1, ldb); }
+    auto iteration = [&](uint32_t it, float4 (&ld)[8]) {       // ld holds block it (mover)
+        if (mover) {
+            if (it < nblk) {
 #pragma unroll
-                    for (int m = 0; m < 4; m++)
-                        *reinterpret_cast<float4 *>(obase + (off + (uint32_t)m * mstep)) = buf[0][slot8(16 * m + (lane >> 2), lane & 3)];
-                } else {
-                    char *obase = reinterpret_cast<char *>((float2 *)A.out + row + (size_t)sbase * A.L + tb);
-#pragma unroll
-                    for (int m = 0; m < 8; m++)
-                        *reinterpret_cast<float4 *>(obase + (voff0 + (uint32_t)m * mstep)) = buf[0][slot8(8 * m + (lane >> 3), pc)];
-                }
-                continue;
+                for (int m = 0; m < 8; m++) ring[s_in][slot8(8 * m + (lane >> 3), pc)] = ld[m];
+                if (it + 2 < nblk) fetch(it + 2, ld);
             }
-#pragma unroll
-            for (int u = 0; u < NS; u++) {
-                if (FM) {
-                    float *outp = (float *)A.out;
-#pragma unroll
-                    for (int m = 0; m < 4; m++) {
-                        const int j = 16 * m + (lane >> 2), p4 = lane & 3;
-                        const uint32_t ss = sbase + 64u * u + j;
-                        if (ss < A.nseg) {
-                            const uint32_t t = ss * A.L + tb + 4 * p4, e = min(A.nf, ss * A.L + A.L);
-                            const float4 v = buf[u][slot8(j, p4)];
-                            const size_t idx = row + t;
-                            float *dst = outp + idx;
-                            if (t + 4 <= e && (idx & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
-                            else {
-                                if (t < e) dst[0] = v.x;
-                                if (t + 1 < e) dst[1] = v.y;
-                                if (t + 2 < e) dst[2] = v.z;
-                                if (t + 3 < e) dst[3] = v.w;
-                            }
-                        }
-                    }
-                } else {
-                    float2 *outp = (float2 *)A.out;
-#pragma unroll
-                    for (int m = 0; m < 8; m++) {
-                        const uint32_t ss = sbase + 64u * u + 8 * m + (lane >> 3);
-                        if (ss < A.nseg) {
-                            const uint32_t t = ss * A.L + tb + 2 * pc, e = min(A.nf, ss * A.L + A.L);
-                            const float4 v = buf[u][slot8(8 * m + (lane >> 3), pc)];
-                            const size_t idx = row + t;
-                            float2 *dst = outp + idx;
-                            if (t + 2 <= e && (idx & 1) == 0) *reinterpret_cast<float4 *>(dst) = v;
-                            else {
-                                if (t < e) dst[0] = make_float2(v.x, v.y);
-                                if (t + 1 < e) dst[1] = make_float2(v.z, v.w);
-                            }
-                        }
-                    }
-                }
-            }
-        }
+            if (it >= 2 && it - 2 >= kreal && it - 2 < nblk) store_block(it - 2, ring[s_out]);
+        } else if (it >= 1 && it - 1 < nblk) work_block(it - 1, ring[s_wk]);
+        lds_barrier();
+        s_out = s_wk; s_wk = s_in; s_in = s_in == 2 ? 0 : s_in + 1;
+    };
+    for (uint32_t it = 0; it < nblk + 2; it += 2) {
+        iteration(it, lda);
+        iteration(it + 1, ldb);                                 // it + 1 may be nblk + 2: nothing left to do but the barrier
     }
-#pragma unroll
-    for (int u = 0; u < NS; u++) if (mine[u]) A.seg_end[(size_t)c * A.nseg + sg[u]] = q[u];
+    if (!mover && mine) A.seg_end[(size_t)c * A.nseg + sg] = q;
 }
 
 // verification + exact fall-back, one wave per channel.  All boundaries are checked in parallel against the
@@ -424,30 +408,27 @@ __global__ __launch_bounds__(64) void k_agc_fix(TailArgs A, AgcState *st_out, fl
 }  // namespace
 
 struct AgcTailPlan {
-    uint32_t C = 0, max_nf = 0, L = 384, W = 1024, max_seg = 0;
+    uint32_t C = 0, max_nf = 0, L = 0, Lmin = 384, W = 1024, max_seg = 0;   // L > 0: fixed by CSDR_AGC_L
     AgcSeg *d_start = nullptr, *d_end = nullptr;
     AgcState *d_st_tmp = nullptr;
     unsigned *d_stats = nullptr;
-    uint32_t lanes_target = 98304;       // 1.5 waves per SIMD
+    uint32_t wg_slots = 1024;            // workgroups the device holds at once
 };
 
 int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
 {
     AgcTailPlan *p = new AgcTailPlan();
     p->C = C; p->max_nf = max_nf;
-    if (const char *e = getenv("CSDR_AGC_L")) p->L = (uint32_t)atol(e);
+    if (const char *e = getenv("CSDR_AGC_L")) { p->L = (uint32_t)atol(e); p->L = (p->L + 15u) / 16u * 16u; if (p->L < 16) p->L = 16; }
     if (const char *e = getenv("CSDR_AGC_W")) p->W = (uint32_t)atol(e);
-    p->L = (p->L + 15u) / 16u * 16u; if (p->L < 16) p->L = 16;
     p->W = (p->W + 15u) / 16u * 16u;
     {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        // streams the segment length aims for: 1.5 waves per SIMD.  More, shorter segments re-read more warm-up
-        // (the kernel turns bandwidth-bound: L = 384 at 2.75 waves per SIMD 0.49 ms per 67 M samples), fewer leave a
-        // lone wave per SIMD to its ~350-cycle dependent step (L = 1024: 0.46 ms); L = 768 at 1.4: 0.44 ms
-        p->lanes_target = (uint32_t)cus * 4u * 64u * 3u / 2u;
-        if (const char *e = getenv("CSDR_AGC_WAVES")) { const uint32_t wps = (uint32_t)atol(e); p->lanes_target = (uint32_t)cus * 4u * 64u * (wps ? wps : 1u); }
+        // k_agc_spec: two waves per workgroup at <= 256 VGPRs -> two waves per SIMD -> four workgroups per CU
+        p->wg_slots = (uint32_t)cus * 4u;
+        if (const char *e = getenv("CSDR_AGC_WGS")) p->wg_slots = (uint32_t)cus * (uint32_t)(atol(e) > 0 ? atol(e) : 1);
     }
     p->max_seg = (max_nf + 15u) / 16u + 1;                      // L >= 16
     const size_t n = (size_t)C * p->max_seg;
@@ -485,10 +466,19 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
 {
     if (!nf || !p->C) return 0;
     if ((uint64_t)p->C * nf >= (1ull << 32)) { set_error("agc tail: C*nf = %llu samples exceeds 2^32", (unsigned long long)p->C * nf); return CSDR_ERR_SIZE; }
-    // segment length: the configured L, doubled while that gives more streams than the target (longer segments
-    // waste less on the warm-up)
+    // Segment length: as many 64-segment groups per channel as the device holds workgroups at once (one round, every
+    // SIMD busy), not more -- shorter segments re-read more warm-up ((W + L) / L times the data) and a second round of
+    // workgroups costs more than it brings.  L / 16 is made odd: with a power-of-two L the 64 streams of a group and
+    // the groups of all channels hit the same few HBM channels at every step (L = 1024: 0.37 ms, 1040: 0.34 ms).
     uint32_t L = p->L;
-    while ((uint64_t)p->C * ((nf + L - 1) / L) > p->lanes_target && L < (1u << 20)) L *= 2;
+    if (!L) {
+        const uint32_t gmax = p->wg_slots / p->C ? p->wg_slots / p->C : 1u;
+        const uint64_t nseg_t = 64ull * gmax;
+        L = (uint32_t)((nf + nseg_t - 1) / nseg_t);
+        L = (L + 15u) / 16u * 16u;
+        if (L < p->Lmin) L = p->Lmin;
+        if (((L / 16u) & 1u) == 0) L += 16u;
+    }
     const uint32_t nseg = (nf + L - 1) / L;
     if (nseg > p->max_seg) { set_error("agc tail: internal segment bound"); return CSDR_ERR_INVALID; }
     TailArgs A{};
@@ -498,13 +488,13 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     // 16-byte load that never reaches past the buffer
     const bool pairs = (nf & 1u) == 0 && (uint64_t)p->C * nf >= 2;
     const uint32_t groups = (nseg + 63u) / 64u;
-    const dim3 grid(p->C * groups), block(64);
+    const dim3 grid(p->C * groups), block(128);
     if (pairs) {
-        if (fm) hipLaunchKernelGGL((k_agc_spec<true, 1, true>), grid, block, 0, s, A, groups);
-        else hipLaunchKernelGGL((k_agc_spec<false, 1, true>), grid, block, 0, s, A, groups);
+        if (fm) hipLaunchKernelGGL((k_agc_spec<true, true>), grid, block, 0, s, A, groups);
+        else hipLaunchKernelGGL((k_agc_spec<false, true>), grid, block, 0, s, A, groups);
     } else {
-        if (fm) hipLaunchKernelGGL((k_agc_spec<true, 1, false>), grid, block, 0, s, A, groups);
-        else hipLaunchKernelGGL((k_agc_spec<false, 1, false>), grid, block, 0, s, A, groups);
+        if (fm) hipLaunchKernelGGL((k_agc_spec<true, false>), grid, block, 0, s, A, groups);
+        else hipLaunchKernelGGL((k_agc_spec<false, false>), grid, block, 0, s, A, groups);
     }
     // the fix-up reads st_in through the segment records only, so st can be overwritten in place
     if (fm) hipLaunchKernelGGL(k_agc_fix<true>, dim3(p->C), dim3(64), 0, s, A, st, rp_out, p->d_stats);
