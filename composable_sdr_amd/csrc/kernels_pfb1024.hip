@@ -28,6 +28,9 @@ namespace csdr {
 
 namespace {
 
+#ifndef CSDR_ABLATE1024
+#define CSDR_ABLATE1024 0        // timing experiments only: 1 skip DFT pass 1, 2 skip pass 2, 4 skip the FM tail arithmetic
+#endif
 constexpr int PM = 1024, PT = 8, PP = 14;       // channels, frames per tile, taps per branch
 constexpr int PAS = 17 * 4;                     // padded stride between k1 rows of the pass-1 image (as k_fft_r16<4>)
 
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
 
         v2fg v[16];
         // ---- pass 1: radix 16 over n1 (stride 64) for (frame, m): threads 0..511 ----
-        if (tid_i < 512) {
+        if (tid_i < 512 && !(CSDR_ABLATE1024 & 1)) {
             const int fr = tid_i >> 6, m = tid_i & 63;
 #pragma unroll
             for (int n1 = 0; n1 < 16; n1++) { const float2 x = bufB[fr * PM + 64 * n1 + m]; v[n1] = (v2fg){x.x, x.y}; }
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(1024) void k_pfb1024(Pfb1024Args A)
         }
         __syncthreads();
         // ---- pass 2: radix 16 over n2 for (frame, k1, n3) ----
-        if (tid_i < 512) {
+        if (tid_i < 512 && !(CSDR_ABLATE1024 & 2)) {
             const int n3 = tid_i & 3, k1 = (tid_i >> 2) & 15, fr = tid_i >> 6;
 #pragma unroll
             for (int n2 = 0; n2 < 16; n2++) { const float2 x = bufA[fr * 16 * PAS + k1 * PAS + 4 * n2 + n3]; v[n2] = (v2fg){x.x, x.y}; }
