@@ -10,10 +10,11 @@
 //                gain forgets its start state at |lambda| = 0.95 per sample), records the state it reaches at
 //                the segment start, then produces the segment's outputs and records its end state.
 //                Segments that begin <= W samples into the call start at sample 0 from the true state instead.
-//   k_agc_fix  : one lane per channel walks the segments in order.  A segment whose recorded start state is
-//                BITWISE equal to the true end state of the segment before it is, by determinism, exactly what
-//                the sequential recurrence produces; any other segment is recomputed sequentially from the
-//                true state.  The result is therefore bit-identical to the one-lane-per-channel kernel
+//   k_agc_fix  : one thread per segment boundary.  A segment whose recorded start state is BITWISE equal to the end
+//                state of the segment before it is, by determinism (and induction from segment 0, which starts from
+//                the true state), exactly what the sequential recurrence produces; segments for which that does not
+//                hold are recomputed from the end state in front of them, in parallel, round after round until every
+//                boundary holds.  The result is therefore bit-identical to the one-lane-per-channel kernel
 //                (k_agc + k_fm in kernels_generic.hip) whatever the signal does; only the speed depends on it.
 //
 // Memory: a workgroup owns 64 streams and has two waves.  The mover fetches the streams' next 128-byte lines
@@ -365,44 +366,74 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec(TailArgs A, uint32_t groups
     if (!mover && mine) A.seg_end[(size_t)c * A.nseg + sg] = q;
 }
 
-// verification + exact fall-back, one wave per channel.  All boundaries are checked in parallel against the
-// recorded (speculative) end states; up to the first boundary that fails, those ARE the true states, so the
-// common case ends there.  From the first failure on, lane 0 walks the remaining segments in order: a segment
-// whose recorded start state equals the true state is taken as recorded, any other is recomputed.
+// verification + exact repair, one workgroup per channel, one thread per segment boundary.
+// A boundary holds when the state the segment was started from (recorded, S_s) is BITWISE the end state of the
+// segment before it (E_{s-1}).  S_0 is the true state, so when every boundary holds every segment is, by
+// determinism, exactly what the sequential recurrence produces.  Boundaries that do not hold are repaired in
+// rounds: every failing segment is recomputed -- all of them in parallel, one lane each -- from the CURRENT E_{s-1},
+// which also becomes its S_s.  After a round the first failing segment of the row is final, so the loop ends after
+// at most nseg rounds; in practice failures are isolated and one or two rounds do (a repaired segment almost always
+// runs into the end state it had before).  Reads and writes of a round are separated by barriers, so nobody compares
+// against a half-written record.
 template <bool FM>
-__global__ __launch_bounds__(64) void k_agc_fix(TailArgs A, AgcState *st_out, float2 *rp_out, unsigned *stats)
+__device__ __forceinline__ void repair_segment(const TailArgs &A, uint32_t c, uint32_t s, AgcSeg &cur)
 {
-    const uint32_t c = blockIdx.x, lane = threadIdx.x;
-    const AgcSeg *ss = A.seg_start + (size_t)c * A.nseg, *se = A.seg_end + (size_t)c * A.nseg;
-    uint32_t first_bad = A.nseg;
-    for (uint32_t s = 1 + lane; s < A.nseg; s += 64) {
-        const AgcSeg e = se[s - 1], st = ss[s];
-        if (!same_state(e, st, FM)) { first_bad = s; break; }
-    }
+    const uint32_t t0 = s * A.L, t1 = min(A.nf, t0 + A.L);
+    const size_t rowo = (size_t)c * A.nf;
+    const float2 *row = A.Z + rowo;
+    auto one = [&](float2 x, uint32_t t) {
+        const float2 y = agc_tail_step(x, cur, A.p);
+        if (FM) {
+            ((float *)A.out)[rowo + t] = fm_tail_sample(make_float2(cur.rx, cur.ry), y, A.ref);
+            cur.rx = y.x; cur.ry = y.y;
+        } else ((float2 *)A.out)[rowo + t] = y;
+    };
+    uint32_t t = t0;
+    if (((rowo + t) & 1) && t < t1) { one(row[t], t); t++; }    // up to a 16-byte boundary
+    for (; t + 16 <= t1; t += 16) {                             // a line per iteration, all eight loads in flight
+        float4 v[8];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) first_bad = min(first_bad, (uint32_t)__shfl_xor((int)first_bad, d));
-    if (lane != 0) return;
-    AgcSeg cur = se[first_bad - 1];                             // true state in front of segment first_bad
-    unsigned redone = 0;
-    for (uint32_t s = first_bad; s < A.nseg; s++) {
-        const AgcSeg st = ss[s];
-        if (same_state(cur, st, FM)) { cur = se[s]; continue; }
-        redone++;
-        const uint32_t t0 = s * A.L, t1 = min(A.nf, t0 + A.L);
-        const float2 *row = A.Z + (size_t)c * A.nf;
-        for (uint32_t t = t0; t < t1; t++) {
-            const float2 y = agc_tail_step(row[t], cur, A.p);
-            if (FM) {
-                ((float *)A.out)[(size_t)c * A.nf + t] = fm_tail_sample(make_float2(cur.rx, cur.ry), y, A.ref);
-                cur.rx = y.x; cur.ry = y.y;
-            } else ((float2 *)A.out)[(size_t)c * A.nf + t] = y;
-        }
+        for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const float4 *>(row + t + 2 * i);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { one(make_float2(v[i].x, v[i].y), t + 2 * i); one(make_float2(v[i].z, v[i].w), t + 2 * i + 1); }
     }
-    AgcState o; o.g = cur.g; o.y2 = cur.y2; s_decode((uint32_t)cur.mode, A.p.timeout, o.mode, o.timer);
-    st_out[c] = o;
-    if (FM) rp_out[c] = make_float2(cur.rx, cur.ry);
+    for (; t < t1; t++) one(row[t], t);
+}
+
+template <bool FM>
+__global__ __launch_bounds__(256) void k_agc_fix(TailArgs A, AgcState *st_out, float2 *rp_out, unsigned *stats)
+{
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    AgcSeg *ss = A.seg_start + (size_t)c * A.nseg, *se = A.seg_end + (size_t)c * A.nseg;
+    unsigned redone = 0;
+    for (uint32_t round = 0; round < A.nseg; round++) {
+        bool changed = false;
+        for (uint32_t base = 0; base + 1 < A.nseg; base += 256) {
+            const uint32_t s = base + 1 + tid;
+            bool need = false;
+            AgcSeg e;
+            if (s < A.nseg) { e = se[s - 1]; need = !same_state(e, ss[s], FM); }
+            __syncthreads();                                    // everybody has read before anybody writes
+            if (need) {
+                AgcSeg cur = e;
+                repair_segment<FM>(A, c, s, cur);
+                ss[s] = e; se[s] = cur;
+                changed = true; redone++;
+            }
+            __threadfence();
+            __syncthreads();                                    // records complete before the next chunk / round reads them
+            __threadfence();
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    if (tid == 0) {
+        const AgcSeg cur = se[A.nseg - 1];
+        AgcState o; o.g = cur.g; o.y2 = cur.y2; s_decode((uint32_t)cur.mode, A.p.timeout, o.mode, o.timer);
+        st_out[c] = o;
+        if (FM) rp_out[c] = make_float2(cur.rx, cur.ry);
+        if (c == 0) atomicAdd(&stats[0], A.C * (A.nseg - 1));
+    }
     if (redone) atomicAdd(&stats[1], redone);
-    if (c == 0) atomicAdd(&stats[0], A.C * (A.nseg - 1));
 }
 
 }  // namespace
@@ -497,8 +528,8 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
         else hipLaunchKernelGGL((k_agc_spec<false, false>), grid, block, 0, s, A, groups);
     }
     // the fix-up reads st_in through the segment records only, so st can be overwritten in place
-    if (fm) hipLaunchKernelGGL(k_agc_fix<true>, dim3(p->C), dim3(64), 0, s, A, st, rp_out, p->d_stats);
-    else hipLaunchKernelGGL(k_agc_fix<false>, dim3(p->C), dim3(64), 0, s, A, st, rp_out, p->d_stats);
+    if (fm) hipLaunchKernelGGL(k_agc_fix<true>, dim3(p->C), dim3(256), 0, s, A, st, rp_out, p->d_stats);
+    else hipLaunchKernelGGL(k_agc_fix<false>, dim3(p->C), dim3(256), 0, s, A, st, rp_out, p->d_stats);
     CSDR_HIP(hipGetLastError());
     return 0;
 }

@@ -649,6 +649,29 @@ def test_agc_tail_is_bit_identical_to_sequential(M, demod, mix, kind, monkeypatc
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("M,demod", [(64, "fm"), (16, "none")])
+def test_agc_tail_default_segment_rule_bit_identical(M, demod):
+    """the same with the segment length the plan picks on its own (no CSDR_AGC_L / _W): several 64-segment groups
+    per channel, the last one partly filled, ragged and odd chunk lengths"""
+    from composable_sdr_amd import _lib
+    frames = [30000, 28111, 4096, 27001]
+    nf = sum(frames)
+    x = _bursty(M, nf, 99 + M, "bursts")
+    kw = dict(channels=M, demod=demod, kf=0.3, agc=8.0, max_frames=max(frames))
+    a = cs.Chain(flags=_lib.FLAG_QUIET, **kw)
+    b = cs.Chain(flags=_lib.FLAG_QUIET | _lib.FLAG_AGC_SEQUENTIAL, **kw)
+    pos = 0
+    for f in frames:
+        xa = x[pos * M:(pos + f) * M]
+        ya, yb = a.process(xa), b.process(xa)
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32)), (M, demod, f, pos)
+        pos += f
+    checked, redone = a.agc_stats()
+    print(f"agc tail default rule M={M} {demod}: segments checked {checked}, recomputed {redone}")
+    assert checked > 4 * M
+    a.close(); b.close()
+
+
 def test_agc_tail_steady_state_needs_no_recompute():
     """on a stationary signal (the bench's) the speculation always verifies after the first call"""
     from composable_sdr_amd import _lib
