@@ -208,7 +208,7 @@ def main():
         res["agc_variant"] = {"value": round(v2, 1), "unit": "MS/s", "agc_db": 10.0, "ms_per_step": round(d2 / reps * 1e3, 4),
                               "path": ch2.path, "frames_per_step": nf, "steps": reps,
                               "strategy": "time-parallel AGC+squelch+freqdem tail: one lane per (channel, segment) with a warm-up, "
-                                          "segment boundaries verified bitwise, failures recomputed sequentially (exact)",
+                                          "segment boundaries verified bitwise, failing segments recomputed in parallel rounds until all hold (exact)",
                               "segments_checked": c1 - c0, "segments_recomputed": r1 - r0,
                               "hbm_roofline_frac_whole_step": round(v2 * 1e6 * alg_bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4)}
         ch2.close()
