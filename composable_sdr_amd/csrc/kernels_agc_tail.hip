@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void k_agc_fix(TailArgs A, AgcState *st_out, f
             bool need = false;
             AgcSeg e;
             if (s < A.nseg) { e = se[s - 1]; need = !same_state(e, ss[s], FM); }
-            __syncthreads();                                    // everybody has read before anybody writes
+            if (!__syncthreads_or(need)) continue;              // (also: everybody has read before anybody writes)
             if (need) {
                 AgcSeg cur = e;
                 repair_segment<FM>(A, c, s, cur);
