@@ -125,7 +125,36 @@ __global__ __launch_bounds__(256) void k_dc_tile(DcTileArgs D)
         }
     }
     __syncthreads();
-    {
+    const uint32_t tl = D.nco.tab_len;
+    if (nleft >= 4096u && D.do_mix && tl && (tl & (tl - 1)) == 0) {
+        // whole tile, tabulated NCO with a power-of-two period (the channelizer's pre-mix): no range tests, the
+        // period by a mask, and all sixteen table reads issued before the first one is needed.  The general loop below
+        // has a lane-varying `continue` in front of its loads (each of them then gets waited for on its own) and two
+        // 32-bit remainders per piece.
+        const float4 *R4 = reinterpret_cast<const float4 *>(R);
+        const int wave = tid >> 6, lane = tid & 63;
+        const uint32_t mask = tl - 1, base = D.nco.tab_pos + n0;
+        float4 yv[8];
+        float2 ca[8], cb[8];
+        uint32_t dst[8];
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
+            const int i = (slot & 7) ^ ((q >> 1) & 7);
+            const uint32_t p0 = (base + 16u * q + 2u * i) & mask;
+            yv[it] = R4[slot];
+            ca[it] = D.nco_tab[p0];
+            cb[it] = D.nco_tab[(p0 + 1) & mask];
+            dst[it] = 8u * q + i;
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const float sa = D.nco.up ? ca[it].y : -ca[it].y, sb = D.nco.up ? cb[it].y : -cb[it].y;
+            const float4 v = yv[it];
+            reinterpret_cast<float4 *>(D.y)[(size_t)b * 2048 + dst[it]] =
+                make_float4(v.x * ca[it].x - v.y * sa, v.x * sa + v.y * ca[it].x, v.z * cb[it].x - v.w * sb, v.z * sb + v.w * cb[it].x);
+        }
+    } else {
         const float4 *R4 = reinterpret_cast<const float4 *>(R);
         const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
