@@ -405,14 +405,24 @@ __global__ __launch_bounds__(256) void k_fft_r16(const float2 *__restrict__ X, f
 #pragma unroll
         for (int fr = 0; fr < F; fr++) red[fr * 256 + t] = part[fr];
         __syncthreads();
-        for (int d = 128; d >= 1; d >>= 1) {
-            if (t < d) {
+        // the same tree as before (t += t + d for d = 128 ... 1, so the sums round identically), but only the two levels
+        // that cross waves go through LDS and a barrier; the rest runs inside wave 0 on shuffles
+        if (t < 128) {
 #pragma unroll
-                for (int fr = 0; fr < F; fr++) { red[fr * 256 + t].x += red[fr * 256 + t + d].x; red[fr * 256 + t].y += red[fr * 256 + t + d].y; }
-            }
-            __syncthreads();
+            for (int fr = 0; fr < F; fr++) { red[fr * 256 + t].x += red[fr * 256 + t + 128].x; red[fr * 256 + t].y += red[fr * 256 + t + 128].y; }
         }
-        if (t < F && f0 + t < nf) Y[f0 + t] = red[t * 256];    // Y is the mixed output [nf] here
+        __syncthreads();
+        if (t < 64) {
+#pragma unroll
+            for (int fr = 0; fr < F; fr++) {
+                float2 x = red[fr * 256 + t];
+                const float2 u = red[fr * 256 + t + 64];
+                x.x += u.x; x.y += u.y;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { x.x += __shfl_down(x.x, d); x.y += __shfl_down(x.y, d); }
+                if (t == 0 && f0 + fr < nf) Y[f0 + fr] = x;     // Y is the mixed output [nf] here
+            }
+        }
     }
 }
 
