@@ -46,8 +46,9 @@ __device__ __forceinline__ int u_index(int n)
     return 2 * (8 * q + (i ^ ((q >> 1) & 7))) + (n & 1);
 }
 
+// FM: two workgroups per CU (212 VGPRs) beat three with 41 spilled dwords (186 -> 209-216 GS/s); DeNo fits three
 template <bool FM>
-__global__ __launch_bounds__(256, 3) void k_run64(SmallArgs SA)
+__global__ __launch_bounds__(256, FM ? 2 : 3) void k_run64(SmallArgs SA)
 {
     const TileArgs &A = SA.t;
     __shared__ __attribute__((aligned(16))) float2 R[RS_F2];
