@@ -12,7 +12,7 @@ resampler in front of `takeNArr`."""
 import struct
 import numpy as np
 
-from .pipes import Chain, ChainConfig, mixDown, mixUp, resampler
+from .pipes import Chain, ChainConfig, compose, idPipe, mixDown, mixUp, resampler, unPipe
 from .trans import Fold, compact, takeNArr
 
 
@@ -53,6 +53,13 @@ class _FusedFold(Fold):
             self.sinks[0].step(a[:0])                 # nx = 0 -> [empty]: only sink 1 sees it
             return self
         usable = len(a) // M * M                      # a ragged stream tail cannot be channelized
+        d = self.chain.decim                          # DeWBFM: firDecimator's n = length `div` m drops the leftover (Liquid.chs:495-497)
+        if d > 1:
+            usable = usable // (M * d) * (M * d)
+            if usable == 0:
+                for s in (self.sinks[:1] if (self.mixed or M == 1) else self.sinks):
+                    s.step(np.empty(0, dtype=np.float32))
+                return self
         y = self.chain.process(a[:usable])
         if self.mixed or M == 1:
             self.sinks[0].step(y.reshape(-1))
@@ -133,22 +140,17 @@ def sdr_process(filename, channels=1, demod="none", kf=0.3, agc=0.0, mix=False, 
     # (f = 2*pi*offset/fs; mixDown f if f > 0, mixUp (-f) if f < 0, :200-205), then the resampler
     # (rate = bandwidth / samplerate, 60 dB, identity when -b 0, :190-194)
     f = np.float32(2 * np.pi * offset / samplerate)
-    stages = []
+    offset_p = idPipe
     if f != 0:
-        stages.append(mixDown(float(f), max_samples=chunksize) if f > 0 else mixUp(float(-f), max_samples=chunksize))
+        offset_p = mixDown(float(f), max_samples=chunksize) if f > 0 else mixUp(float(-f), max_samples=chunksize)
+    resamp_p = idPipe
     if bandwidth != 0:
-        stages.append(resampler(float(np.float32(bandwidth / samplerate)), 60.0, max_samples=chunksize))
-    states = [p._start() for p in stages]
-    src = readFromFile(chunksize, filename)
-
-    def front(gen):
-        for a in gen:
-            for p, st in zip(stages, states):
-                a = p._process(st, a)
-            yield a
-    for a in takeNArr(numsamples, front(src) if stages else src):
-        fold.step(a)
-    fold.done()
-    for p, st in zip(stages, states):
-        p._done(st)
+        resamp_p = resampler(float(np.float32(bandwidth / samplerate)), 60.0, max_samples=chunksize)
+    process, cleanup = unPipe(compose(resamp_p, offset_p))       # (process, cleanup) <- unPipe (resampler . offset)
+    try:
+        for a in takeNArr(numsamples, process(readFromFile(chunksize, filename))):
+            fold.step(a)
+    finally:
+        fold.done()
+        cleanup()
     return names

@@ -4,6 +4,8 @@
 //
 //   Pipe<A,B>      Types.hs:51-55     { start, process, done } around one native handle
 //   compose        Types.hs:93-99     process2 >=> process1, done2 before done1
+//   idPipe         Types.hs:101-102   Category id
+//   unPipe         Types.hs:109-115   create now; (per-array map, cleanup) for the stream side
 //   Fold<A>        streamly Fold      step / done
 //   addPipe        Types.hs:117-131   downstream start first, then create; done: destroy, then downstream
 //   takeNArr       Trans.hs:33-56     pass arrays until n samples, trimming the last one
@@ -51,6 +53,31 @@ template <class A, class B, class C> Pipe<A, C> compose(Pipe<B, C> p1, Pipe<A, B
     p.process = [=](void *r, const A &a) { auto *rr = static_cast<R *>(r); return p1.process(rr->r1.get(), p2.process(rr->r2.get(), a)); };
     p.done = [=](void *r) { auto *rr = static_cast<R *>(r); p2.done(rr->r2.get()); p1.done(rr->r1.get()); };
     return p;
+}
+
+template <class A> Pipe<A, A> idPipe()
+{
+    Pipe<A, A> p;
+    p.start = []() { return std::shared_ptr<void>(); };
+    p.process = [](void *, const A &a) { return a; };
+    p.done = [](void *) {};
+    return p;
+}
+
+// unPipe (Types.hs:109-115): `r <- creat; return (S.mapM (process r), dest r)`.  The stream side here is a push
+// loop, so the transformer is the per-array function S.mapM would apply; `cleanup` is run once the stream has been
+// folded (SoapySDR.hs:206, :282).
+template <class A, class B> struct UnPiped {
+    std::function<B(const A &)> process;
+    std::function<void()> cleanup;
+};
+template <class A, class B> UnPiped<A, B> unPipe(Pipe<A, B> p)
+{
+    std::shared_ptr<void> r = p.start();
+    UnPiped<A, B> u;
+    u.process = [p, r](const A &a) { return p.process(r.get(), a); };
+    u.cleanup = [p, r]() { p.done(r.get()); };
+    return u;
 }
 
 // ---- Fold -------------------------------------------------------------------------------
@@ -230,12 +257,13 @@ template <class Out> Pipe<Array<cf32>, std::vector<Array<Out>>> fusedChain(const
         auto *h = static_cast<csdr_chain *>(r);
         const uint32_t M = o.channels;
         if (a.empty()) return std::vector<Array<Out>>{Array<Out>{}};          // nx = 0 -> [empty] (Liquid.chs:856-862)
-        const uint32_t usable = (uint32_t)(a.size() / M * M), nf = usable / M;
+        uint32_t usable = (uint32_t)(a.size() / M * M), nf = usable / M;
         const bool mixed = o.mix && M > 1;
         const uint32_t no = o.wbfm ? nf / o.decim : nf;                        // DeWBFM: nf div decim samples per channel
+        if (o.wbfm) { nf = no * o.decim; usable = nf * M; }                    // firDecimator drops the leftover (Liquid.chs:495-497)
         Array<Out> flat((size_t)(mixed ? no : (size_t)M * no));
         uint32_t n_out = 0;
-        check(csdr_chain_process(h, reinterpret_cast<const float *>(a.data()), usable, flat.data(), &n_out));
+        if (usable) check(csdr_chain_process(h, reinterpret_cast<const float *>(a.data()), usable, flat.data(), &n_out));
         std::vector<Array<Out>> outs;
         if (mixed || M == 1) { outs.push_back(std::move(flat)); return outs; }
         for (uint32_t k = 0; k < M; k++) outs.emplace_back(flat.begin() + (size_t)k * no, flat.begin() + (size_t)(k + 1) * no);

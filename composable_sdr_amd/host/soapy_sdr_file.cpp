@@ -40,13 +40,12 @@ template <class Out> static int run(const std::string &in, const ChainOpts &o, s
     FILE *f = std::fopen(in.c_str(), "rb");
     if (!f) { std::cerr << "Unable to open source: " << in << "\n"; return 1; }
     // prep = takeNArr ns . (resampler . offset)  (SoapySDR.hs:190-207)
-    std::vector<Pipe<Array<cf32>, Array<cf32>>> front;
+    using CPipe = Pipe<Array<cf32>, Array<cf32>>;
     const float fo = (float)(2.0 * 3.14159265358979323846 * g_front.offset / g_front.samplerate);
-    if (fo > 0) front.push_back(mixDown(fo, (uint32_t)chunk));
-    else if (fo < 0) front.push_back(mixUp(-fo, (uint32_t)chunk));
-    if (g_front.bandwidth != 0.0) front.push_back(resampler((float)(g_front.bandwidth / g_front.samplerate), 60.0f, (uint32_t)chunk));
-    std::vector<std::shared_ptr<void>> fstate;
-    for (auto &p : front) fstate.push_back(p.start());
+    CPipe offset = fo > 0 ? mixDown(fo, (uint32_t)chunk) : (fo < 0 ? mixUp(-fo, (uint32_t)chunk) : idPipe<Array<cf32>>());
+    CPipe resamp = g_front.bandwidth != 0.0 ? resampler((float)(g_front.bandwidth / g_front.samplerate), 60.0f, (uint32_t)chunk)
+                                            : idPipe<Array<cf32>>();
+    auto prep = unPipe(compose(resamp, offset));            // (process, cleanup) <- unPipe (resampler . offset)
     TakeN take(n);
     Array<cf32> a(chunk);
     while (true) {
@@ -54,14 +53,13 @@ template <class Out> static int run(const std::string &in, const ChainOpts &o, s
         const size_t got = std::fread(a.data(), sizeof(cf32), chunk, f);
         if (!got) break;
         a.resize(got);
-        Array<cf32> b = a;
-        for (size_t i = 0; i < front.size(); i++) b = front[i].process(fstate[i].get(), b);
+        Array<cf32> b = prep.process(a);
         if (!take.feed(b)) break;
         fold->step(b);
     }
     std::fclose(f);
     fold->done();
-    for (size_t i = 0; i < front.size(); i++) front[i].done(fstate[i].get());
+    prep.cleanup();
     return 0;
 }
 

@@ -62,6 +62,20 @@ int main()
         f->step(Array<float>{1.f}); f->done();
         assert(sink->items[0][0] == 2.f && sink->finished);
     }
+    {   // unPipe (Types.hs:109-115): resource created at unPipe, cleanup = done; idPipe is the Category id
+        std::string log;
+        Pipe<Array<float>, Array<float>> a;
+        a.start = [&]() { log += "s"; return std::shared_ptr<void>(); };
+        a.process = [](void *, const Array<float> &x) { auto y = x; for (auto &v : y) v += 1; return y; };
+        a.done = [&](void *) { log += "d"; };
+        auto u = unPipe(compose<Array<float>, Array<float>, Array<float>>(a, idPipe<Array<float>>()));
+        assert(log == "s");
+        auto y = u.process(Array<float>{1.f});
+        auto z = u.process(y);
+        assert(z[0] == 3.f && log == "s");
+        u.cleanup();
+        assert(log == "sd");
+    }
     {   // distribute_ (Trans.hs:106-117)
         auto s0 = std::make_shared<Collect<float>>(), s1 = std::make_shared<Collect<float>>();
         Distribute<float> d({s0, s1});

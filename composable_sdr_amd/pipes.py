@@ -49,6 +49,23 @@ def compose(p1, p2):
     return Pipe(start, process, done)
 
 
+# Category instance: id (Types.hs:101-102)
+idPipe = Pipe(lambda: None, lambda r, a: a, lambda r: None)
+
+
+def unPipe(pipe):
+    """unPipe (Types.hs:109-115): create the pipe's resource NOW and hand back
+    (stream transformer = S.mapM (process r), cleanup = dest r).  The caller runs
+    `cleanup` after the stream has been folded (SoapySDR.hs:206, :282)."""
+    r = pipe._start()
+
+    def process(stream):
+        for a in stream:
+            yield pipe._process(r, a)
+
+    return process, (lambda: pipe._done(r))
+
+
 class _Handle:
     """Owns one native handle; destroy is idempotent."""
 

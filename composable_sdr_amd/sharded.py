@@ -8,7 +8,8 @@ Two partitions of the reference's `-c M` channelizer:
                   sample of memory, so a stripe only needs a warm-up prefix (13 frames of FIR
                   window + 32768 samples for the DC blocker's (1-alpha)^n tail): no data-path
                   collective, input read once across the node, `--mix` stays local.  Not valid
-                  with the AGC on (its state depends on unbounded history).
+                  with the AGC on (its state depends on unbounded history) nor for the AM / WBFM
+                  tails (peak detector, de-emphasis and decimator memory are not warmed).
   mode="channel"  every rank sees the whole stream and produces channels
                   [chan_first, chan_first+chan_count) -- what the per-channel AGC/squelch/demod
                   tails and the per-channel sinks need.  `--mix` = local left-fold over the owned
@@ -56,6 +57,10 @@ class ShardedChain:
         if mode == "time":
             if cfg.agc != 0.0 and self.world > 1:
                 raise ValueError("time stripes cannot carry the AGC state; use mode='channel' with the AGC on")
+            if cfg.demod in ("am", "wbfm") and self.world > 1:
+                # the warm-up prefix covers the DC blocker, the FIR window and freqdem's one sample; the AM peak
+                # detector (0.99^n), the de-emphasis IIR and the decimator phase are not warmed by it
+                raise ValueError("time stripes do not warm the %s tail's memory; use mode='channel'" % cfg.demod)
             self.chain = chain_factory(cfg)
         elif mode == "channel":
             c0, cn = channel_bounds(cfg.channels, self.world, self.rank)

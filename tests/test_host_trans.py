@@ -86,6 +86,29 @@ def test_compose_order_and_addPipe_lifecycle():                # Types.hs:93-131
     assert [x.tolist() for x in sink.items] == [[2.0, 4.0], [6.0]]
 
 
+def test_unPipe_creates_now_and_returns_stream_map_and_cleanup():   # Types.hs:109-115, SoapySDR.hs:206,282
+    from composable_sdr_amd.pipes import idPipe, unPipe
+    log = []
+    a = Pipe(lambda: log.append("start") or {"n": 0}, lambda r, x: x + 1, lambda r: log.append("done"))
+    process, cleanup = unPipe(compose(a, idPipe))             # resampler . offset with offset = id
+    assert log == ["start"]                                   # r <- creat happens inside unPipe
+    out = list(process(iter([np.float32([1]), np.float32([2, 3])])))
+    assert [o.tolist() for o in out] == [[2.0], [3.0, 4.0]] and log == ["start"]
+    cleanup()
+    assert log == ["start", "done"]
+    assert idPipe._process(idPipe._start(), 7) == 7
+
+
+def test_time_stripes_reject_tails_with_unwarmed_memory():     # am / wbfm / agc in time mode
+    from composable_sdr_amd.pipes import ChainConfig
+    from composable_sdr_amd.sharded import ShardedChain
+    import pytest
+    for kw in (dict(demod="am"), dict(demod="wbfm"), dict(demod="fm", agc=10.0)):
+        with pytest.raises(ValueError):
+            ShardedChain(ChainConfig(channels=16, **kw), mode="time", rank=1, world=2, chain_factory=lambda c: None)
+    ShardedChain(ChainConfig(channels=16, demod="fm"), mode="time", rank=1, world=2, chain_factory=lambda c: None)
+
+
 def test_distribute_routes_channel_k_to_sink_k():              # Trans.hs:106-117, SoapySDR.hs:209-212
     sinks = [collect() for _ in range(3)]
     d = distribute_(sinks)
