@@ -32,6 +32,10 @@ int  fused_status(FusedPlan *plan, unsigned *status);
 // CSDR_TRACE=1: per-tile s_memtime stamps (16 per tile) of the last launches; returns tiles copied
 int  fused_trace(FusedPlan *plan, unsigned long long *out, uint32_t ntiles);
 void fused_destroy(FusedPlan *plan);
+// second-generation run kernel of the M = 256 chain (kernels_fused_v2.hip): whole-band calls of >= run_min_tiles tiles.
+// run_args points at the RunArgs the first-generation k_run256 would have been launched with.
+int  run256_v2_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s);
+int  run256_v2_blocks_per_cu(bool fm);
 
 
 // M = 64 run kernel (kernels_fused_small.hip): same call interface

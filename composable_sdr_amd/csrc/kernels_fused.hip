@@ -708,6 +708,8 @@ struct FusedPlan {
     uint32_t cus = 256;
     float slot_weight[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // tile share of the k-th co-resident run of a CU
     uint32_t resident_wgs = 512;     // workgroups of k_run256 the device holds at once
+    uint32_t resident_wgs_v2 = 512;  // workgroups of k_run256v2 the device holds at once
+    bool use_v2 = true;              // CSDR_RUN_V1=1: first-generation run kernel (A/B)
     TileArgs proto;
 };
 
@@ -780,7 +782,9 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
         if (occ < 1) occ = 1;
         p->resident_wgs = (uint32_t)(cus * occ);
         p->cus = (uint32_t)cus;
-        if (const char *e = getenv("CSDR_RESIDENT_WGS")) p->resident_wgs = (uint32_t)atol(e);
+        p->resident_wgs_v2 = (uint32_t)(cus * run256_v2_blocks_per_cu(cfg.fm));
+        if (const char *e = getenv("CSDR_RESIDENT_WGS")) p->resident_wgs = p->resident_wgs_v2 = (uint32_t)atol(e);
+        if (const char *e = getenv("CSDR_RUN_V1")) p->use_v2 = atoi(e) == 0;
         if (const char *e = getenv("CSDR_RUN_WEIGHTS")) {
             int k = 0;
             for (const char *q = e; *q && k < 8; k++) { p->slot_weight[k] = (float)atof(q); q = strchr(q, ','); if (!q) break; q++; }
@@ -819,23 +823,27 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     if (nb_full >= p->run_min_tiles) {
         // large chunk: dependency-free runs of S full tiles; a ragged tail (< 16 frames) follows as
         // a second launch of the tile kernel on the state the run kernel leaves behind
-        p->name = c.fm ? "k_run256<FM>" : "k_run256<CF32>";
+        // whole-band calls whose output fits 32-bit byte offsets take the second-generation kernel
+        const bool v2 = p->use_v2 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32);
+        p->name = v2 ? (c.fm ? "k_run256v2<FM>" : "k_run256v2<CF32>") : (c.fm ? "k_run256<FM>" : "k_run256<CF32>");
         RunArgs RA{};
         A.nf = nb_full * NB; A.nb = nb_full;
         RA.t = A; RA.yfirst = p->d_yfirst; RA.pk = phase_consts(c.fm_ref);
         // one run per resident workgroup slot (a single round), runs balanced to within one tile,
         // at least 8 tiles per run so that the warm-up reads stay below 7/8 of a run
-        uint32_t nruns = p->resident_wgs;
+        uint32_t nruns = v2 ? p->resident_wgs_v2 : p->resident_wgs;
         if (nruns > A.nb / 8) nruns = A.nb / 8;
         if (nruns < 1) nruns = 1;
         RA.nruns = nruns; RA.S = (A.nb + nruns - 1) / nruns;
-        RA.split = make_split(A.nb, nruns, p->cus, p->slot_weight);
+        static const float even[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        RA.split = make_split(A.nb, nruns, p->cus, v2 ? even : p->slot_weight);
         { const char *e = getenv("CSDR_PRIO_ROT"); RA.prio_div = (e && atoi(e) == 0) ? 0u : p->cus; }
         { const char *e = getenv("CSDR_TRACE"); RA.trace_light = (e && atoi(e) == 2) ? 1u : 0u; }
         RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;
         if (timer && (r = timer->begin(s))) return r;
         static const size_t extra_lds = getenv("CSDR_EXTRA_LDS") ? (size_t)atol(getenv("CSDR_EXTRA_LDS")) : 0;   // occupancy experiments
-        if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), extra_lds, s, RA);
+        if (v2) { if ((r = run256_v2_launch(&RA, c.fm, nruns, s))) return r; }
+        else if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), extra_lds, s, RA);
         else hipLaunchKernelGGL(k_run256<false>, dim3(nruns), dim3(256), extra_lds, s, RA);
         if (timer && (r = timer->end(s))) return r;
         if (c.fm && nruns > 1)

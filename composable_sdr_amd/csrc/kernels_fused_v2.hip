@@ -1,0 +1,434 @@
+// Second-generation run kernel of the fused M = 256 chain (replaces k_run256 of kernels_fused.hip for whole-band calls).
+//
+//   raw CF32 x --DC blocker--> y --NCO pre-mix, 14-tap polyphase FIR--> X_t[j] --256-point forward DFT (16 x 16)--> Y_t[k]
+//              --per-channel freqdem--> out[256][nf]                (8 B read + 4 / 8 B written per sample, Liquid.chs:575-589,
+//                                                                     828-862, 324-328)
+//
+// Same run structure as k_run256 (a workgroup walks a run of 16-frame tiles; FIR window, DC state and freqdem history
+// never leave the workgroup; read-only warm-up at the run start; k_run_fixup finishes the first freqdem sample of a
+// run), but the tile body is rebuilt around what tools/probes/issue_probe*.hip measured on gfx950:
+//   * every VALU instruction costs an issue slot of ~3 (plain VOP1/2/3 on VGPRs) to ~4.7 cycles (DPP, packed, SGPR
+//     operand, min/max/bfi), v_rcp 9 and a VCC-based v_cndmask 16; k_run256 spent 160 DPP + 190 v_mov + 32 VCC selects
+//     per tile and thread.  Here the DC blocker runs as a plain serial scan over 16 consecutive samples per thread out
+//     of an LDS image that the tile was DMA'd into (global_load_lds: no VGPR staging, no ds_write), freqdem uses literal
+//     coefficients and SGPR-mask selects, and the FIR window changes hands by register renaming (two tiles per loop
+//     iteration) instead of moves.
+//   * barriers: 5 per tile instead of 10-12.  Pass 2 of the DFT runs with the frame index in the low four lane bits, so
+//     the previous frame of a channel is one DPP row shift away and a 16-lane row writes 64 (F32) / 128 (CF32)
+//     contiguous bytes of a channel row: no transpose of Y or of the demodulated samples through LDS at all.
+//   * two workgroups per CU (70 KiB of LDS each), up to 256 VGPRs: taps and pass-1 twiddles live in registers.
+//
+// LDS map (float2 units): two tile buffers of 4096 (tile b lives in buffer b & 1 from its DMA to its last Z read, the
+// other buffer receives tile b + 1 meanwhile): raw image, 16-byte XOR swizzle (run-major b128 and column-major b64 both
+// conflict-free) -> y' in place -> FIR output X in place (thread j overwrites exactly the column it read) -> pass-1
+// output Z (own swizzle); STASH 256: last Y frame of the previous tile in pass-2 register order; T 16 frame totals; RED.
+#include "fused_common.h"
+#ifndef V2_ABLATE
+#define V2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem, 8 one FIR tap
+#endif
+
+namespace csdr {
+namespace {
+
+constexpr int V2_BUF = 4096;                       // float2 per tile buffer (32 KiB)
+constexpr int V2_STASH = 2 * V2_BUF;               // 8192
+constexpr int V2_T = V2_STASH + 256;
+constexpr int V2_RED = V2_T + 16;
+constexpr int V2_F2 = V2_RED + 16;                 // 8480 float2 = 67 840 B
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void bar()              // LDS-only barrier: outstanding global stores / LDS-DMA are not waited for
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ float opaque_v(float x) { asm volatile("" : "+v"(x)); return x; }
+
+// HBM -> LDS without registers: lane l of wave instruction `it` fills 16-byte slot 64 (4 it + wave) + l of the RAW image.
+// Spelled in asm so that hipcc does not count it: with the builtin it drains vmcnt(0) in front of the next LDS read.
+// The kernel waits for it by hand (s_waitcnt vmcnt(0) in front of the tile's output stores).  goff[it]: byte offset
+// of my piece inside a tile (the same for every tile); lds_wave: LDS byte address of my wave's first slot.
+__device__ __forceinline__ void dma_offsets(unsigned (&goff)[8], int tid)
+{
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3, i = (slot & 7) ^ ((q >> 1) & 7);
+        goff[it] = (unsigned)(8 * q + i) * 16u;
+    }
+}
+__device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, const unsigned (&goff)[8], unsigned lds_wave)
+{
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const unsigned dst = lds_wave + 4096u * (unsigned)it;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(goff[it]), "s"(dst), "s"(tile_base) : "memory");
+    }
+}
+
+// |a| > |b| ? t : f  and  (sign bit of a) ? t : f  with the condition in an SGPR pair (the VCC form of v_cndmask
+// costs 16 cycles per wave on gfx950, the SGPR form 4.6)
+__device__ __forceinline__ float sel_abs_gt(float a, float b, float t, float f)
+{
+    unsigned long long m; float r;
+    asm("v_cmp_gt_f32_e64 %0, |%1|, |%2|" : "=s"(m) : "v"(a), "v"(b));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float sel_neg(float a, float t, float f)
+{
+    unsigned long long m; float r;
+    asm("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+
+// ref * arg(conj(rp) r): the degree-15 minimax polynomial of scaled_atan2f with literal coefficients (v_fmaak), the
+// scale applied to a = min/max before the last product; hp = ref pi/2, pi = ref pi, tiny = 1e-37 held in VGPRs
+struct FmK { float tiny, ref, hp, pi; };
+__device__ __forceinline__ float fm_sample(float2 rp, float2 r, const FmK &k)
+{
+    const float re = fmaf(rp.x, r.x, rp.y * r.y);
+    const float im = fmaf(rp.x, r.y, -(rp.y * r.x));
+    const float mx = fmaxf(fmaxf(fabsf(re), fabsf(im)), k.tiny);
+    const float mn = fminf(fabsf(re), fabsf(im));
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const float z = a * a;
+    float p = -4.054457881e-03f;
+    p = fmaf(p, z, 2.186254039e-02f);
+    p = fmaf(p, z, -5.591168255e-02f);
+    p = fmaf(p, z, 9.642146528e-02f);
+    p = fmaf(p, z, -1.390860826e-01f);
+    p = fmaf(p, z, 1.994656026e-01f);
+    p = fmaf(p, z, -3.332985938e-01f);
+    p = fmaf(p, z, 9.999993443e-01f);
+    float t = p * (a * k.ref);
+    t = sel_abs_gt(im, re, k.hp - t, t);
+    t = sel_neg(re, k.pi - t, t);
+    return copysignf(t, im);
+}
+
+template <int CTRL> __device__ __forceinline__ float dpp_keep(float old, float v)      // lanes without a source keep `old`
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+struct V2Args {
+    RunArgs r;
+};
+
+template <bool FM>
+__global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
+{
+    const RunArgs &RA = VA.r;
+    const TileArgs &A = RA.t;
+    __shared__ __attribute__((aligned(16))) float2 L[V2_F2];
+    float2 *R = L, *ST = L + V2_STASH, *Tt = L + V2_T, *red = L + V2_RED;
+    float2 *E = L + V2_BUF;                             // run start only
+    const int tid = threadIdx.x, j = tid;
+    const unsigned w = blockIdx.x;
+    unsigned first, last;
+    run_range(RA.split, w, first, last);
+    const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
+    const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
+
+    float2 wa[NB], wb[NB];                              // FIR window halves: one holds the previous tile, the other the new one
+#pragma unroll
+    for (int f = 0; f < NB; f++) { wa[f] = make_float2(0.f, 0.f); wb[f] = make_float2(0.f, 0.f); }
+    float2 c;                                           // DC state v before the next tile (same in every lane)
+
+    // ------------------------------------------------------------------ run start (as k_run256)
+    if (w == 0) {
+        c = A.vend_in[0];
+#pragma unroll
+        for (int f = 3; f < NB; f++) wa[f] = A.yhist_in[(f - 3) * M256 + j];
+    } else {
+        const unsigned halo = first - 1;
+        const unsigned h0 = halo > (unsigned)WU ? halo - WU : 0u;
+        float4 raw[8];
+        float w0[8], w1[8];
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
+                const int i = (slot & 7) ^ ((q >> 1) & 7);
+                const int n = 16 * q + 2 * i;
+                w0[it] = exp2f((float)(4095 - n) * RA.l2beta);
+                w1[it] = exp2f((float)(4094 - n) * RA.l2beta);
+            }
+        }
+        float2 acc = make_float2(0.f, 0.f);
+        auto fold = [&](const float4 (&r)[8]) {
+            float2 p = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                p = cfma(make_float2(r[it].x, r[it].y), w0[it], p);
+                p = cfma(make_float2(r[it].z, r[it].w), w1[it], p);
+            }
+            acc = cfma(acc, A.b256[16], p);
+        };
+        unsigned t = h0;
+        if (halo - h0 == (unsigned)WU) {
+            float4 rb[8], rc[8];
+#pragma unroll 1
+            for (int half = 0; half < 2; half++, t += 3) {
+                tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
+                tile_load(x4 + (size_t)(t + 1) * 2048, 256, rb, tid);
+                tile_load(x4 + (size_t)(t + 2) * 2048, 256, rc, tid);
+                fold(raw); fold(rb); fold(rc);
+            }
+        }
+        for (; t < halo; t++) {
+            tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
+            fold(raw);
+        }
+        float2 ch = wg_sum(acc, red, tid);
+        if (h0 == 0) ch = cfma(A.vend_in[0], exp2f((float)(4096u * halo) * RA.l2beta), ch);
+        tile_load(x4 + (size_t)halo * 2048, 256, raw, tid);
+        stage_and_scan(raw, R, E, Tt, A, tid);
+#pragma unroll
+        for (int f = 3; f < NB; f++) wa[f] = R[256 * f + col_off];
+        const float kj = -A.alpha * A.bj[j & 15];
+        const float br = A.b16[tid & 15], bf = A.b256[tid >> 4];
+        float2 vb, ve;
+        frame_carries(Tt, A, tid, vb, ve);
+        E[tid] = cfma(cfma(ch, bf, vb), br, E[tid]);
+        c = cfma(ch, A.b256[16], ve);
+        __syncthreads();
+#pragma unroll
+        for (int f = 3; f < NB; f++) wa[f] = cfma(E[16 * f + (j >> 4)], kj, wa[f]);
+    }
+    const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
+#pragma unroll
+    for (int f = 3; f < NB; f++) wa[f] = cmul(wa[f], (f & 1) ? Wb : Wa);       // the window holds pre-mixed samples
+    // freqdem history: stash[k1][i] = last Y frame of channel k1 + 16 XIDX(i)
+    ST[(tid & 15) * 16 + XIDX(tid >> 4)] = (FM && w == 0) ? A.rp_in[tid] : make_float2(0.f, 0.f);
+    __syncthreads();                                    // R, E free; stash visible
+
+    // ------------------------------------------------------------------ per-thread constants of the tile loop
+    float h[P];
+#pragma unroll
+    for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j) + n * M256];
+    v2f tw[16];
+#pragma unroll
+    for (int i = 1; i < 16; i++) tw[i] = to_v(A.tw[16 * XIDX(i) + (tid & 15)]);
+    const v2f Wav = to_v(Wa), Wbv = to_v(Wb);
+    const float na = opaque_v(-A.alpha), be = opaque_v(A.beta);
+    const float kJ = -A.alpha * exp2f((float)j * RA.l2beta);                    // -alpha beta^j: frame state into column j
+    const float b256 = A.b256[1];
+    const FmK fk = {opaque_v(1e-37f), opaque_v(A.fm_ref), opaque_v(RA.pk.hp), opaque_v(RA.pk.pi)};
+    unsigned goff[8];
+    dma_offsets(goff, tid);
+    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)R + 1024u * (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+    // LDS byte offsets inside a tile buffer that do not change from tile to tile
+    const int q = tid, sw = (q >> 1) & 7;
+    const unsigned raw_a = (unsigned)q * 128u + ((unsigned)sw << 4);            // slot i of my run: raw_a ^ (i << 4)
+    const int f1 = tid >> 4, b1 = tid & 15;                                     // pass 1: frame, column digit
+    const int k1 = tid >> 4, f2 = tid & 15;                                     // pass 2 / tail: channel digit, frame
+    const unsigned x_a = (unsigned)f1 * 2048u + (unsigned)b1 * 8u;              // X[f1][16 a + b1]: (x_a ^ ((a >> 1) << 4)) + 128 a
+    const unsigned zw_a = (unsigned)(f1 * 256 + ((((b1 >> 1) ^ (f1 & 7)) << 1) | (b1 & 1))) * 8u;   // Z[f1][k1][b1]: + 128 k1
+    const unsigned z_a = (unsigned)(f2 * 256 + k1 * 16) * 8u + ((unsigned)(f2 & 7) << 4);           // pair i of Z[f2][k1][.]: z_a ^ (i << 4)
+    const uint32_t voff = ((uint32_t)k1 * A.out_stride + A.out_t0 + (uint32_t)f2) * (FM ? 4u : 8u);  // + 16 k2 rows, + 16 b frames
+    const size_t row16 = (size_t)16 * A.out_stride * (FM ? 4u : 8u);
+#define V2STAMP(i) do { if (A.trace && tid == 0) A.trace[(size_t)b_ * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+    auto tile = [&](float2 (&old)[NB], float2 (&nw)[NB], unsigned b_, const int par) {
+        unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)b_);            // keep the tile index (store / DMA bases) in SGPRs
+        asm volatile("" : "+s"(b));
+        char *B = reinterpret_cast<char *>(L) + par * (V2_BUF * 8);             // this tile's buffer
+        float2 *Bf = reinterpret_cast<float2 *>(B);
+        V2STAMP(0);
+        bar();                                          // B_a: the tile image has landed (every wave waited for its own DMA); the other buffer is free
+        V2STAMP(1);
+        if (!(V2_ABLATE & 1) && b + 1 < last) dma_tile(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
+        // ---- DC blocker inside a frame: thread q owns the run of 16 consecutive samples q.  First the run total (zero state),
+        // a decayed DPP row scan over the 16 runs of the frame gives the state e at my run's start (frame state still
+        // missing: it is added in column layout below), then the blocker itself from that state
+        v4f xr[8];
+        float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            xr[i] = *reinterpret_cast<const v4f *>(B + (raw_a ^ (unsigned)(i << 4)));
+            s = make_float2(fmaf(s.x, be, xr[i].x), fmaf(s.y, be, xr[i].y));
+            s = make_float2(fmaf(s.x, be, xr[i].z), fmaf(s.y, be, xr[i].w));
+        }
+        {
+            float2 t;
+            t = dpp2<0x111>(s); s = cfma(t, A.b16[1], s);
+            t = dpp2<0x112>(s); s = cfma(t, A.b16[2], s);
+            t = dpp2<0x114>(s); s = cfma(t, A.b16[4], s);
+            t = dpp2<0x118>(s); s = cfma(t, A.b16[8], s);
+        }
+        if ((q & 15) == 15) Tt[q >> 4] = s;
+        s = dpp2<0x111>(s);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            v4f y;
+            y.x = fmaf(s.x, na, xr[i].x); y.y = fmaf(s.y, na, xr[i].y);
+            s = make_float2(fmaf(s.x, be, xr[i].x), fmaf(s.y, be, xr[i].y));
+            y.z = fmaf(s.x, na, xr[i].z); y.w = fmaf(s.y, na, xr[i].w);
+            s = make_float2(fmaf(s.x, be, xr[i].z), fmaf(s.y, be, xr[i].w));
+            *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = y;
+        }
+        V2STAMP(2);
+        bar();                                          // B_c: y' (frame carry still missing) and the frame totals are visible
+        V2STAMP(3);
+        // ---- column layout: thread j owns branch j; frame state chain V[f] (uniform), y = y' - alpha beta^j V[f], pre-mix
+#pragma unroll
+        for (int f = 0; f < NB; f++) nw[f] = Bf[256 * f + col_off];
+        {
+            v2f V = to_v(c);
+            const v2f kJv = {kJ, kJ}, bv = {b256, b256};
+#pragma unroll
+            for (int f = 0; f < NB; f++) {
+                nw[f] = to_f2(__builtin_elementwise_fma(V, kJv, to_v(nw[f])));
+                V = __builtin_elementwise_fma(V, bv, to_v(Tt[f]));
+            }
+            c = to_f2(V);
+        }
+        if (b + 1 == A.nb) {                            // the stream's last 13 frames of y
+#pragma unroll
+            for (int f = 3; f < NB; f++) A.yhist_out[(f - 3) * M256 + j] = nw[f];
+        }
+#pragma unroll
+        for (int f = 0; f < NB; f += 2) {
+            v2f a0 = to_v(nw[f]), a1 = to_v(nw[f + 1]);
+            cmul2_v(a0, Wav, a1, Wbv);
+            nw[f] = to_f2(a0); nw[f + 1] = to_f2(a1);
+        }
+        V2STAMP(4);
+        // ---- polyphase FIR on the pre-mixed window, four frames at a time (independent accumulators); X goes where the
+        // thread's column came from
+#pragma unroll
+        for (int f0 = 0; f0 < NB; f0 += 4) {
+            v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int n = ((V2_ABLATE & 8) ? 0 : P - 1); n >= 0; n--) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = f0 + u - n;
+                    const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
+                    const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
+                    acc[u] = __builtin_elementwise_fma(sv, hv, acc[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) Bf[256 * (f0 + u) + col_off] = to_f2(acc[u]);
+        }
+        V2STAMP(5);
+        bar();                                          // B_d: X complete
+        V2STAMP(6);
+        // ---- DFT pass 1: thread (f1, b1)
+        v2f vv[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B + (x_a ^ (unsigned)((a >> 1) << 4)) + 128 * a));
+        fft16_v(vv);
+#pragma unroll
+        for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], tw[i]);
+        V2STAMP(7);
+        bar();                                          // B_e: everyone has read X
+        V2STAMP(8);
+#pragma unroll
+        for (int i = 0; i < 16; i++) *reinterpret_cast<float2 *>(B + zw_a + 128 * XIDX(i)) = to_f2(vv[i]);
+        V2STAMP(9);
+        bar();                                          // B_f: Z complete
+        V2STAMP(10);
+        // ---- DFT pass 2: thread (k1, f2) reads its 16 consecutive Z values as eight 16-byte pairs
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const v4f v = *reinterpret_cast<const v4f *>(B + (z_a ^ (unsigned)(i << 4)));
+            vv[2 * i] = (v2f){v.x, v.y}; vv[2 * i + 1] = (v2f){v.z, v.w};
+        }
+        fft16_v(vv);                                    // vv[i] = Y[k1 + 16 XIDX(i)] of frame f2
+        V2STAMP(11);
+        // ---- tail
+        char *obase = reinterpret_cast<char *>(A.out) + (size_t)16 * b * (FM ? 4u : 8u);
+        if (FM) {
+            if (b == first && w > 0 && f2 == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) RA.yfirst[(size_t)w * M256 + k1 + 16 * XIDX(i)] = to_f2(vv[i]);
+            }
+            float m[16];
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const v4f sp = *reinterpret_cast<const v4f *>(ST + k1 * 16 + i);         // previous tile's last frame (lane f2 = 0 uses it)
+                const float2 rp0 = make_float2(dpp_keep<0x111>(sp.x, vv[i].x), dpp_keep<0x111>(sp.y, vv[i].y));
+                const float2 rp1 = make_float2(dpp_keep<0x111>(sp.z, vv[i + 1].x), dpp_keep<0x111>(sp.w, vv[i + 1].y));
+                if (V2_ABLATE & 4) { m[i] = rp0.x + vv[i].y; m[i + 1] = rp1.y + vv[i + 1].x; continue; }
+                m[i] = fm_sample(rp0, to_f2(vv[i]), fk);
+                m[i + 1] = fm_sample(rp1, to_f2(vv[i + 1]), fk);
+            }
+            if (f2 == 15) {
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) *reinterpret_cast<v4f *>(ST + k1 * 16 + i) = (v4f){vv[i].x, vv[i].y, vv[i + 1].x, vv[i + 1].y};
+            }
+            V2STAMP(12);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of the next tile image has landed (issued a tile ago)
+            V2STAMP(13);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const char *rowp = obase + (size_t)XIDX(i) * row16;
+                if (V2_ABLATE & 2) asm volatile("" :: "v"(m[i]), "s"(rowp));
+                else asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(m[i]), "s"(rowp) : "memory");
+            }
+        } else {
+            V2STAMP(12);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            V2STAMP(13);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const char *rowp = obase + (size_t)XIDX(i) * row16;
+                if (V2_ABLATE & 2) asm volatile("" :: "v"(vv[i]), "s"(rowp));
+                else asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(vv[i]), "s"(rowp) : "memory");
+            }
+        }
+        V2STAMP(14);
+    };
+
+    if (first < last) dma_tile(x4 + (size_t)first * 2048, goff, lds_wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (unsigned b = first; b < last; b += 2) {
+        tile(wa, wb, b, 0);
+        if (b + 1 >= last) break;
+        tile(wb, wa, b + 1, 1);
+    }
+
+    // ------------------------------------------------------------------ state after the run
+    bar();                                              // stash of the last tile visible to every wave
+    if (FM) {
+        const float2 lastY = ST[(tid & 15) * 16 + XIDX(tid >> 4)];
+        reinterpret_cast<float2 *>(A.ylast)[(size_t)w * M256 + tid] = lastY;
+        if (last == A.nb) A.rp_out[tid] = lastY;
+    }
+    if (last == A.nb && tid == 0) A.vend_out[0] = c;
+}
+
+}  // namespace
+
+static V2Args make_v2(const void *run_args)
+{
+    V2Args VA;
+    VA.r = *static_cast<const RunArgs *>(run_args);
+    return VA;
+}
+
+int run256_v2_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s)
+{
+    const V2Args VA = make_v2(run_args);
+    if (fm) hipLaunchKernelGGL(k_run256v2<true>, dim3(nruns), dim3(256), 0, s, VA);
+    else hipLaunchKernelGGL(k_run256v2<false>, dim3(nruns), dim3(256), 0, s, VA);
+    return 0;
+}
+
+int run256_v2_blocks_per_cu(bool fm)
+{
+    int occ = 0;
+    if (fm) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run256v2<true>, 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run256v2<false>, 256, 0);
+    return occ < 1 ? 1 : occ;
+}
+
+}  // namespace csdr

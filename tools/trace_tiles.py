@@ -15,8 +15,8 @@ from synth import synth_cf32_torch
 M, nf = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 dev = torch.device("cuda", 0)
 x = synth_cf32_torch(M * nf, M, dev)
-out = torch.empty(M * nf, dtype=torch.float32, device=dev)
-ch = cs.Chain(channels=M, demod="fm", max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
+out = torch.empty(M * nf * 2, dtype=torch.float32, device=dev)
+ch = cs.Chain(channels=M, demod=os.environ.get("TRACE_DEMOD", "fm"), max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
 for _ in range(3):
     ch.process_device(x.data_ptr(), M * nf, out.data_ptr(), 0)
 torch.cuda.synchronize()
@@ -29,6 +29,17 @@ buf = np.zeros((nb, 16), dtype=np.uint64)
 got = _lib.lib().csdr_chain_debug_trace(ch.h, buf.ctypes.data, nb)
 kn, kms, kl = ch.kernel_time()
 run = "k_run256" in kn or nf // 16 >= 8192
+if "v2" in kn:
+    t = buf[:got, :15].astype(np.int64)
+    t = t[(t[:, 14] > 0) & (t[:, 0] > 0)]
+    names = ["B_a wait (tile image landed)", "DMA issue + run totals + row scan + blocker (y' in place)", "B_c wait", "column read + frame chain + pre-mix",
+             "FIR + X in place", "B_d wait", "pass 1 (read X, radix-16, twiddle)", "B_e wait", "Z write", "B_f wait", "pass 2 (read Z, radix-16)",
+             "freqdem + stash", "vmcnt(0) (next tile's DMA)", "stores"]
+    d = np.diff(t, axis=1)
+    print(f"{kn}: tiles traced {len(t)}; avg launch {kms / max(kl, 1) * 1e3:.1f} us; median tile time {np.median(t[:, 14] - t[:, 0]):.0f} cycles (wave 0 of each workgroup)")
+    for i in range(14):
+        print(f"  {names[i]:60s} median {np.median(d[:, i]):8.0f}  p90 {np.quantile(d[:, i], 0.9):8.0f}")
+    sys.exit(0)
 if run and os.environ["CSDR_TRACE"] == "2":
     L = buf[:got, 11:15].astype(np.int64)
     ent = L[L[:, 0] > 0]; e0 = ent[:, 0].min()
