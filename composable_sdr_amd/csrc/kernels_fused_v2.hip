@@ -23,6 +23,9 @@
 // conflict-free) -> y' in place -> FIR output X in place (thread j overwrites exactly the column it read) -> pass-1
 // output Z (own swizzle); STASH 256: last Y frame of the previous tile in pass-2 register order; T 16 frame totals; RED.
 #include "fused_common.h"
+#ifndef V2_FM_PACKED
+#define V2_FM_PACKED 1    // freqdem on packed pairs (fm_quad) instead of one sample at a time (fm_sample)
+#endif
 #ifndef V2_ABLATE
 #define V2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem, 8 one FIR tap
 #endif
@@ -31,10 +34,9 @@ namespace csdr {
 namespace {
 
 constexpr int V2_BUF = 4096;                       // float2 per tile buffer (32 KiB)
-constexpr int V2_STASH = 2 * V2_BUF;               // 8192
-constexpr int V2_T = V2_STASH + 256;
-constexpr int V2_RED = V2_T + 16;
-constexpr int V2_F2 = V2_RED + 16;                 // 8480 float2 = 67 840 B
+// two tile buffers, then: STASH 256, T 16, RED 16, pass-1 twiddles 256
+constexpr int V2_STASH = 2 * V2_BUF;
+constexpr int V2_F2 = V2_STASH + 256 + 32 + 256;   // 8736 float2 = 69 888 B: two workgroups per CU
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -110,6 +112,66 @@ __device__ __forceinline__ float fm_sample(float2 rp, float2 r, const FmK &k)
     return copysignf(t, im);
 }
 
+// two samples at once: the complex products, the polynomial and the scalings as packed f32 (half the instructions: a lone
+// wave issues one instruction per ~5.5 cycles whatever it is), selects and the transcendental per sample.  Coefficients
+// are splat from VGPRs (VOP3P takes no literals).
+struct FmK2 { float c[8]; float tiny, ref, hp, pi; };
+__device__ __forceinline__ v2f conj_mul_v(v2f rp, v2f r)                 // conj(rp) * r = (rp.x r.x + rp.y r.y, rp.x r.y - rp.y r.x)
+{
+    v2f t, o;
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[1,0] neg_hi:[1,0]\n\t"          // (rp.y r.y, -rp.y r.x)
+        "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]"                   // (rp.x r.x, rp.x r.y) + t
+        : "=&v"(t), "=&v"(o) : "v"(rp), "v"(r));
+    return o;
+}
+__device__ __forceinline__ float max3_abs(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min_abs(float a, float b)
+{
+    float r;
+    asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// four samples (two packed pairs A, B) with the dependent chains of the two pairs interleaved step by step: a packed op
+// that feeds the next packed op costs a wait state (s_nop) unless something independent sits in between
+__device__ __forceinline__ void fm_quad(const float2 (&rp)[4], const float2 (&r)[4], const FmK2 &k, float (&m)[4])
+{
+    v2f q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) q[u] = conj_mul_v(to_v(rp[u]), to_v(r[u]));                     // (re, im)
+    const v2f mxA = {max3_abs(q[0].x, q[0].y, k.tiny), max3_abs(q[1].x, q[1].y, k.tiny)};
+    const v2f mxB = {max3_abs(q[2].x, q[2].y, k.tiny), max3_abs(q[3].x, q[3].y, k.tiny)};
+    const v2f mnA = {min_abs(q[0].x, q[0].y), min_abs(q[1].x, q[1].y)};
+    const v2f mnB = {min_abs(q[2].x, q[2].y), min_abs(q[3].x, q[3].y)};
+    const v2f rcA = {__builtin_amdgcn_rcpf(mxA.x), __builtin_amdgcn_rcpf(mxA.y)};
+    const v2f rcB = {__builtin_amdgcn_rcpf(mxB.x), __builtin_amdgcn_rcpf(mxB.y)};
+    const v2f aA = mnA * rcA, aB = mnB * rcB;
+    const v2f zA = aA * aA, zB = aB * aB;
+    const v2f refv = {k.ref, k.ref};
+    const v2f sA = aA * refv, sB = aB * refv;
+    v2f pA = __builtin_elementwise_fma((v2f){k.c[7], k.c[7]}, zA, (v2f){k.c[6], k.c[6]});
+    v2f pB = __builtin_elementwise_fma((v2f){k.c[7], k.c[7]}, zB, (v2f){k.c[6], k.c[6]});
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        pA = __builtin_elementwise_fma(pA, zA, (v2f){k.c[i], k.c[i]});
+        pB = __builtin_elementwise_fma(pB, zB, (v2f){k.c[i], k.c[i]});
+    }
+    const v2f tA = pA * sA, tB = pB * sB;
+    const v2f hpv = {k.hp, k.hp}, piv = {k.pi, k.pi};
+    const v2f thA = hpv - tA, thB = hpv - tB;
+    const v2f uA = {sel_abs_gt(q[0].y, q[0].x, thA.x, tA.x), sel_abs_gt(q[1].y, q[1].x, thA.y, tA.y)};
+    const v2f uB = {sel_abs_gt(q[2].y, q[2].x, thB.x, tB.x), sel_abs_gt(q[3].y, q[3].x, thB.y, tB.y)};
+    const v2f wA = piv - uA, wB = piv - uB;
+    m[0] = copysignf(sel_neg(q[0].x, wA.x, uA.x), q[0].y);
+    m[1] = copysignf(sel_neg(q[1].x, wA.y, uA.y), q[1].y);
+    m[2] = copysignf(sel_neg(q[2].x, wB.x, uB.x), q[2].y);
+    m[3] = copysignf(sel_neg(q[3].x, wB.y, uB.y), q[3].y);
+}
+
 template <int CTRL> __device__ __forceinline__ float dpp_keep(float old, float v)      // lanes without a source keep `old`
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
@@ -125,8 +187,9 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const RunArgs &RA = VA.r;
     const TileArgs &A = RA.t;
     __shared__ __attribute__((aligned(16))) float2 L[V2_F2];
-    float2 *R = L, *ST = L + V2_STASH, *Tt = L + V2_T, *red = L + V2_RED;
-    float2 *E = L + V2_BUF;                             // run start only
+    float2 *R = L, *ST = L + V2_STASH, *Tt = ST + 256, *red = Tt + 16;
+    float2 *tw_s = red + 16;
+    float2 *E = L + V2_BUF;                             // run start only: 256 run carries
     const int tid = threadIdx.x, j = tid;
     const unsigned w = blockIdx.x;
     unsigned first, last;
@@ -134,6 +197,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
 
+#define V2LSTAMP(i) do { if (A.trace && RA.trace_light && tid == 0) A.trace[(size_t)first * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    V2LSTAMP(0);
     float2 wa[NB], wb[NB];                              // FIR window halves: one holds the previous tile, the other the new one
 #pragma unroll
     for (int f = 0; f < NB; f++) { wa[f] = make_float2(0.f, 0.f); wb[f] = make_float2(0.f, 0.f); }
@@ -186,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             fold(raw);
         }
         float2 ch = wg_sum(acc, red, tid);
+        V2LSTAMP(1);
         if (h0 == 0) ch = cfma(A.vend_in[0], exp2f((float)(4096u * halo) * RA.l2beta), ch);
         tile_load(x4 + (size_t)halo * 2048, 256, raw, tid);
         stage_and_scan(raw, R, E, Tt, A, tid);
@@ -210,19 +276,20 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 
     // ------------------------------------------------------------------ per-thread constants of the tile loop
     float h[P];
+    tw_s[tid] = A.tw[tid];
 #pragma unroll
     for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j) + n * M256];
-    v2f tw[16];
-#pragma unroll
-    for (int i = 1; i < 16; i++) tw[i] = to_v(A.tw[16 * XIDX(i) + (tid & 15)]);
     const v2f Wav = to_v(Wa), Wbv = to_v(Wb);
     const float na = opaque_v(-A.alpha), be = opaque_v(A.beta);
     const float kJ = -A.alpha * exp2f((float)j * RA.l2beta);                    // -alpha beta^j: frame state into column j
     const float b256 = A.b256[1];
-    const FmK fk = {opaque_v(1e-37f), opaque_v(A.fm_ref), opaque_v(RA.pk.hp), opaque_v(RA.pk.pi)};
+    const FmK2 fk = {{opaque_v(9.999993443e-01f), opaque_v(-3.332985938e-01f), opaque_v(1.994656026e-01f), opaque_v(-1.390860826e-01f),
+                      opaque_v(9.642146528e-02f), opaque_v(-5.591168255e-02f), opaque_v(2.186254039e-02f), opaque_v(-4.054457881e-03f)},
+                     opaque_v(1e-37f), opaque_v(A.fm_ref), opaque_v(RA.pk.hp), opaque_v(RA.pk.pi)};
     unsigned goff[8];
     dma_offsets(goff, tid);
-    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)R + 1024u * (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)R + 1024u * wave_u;
     // LDS byte offsets inside a tile buffer that do not change from tile to tile
     const int q = tid, sw = (q >> 1) & 7;
     const unsigned raw_a = (unsigned)q * 128u + ((unsigned)sw << 4);            // slot i of my run: raw_a ^ (i << 4)
@@ -233,14 +300,20 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const unsigned z_a = (unsigned)(f2 * 256 + k1 * 16) * 8u + ((unsigned)(f2 & 7) << 4);           // pair i of Z[f2][k1][.]: z_a ^ (i << 4)
     const uint32_t voff = ((uint32_t)k1 * A.out_stride + A.out_t0 + (uint32_t)f2) * (FM ? 4u : 8u);  // + 16 k2 rows, + 16 b frames
     const size_t row16 = (size_t)16 * A.out_stride * (FM ? 4u : 8u);
-#define V2STAMP(i) do { if (A.trace && tid == 0) A.trace[(size_t)b_ * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define V2STAMP(i) do { if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b_ * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
     auto tile = [&](float2 (&old)[NB], float2 (&nw)[NB], unsigned b_, const int par) {
         unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)b_);            // keep the tile index (store / DMA bases) in SGPRs
         asm volatile("" : "+s"(b));
         char *B = reinterpret_cast<char *>(L) + par * (V2_BUF * 8);             // this tile's buffer
         float2 *Bf = reinterpret_cast<float2 *>(B);
+        if (RA.prio_div) {
+            // the CU issues oldest-wave-first: without this the older of a CU's two workgroups finishes its run ~35 % earlier
+            // and the CU is half empty for the rest of the launch; alternating the priority per tile shares the issue slots
+            if (((b_ - first) + w / RA.prio_div) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
         V2STAMP(0);
+        if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b_ * 16 + 15] = __builtin_amdgcn_s_memrealtime();
         bar();                                          // B_a: the tile image has landed (every wave waited for its own DMA); the other buffer is free
         V2STAMP(1);
         if (!(V2_ABLATE & 1) && b + 1 < last) dma_tile(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
@@ -327,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B + (x_a ^ (unsigned)((a >> 1) << 4)) + 128 * a));
         fft16_v(vv);
 #pragma unroll
-        for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], tw[i]);
+        for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + b1]));
         V2STAMP(7);
         bar();                                          // B_e: everyone has read X
         V2STAMP(8);
@@ -351,29 +424,38 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 #pragma unroll
                 for (int i = 0; i < 16; i++) RA.yfirst[(size_t)w * M256 + k1 + 16 * XIDX(i)] = to_f2(vv[i]);
             }
-            float m[16];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile image (issued a tile ago): nothing else is outstanding
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const v4f sp = *reinterpret_cast<const v4f *>(ST + k1 * 16 + i);         // previous tile's last frame (lane f2 = 0 uses it)
-                const float2 rp0 = make_float2(dpp_keep<0x111>(sp.x, vv[i].x), dpp_keep<0x111>(sp.y, vv[i].y));
-                const float2 rp1 = make_float2(dpp_keep<0x111>(sp.z, vv[i + 1].x), dpp_keep<0x111>(sp.w, vv[i + 1].y));
-                if (V2_ABLATE & 4) { m[i] = rp0.x + vv[i].y; m[i + 1] = rp1.y + vv[i + 1].x; continue; }
-                m[i] = fm_sample(rp0, to_f2(vv[i]), fk);
-                m[i + 1] = fm_sample(rp1, to_f2(vv[i + 1]), fk);
+            for (int i = 0; i < 16; i += 4) {
+                float2 rp[4], rr[4];
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                    const v4f sp = *reinterpret_cast<const v4f *>(ST + k1 * 16 + i + u);  // previous tile's last frame (lane f2 = 0 uses it)
+                    rp[u] = make_float2(dpp_keep<0x111>(sp.x, vv[i + u].x), dpp_keep<0x111>(sp.y, vv[i + u].y));
+                    rp[u + 1] = make_float2(dpp_keep<0x111>(sp.z, vv[i + u + 1].x), dpp_keep<0x111>(sp.w, vv[i + u + 1].y));
+                    rr[u] = to_f2(vv[i + u]); rr[u + 1] = to_f2(vv[i + u + 1]);
+                }
+                float mq[4];
+                if (V2_ABLATE & 4) { mq[0] = rp[0].x + rr[0].y; mq[1] = rp[1].y + rr[1].x; mq[2] = rp[2].x + rr[2].y; mq[3] = rp[3].y + rr[3].x; }
+                else if (V2_FM_PACKED) fm_quad(rp, rr, fk, mq);
+                else {
+                    const FmK k1s = {fk.tiny, fk.ref, fk.hp, fk.pi};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) mq[u] = fm_sample(rp[u], rr[u], k1s);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {                       // stores go out between the quads
+                    const char *rowp = obase + (size_t)XIDX(i + u) * row16;
+                    if (V2_ABLATE & 2) asm volatile("" :: "v"(mq[u]), "s"(rowp));
+                    else asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
+                }
             }
             if (f2 == 15) {
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) *reinterpret_cast<v4f *>(ST + k1 * 16 + i) = (v4f){vv[i].x, vv[i].y, vv[i + 1].x, vv[i + 1].y};
             }
             V2STAMP(12);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my share of the next tile image has landed (issued a tile ago)
             V2STAMP(13);
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const char *rowp = obase + (size_t)XIDX(i) * row16;
-                if (V2_ABLATE & 2) asm volatile("" :: "v"(m[i]), "s"(rowp));
-                else asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(m[i]), "s"(rowp) : "memory");
-            }
         } else {
             V2STAMP(12);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -388,8 +470,10 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         V2STAMP(14);
     };
 
+    V2LSTAMP(2);
     if (first < last) dma_tile(x4 + (size_t)first * 2048, goff, lds_wave);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    V2LSTAMP(3);
     for (unsigned b = first; b < last; b += 2) {
         tile(wa, wb, b, 0);
         if (b + 1 >= last) break;
@@ -397,6 +481,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     }
 
     // ------------------------------------------------------------------ state after the run
+    V2LSTAMP(4);
     bar();                                              // stash of the last tile visible to every wave
     if (FM) {
         const float2 lastY = ST[(tid & 15) * 16 + XIDX(tid >> 4)];

@@ -17,6 +17,8 @@ agc = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 mix = len(sys.argv) > 5 and sys.argv[5] == "mix"
 dev = torch.device("cuda", 0)
 xs = [synth_cf32_torch(M * nf, M, dev, seed=5 + i) for i in range(2)]
+if os.environ.get("ZERO_INPUT"):            # DVFS check: same instruction stream, no data toggling
+    xs = [torch.zeros_like(x) for x in xs]
 out = torch.empty(M * nf * 2, dtype=torch.float32, device=dev)
 ch = cs.Chain(channels=M, demod=demod, agc=agc, mix=mix, max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
 for i in range(3):

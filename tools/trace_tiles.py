@@ -29,6 +29,33 @@ buf = np.zeros((nb, 16), dtype=np.uint64)
 got = _lib.lib().csdr_chain_debug_trace(ch.h, buf.ctypes.data, nb)
 kn, kms, kl = ch.kernel_time()
 run = "k_run256" in kn or nf // 16 >= 8192
+if "v2" in kn and os.environ["CSDR_TRACE"] == "2":
+    L = buf[:got, 0:5].astype(np.int64)
+    ent = L[(L[:, 0] > 0) & (L[:, 4] > 0)]
+    e0 = ent[:, 0].min()
+    q = [0, .1, .5, .9, 1]
+    print(f"{kn}: light trace of {len(ent)} runs; avg launch {kms / max(kl, 1) * 1e3:.1f} us (us after the first entry, quantiles 0/10/50/90/100)")
+    print("  run entry        :", (np.quantile(ent[:, 0] - e0, q) / 100).round(1))
+    wu = ent[ent[:, 1] > 0]
+    print("  warm-up done     :", (np.quantile(wu[:, 1] - e0, q) / 100).round(1), " duration", (np.quantile(wu[:, 1] - wu[:, 0], q) / 100).round(1))
+    print("  halo + constants :", (np.quantile(ent[:, 2] - e0, q) / 100).round(1), " duration", (np.quantile(wu[:, 2] - wu[:, 1], q) / 100).round(1))
+    print("  first tile landed:", (np.quantile(ent[:, 3] - e0, q) / 100).round(1), " duration", (np.quantile(ent[:, 3] - ent[:, 2], q) / 100).round(1))
+    print("  run end          :", (np.quantile(ent[:, 4] - e0, q) / 100).round(1), " tile loop duration", (np.quantile(ent[:, 4] - ent[:, 3], q) / 100).round(1))
+    idx = np.flatnonzero((buf[:got, 0] > 0) & (buf[:got, 4] > 0))       # row = first tile of run w, ascending in w
+    wv = np.arange(len(idx))
+    loop = (buf[idx, 4].astype(np.int64) - buf[idx, 3].astype(np.int64)) / 100.0
+    endw = (buf[idx, 4].astype(np.int64) - e0) / 100.0
+    pro = (buf[idx, 3].astype(np.int64) - e0) / 100.0
+    nslot = max(1, len(idx) // 256)
+    print("  by CU slot (w // 256): loop", [round(float(loop[wv // 256 == k].mean()), 1) for k in range(nslot)],
+          " prologue end", [round(float(pro[wv // 256 == k].mean()), 1) for k in range(nslot)],
+          " run end", [round(float(endw[wv // 256 == k].mean()), 1) for k in range(nslot)])
+    print("  by XCD (w % 8): loop", [round(float(loop[wv % 8 == k].mean()), 1) for k in range(8)], " run end max", [round(float(endw[wv % 8 == k].max()), 1) for k in range(8)])
+    cu = wv % 256
+    pair = np.array([endw[cu == c].max() - endw[cu == c].min() for c in range(256)]) if len(idx) >= 512 else np.zeros(1)
+    print("  spread of run end inside a CU (max - min over its workgroups): median", round(float(np.median(pair)), 1), "max", round(float(pair.max()), 1),
+          "; CU-level last end: quantiles", np.quantile(np.array([endw[cu == c].max() for c in range(256)]), q).round(1))
+    sys.exit(0)
 if "v2" in kn:
     t = buf[:got, :15].astype(np.int64)
     t = t[(t[:, 14] > 0) & (t[:, 0] > 0)]
@@ -38,7 +65,21 @@ if "v2" in kn:
     d = np.diff(t, axis=1)
     print(f"{kn}: tiles traced {len(t)}; avg launch {kms / max(kl, 1) * 1e3:.1f} us; median tile time {np.median(t[:, 14] - t[:, 0]):.0f} cycles (wave 0 of each workgroup)")
     for i in range(14):
-        print(f"  {names[i]:60s} median {np.median(d[:, i]):8.0f}  p90 {np.quantile(d[:, i], 0.9):8.0f}")
+        print(f"  {names[i]:60s} median {np.median(d[:, i]):8.0f}  mean {np.mean(d[:, i]):8.0f}  p90 {np.quantile(d[:, i], 0.9):8.0f}")
+    # shader clock: consecutive tiles of one run are consecutive rows; s_memtime ticks per 10 ns of s_memrealtime
+    full = buf[:got].astype(np.int64)
+    ok = (full[1:, 0] > 0) & (full[:-1, 0] > 0) & (full[1:, 15] > full[:-1, 15]) & (full[1:, 15] - full[:-1, 15] < 5000)
+    clk = (full[1:, 0] - full[:-1, 0])[ok] / (full[1:, 15] - full[:-1, 15])[ok] * 0.1
+    # per XCD: run w = row // tiles-per-run (uniform split), XCD = w % 8
+    nruns = int(os.environ.get("CSDR_RESIDENT_WGS", "512"))
+    tpr = max(1, got // nruns)
+    xcd = (np.arange(got - 1) // tpr) % 8
+    per = (full[1:, 0] - full[:-1, 0]); rt = (full[1:, 15] - full[:-1, 15])
+    vm = full[:, 13] - full[:, 12]
+    print("  by XCD: clock GHz", [round(float(np.median(clk[xcd[ok] == k])), 3) for k in range(8)],
+          " tile period us", [round(float(np.mean(rt[ok & (xcd == k)])) / 100, 2) for k in range(8)],
+          " mean DMA wait cyc", [int(np.mean(vm[:-1][ok & (xcd == k)])) for k in range(8)])
+    print(f"  mean tile period {np.mean((full[1:, 0] - full[:-1, 0])[ok]):.0f} cycles = {np.mean((full[1:, 15] - full[:-1, 15])[ok]) / 100:.2f} us; shader clock median {np.median(clk):.3f} GHz (p10 {np.quantile(clk, .1):.3f}, p90 {np.quantile(clk, .9):.3f})")
     sys.exit(0)
 if run and os.environ["CSDR_TRACE"] == "2":
     L = buf[:got, 11:15].astype(np.int64)
