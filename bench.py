@@ -162,15 +162,19 @@ def main():
     alg_bytes_per_sample = 8 + (out_elem / M if a.mix else out_elem)   # read CF32 once + write W
     kavg_ms = kms / max(klaunches, 1)
     achieved = (nx * alg_bytes_per_sample) / (kavg_ms * 1e-3) / 1e9 if klaunches else None
-    traffic = None
+    # HBM bytes per launch from the committed PMC passes of this very configuration (tools/profile_all.sh +
+    # tools/collect_all.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc runs); null when it has not been profiled
+    tj = {}
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            key = f"{kname}|M={M}|nf={nf}"
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
-            traffic = None
+            tj = {}
+
+    def traffic_of(kernel):
+        return tj.get(f"{kernel}|M={M}|nf={nf}", {}).get("hbm_bytes_per_launch")
+    traffic = traffic_of(kname)
     res = {
         "metric": "MS/s CF32 throughput, 256-ch PFB+FM pipeline", "value": round(value, 1), "unit": "MS/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
@@ -211,6 +215,13 @@ def main():
                                           "segment boundaries verified bitwise, failing segments recomputed in parallel rounds until all hold (exact)",
                               "segments_checked": c1 - c0, "segments_recomputed": r1 - r0,
                               "hbm_roofline_frac_whole_step": round(v2 * 1e6 * alg_bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4)}
+        # the AGC step is two kernels (channelizer to channel-major CF32 scratch, then the AGC + freqdem tail): achieved
+        # = algorithmic bytes of the STEP over the step time; traffic = counter bytes of both launches
+        ta, tb = traffic_of("k_run256v2<CF32>") or traffic_of("k_run256<CF32>"), traffic_of("k_agc_spec")
+        res["agc_variant"]["roofline"] = {"bound": "hbm", "kernel": "k_run256v2<CF32> + k_agc_spec (+ k_agc_fix)",
+                                          "achieved": round(nx * alg_bytes_per_sample / (d2 / reps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(nx * alg_bytes_per_sample / (d2 / reps) / 1e9 / HBM_PEAK_GBS, 4),
+                                          "traffic": (ta + tb) if (ta and tb) else None}
         ch2.close()
 
     if world == 1 and not a.no_cpu_baseline:

@@ -32,8 +32,9 @@ if os.path.exists(tl):
         if line.startswith('{"metric"'):
             bench_line = line.strip()
 with open(os.path.join(dst, f"{tag}_rocprofv3_summary.txt"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats / --pmc passes of: python3 bench.py --steps 5 --warmup 1 "
-            f"--no-cpu-baseline --no-agc-variant   (tools/profile.sh)\n# bench line of the traced run:\n# {bench_line}\n\n")
+    args = open(os.path.join(src, "args.txt")).read().strip() if os.path.exists(os.path.join(src, "args.txt")) else "--steps 5 --warmup 1 --no-cpu-baseline --no-agc-variant"
+    f.write(f"# rocprofv3 --kernel-trace --stats / --pmc passes of: python3 bench.py {args}   (tools/profile.sh, tools/profile_lite.sh)\n"
+            f"# bench line of the traced run:\n# {bench_line}\n\n")
     f.write(summary)
 for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
@@ -48,12 +49,24 @@ for sub in ("pmc3", "pmc4"):
             vals[k][c] = sum(v) / len(v)
 tj_path = os.path.join(dst, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+
+
+def short_name(k):
+    """rocprofv3's demangled kernel name -> the name csdr_chain_kernel_time reports (bench.py's roofline.kernel)"""
+    k = k.replace("void ", "").replace("csdr::(anonymous namespace)::", "").replace("csdr::", "").split("(")[0]
+    base, _, targs = k.partition("<")
+    first = targs.split(",")[0].strip(" >")
+    if first in ("true", "false") and (base.startswith("k_run") or base.startswith("k_tile")):
+        return base + ("<FM>" if first == "true" else "<CF32>")
+    return base
+
+
 for k, c in vals.items():
-    if "FETCH_SIZE" in c and "WRITE_SIZE" in c and ("k_run256" in k or "k_tile256" in k):
-        short = "k_run256" if "k_run256" in k else "k_tile256"
-        short += "<FM>" if "<true>" in k or "ILb1" in k else "<CF32>"
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c and "k_" in k:
         rd, wr = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024
-        tj[f"{short}|M={M}|nf={nf}"] = {
+        if rd + wr < (1 << 20):
+            continue                                    # fix-up / init kernels
+        tj[f"{short_name(k)}|M={M}|nf={nf}"] = {
             "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
             "fetch_size_kib_raw": c["FETCH_SIZE"], "write_size_kib_raw": c["WRITE_SIZE"],
             "note": "FETCH_SIZE x2 (gfx950 wide-load under-count), WRITE_SIZE as reported", "source": f"profiles/{tag}_rocprofv3_summary.txt"}

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-agc-variant $*"
-KRE='k_run|k_tile|k_fused|k_dc_|k_pfb|k_fm|k_agc'
+KRE='k_'
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
    --kernel-include-regex "$KRE" -f csv -d $OUT/pmc1 -o p -- python3 bench.py $ARGS > $OUT/pmc1.log 2>&1
@@ -16,5 +16,5 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_
    --kernel-include-regex "$KRE" -f csv -d $OUT/pmc2 -o p -- python3 bench.py $ARGS > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KRE" -f csv -d $OUT/pmc3 -o p -- python3 bench.py $ARGS > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KRE" -f csv -d $OUT/pmc4 -o p -- python3 bench.py $ARGS > $OUT/pmc4.log 2>&1
-find $OUT -name "*.csv" | head -20
+echo "$ARGS" > $OUT/args.txt
 grep -h '"metric"' $OUT/trace.log | head -1

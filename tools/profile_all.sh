@@ -1,0 +1,10 @@
+#!/bin/bash
+# Every configuration DESIGN.md / README.md quote a number for: kernel trace + HBM traffic passes, the headline also
+# with the SQ counter passes.  Usage (GPU box, repo root): tools/profile_all.sh rNN ; then tools/collect_all.sh rNN here.
+R=${1:-rXX}
+tools/profile.sh ${R}_cfg3_fm --no-agc-variant
+tools/profile_lite.sh ${R}_cfg3_deno --demod none --no-agc-variant
+tools/profile_lite.sh ${R}_cfg3_agc --steps 3
+tools/profile_lite.sh ${R}_cfg2_m64_deno --channels 64 --frames 1048576 --demod none --no-agc-variant
+tools/profile_lite.sh ${R}_cfg4shape_1024_fm --channels 1024 --frames 65536 --no-agc-variant
+tools/profile_lite.sh ${R}_cfg5shape_4096_mix --channels 4096 --frames 16384 --demod none --mix --no-agc-variant

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Kernel trace + the two HBM traffic passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; the pool refuses --pmc
+# combined with tracing domains) of one bench.py configuration.  Usage (GPU box, repo root): tools/profile_lite.sh TAG [bench args]
+set -u
+TAG=${1:-run}; shift || true
+export TMPDIR=/tmp
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline $*"
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_" -f csv -d $OUT/pmc3 -o p -- python3 bench.py $ARGS > $OUT/pmc3.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_" -f csv -d $OUT/pmc4 -o p -- python3 bench.py $ARGS > $OUT/pmc4.log 2>&1
+echo "$ARGS" > $OUT/args.txt
+grep -h '"metric"' $OUT/trace.log | head -1 | cut -c1-300
