@@ -71,6 +71,11 @@ SIGNATURES = {
     "csdr_chain_create": (_i32, [C.POINTER(ChainCfg), _pp]),
     "csdr_chain_process": (_i32, [_vp, _vp, _u32, _vp, _pu32]),
     "csdr_chain_process_device": (_i32, [_vp, _vp, _u32, _vp, _pu32, _vp]),
+    "csdr_chain_submit": (_i32, [_vp, _vp, _u32, _vp]),
+    "csdr_chain_collect": (_i32, [_vp, _pu32]),
+    "csdr_chain_status": (_i32, [_vp]),
+    "csdr_host_alloc": (_vp, [C.c_size_t]),
+    "csdr_host_free": (None, [_vp]),
     "csdr_chain_reset": (_i32, [_vp]),
     "csdr_chain_seek_frames": (_i32, [_vp, C.c_uint64]),
     "csdr_chain_destroy": (_i32, [_vp]),

@@ -120,8 +120,15 @@ struct csdr_chain {
     float2 *d_u = nullptr, *d_hist_tmp = nullptr, *d_A = nullptr, *d_B = nullptr;
     AgcState *d_agc = nullptr;
     float2 *d_rp[2] = {nullptr, nullptr}; int rp_cur = 0;
-    // host-API staging
-    float2 *d_in_stage = nullptr; void *d_out_stage = nullptr;
+    // host-API staging: CSDR_CHAIN_INFLIGHT slots (device in / out, page-locked host in / out), three streams
+    struct HostSlot {
+        float2 *d_in = nullptr; void *d_out = nullptr; void *h_in = nullptr, *h_out = nullptr;
+        hipEvent_t e_in = nullptr, e_k = nullptr, e_out = nullptr;
+        void *user_out = nullptr; uint32_t n_out = 0; size_t out_bytes = 0; bool staged_out = false;
+    };
+    HostSlot slot[CSDR_CHAIN_INFLIGHT];
+    hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+    uint32_t q_head = 0, q_count = 0;      // oldest pending slot, number of pending chunks
     FusedPlan *fused = nullptr;
     SmallPlan *small = nullptr;
     BigPlan *big = nullptr;          // M = 1024 run kernel
@@ -950,30 +957,147 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
     return CSDR_OK;
 }
 
+// Device-side spin-wait time-outs (k_tile256 look-back / hand-off, k_dc_tile look-back) set a sticky status word and the
+// kernel carries on with garbage carries: report it as an error once, then clear it.  Synchronises the device.
+static int chain_device_status(csdr_chain *h)
+{
+    unsigned st = 0, st2 = 0;
+    int r;
+    if (h->fused && (r = fused_status(h->fused, &st))) return r;
+    if (h->dctile && (r = dctile_status(h->dctile, &st2))) return r;
+    if (st || st2) {
+        set_error("chain: an inter-workgroup wait timed out on the device (fused status 0x%x, dc-tile status 0x%x): the output of the affected calls is invalid", st, st2);
+        return CSDR_ERR_HIP;
+    }
+    return CSDR_OK;
+}
+
+int csdr_chain_status(csdr_chain *h)
+{
+    if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
+    DevGuard guard(h->device);
+    return chain_device_status(h);
+}
+
+void *csdr_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void csdr_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+static bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+static int chain_host_init(csdr_chain *h)
+{
+    if (h->s_k) return CSDR_OK;
+    CSDR_HIP(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
+    CSDR_HIP(hipStreamCreateWithFlags(&h->s_k, hipStreamNonBlocking));
+    CSDR_HIP(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));
+    for (auto &sl : h->slot) {
+        CSDR_HIP(hipEventCreateWithFlags(&sl.e_in, hipEventDisableTiming));
+        CSDR_HIP(hipEventCreateWithFlags(&sl.e_k, hipEventDisableTiming));
+        CSDR_HIP(hipEventCreateWithFlags(&sl.e_out, hipEventDisableTiming));
+    }
+    return CSDR_OK;
+}
+
+int csdr_chain_submit(csdr_chain *h, const float *in, uint32_t n_in, void *out)
+{
+    if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
+    if (n_in && (!in || !out)) { set_error("chain: null buffer"); return CSDR_ERR_INVALID; }
+    if (n_in % h->M) { set_error("chain: n_in=%u is not a multiple of channels=%u (the reference misbehaves here; Liquid.chs:832-862)", n_in, h->M); return CSDR_ERR_SIZE; }
+    if (n_in > h->max_nx) { set_error("chain: n_in=%u exceeds max_frames*channels=%llu", n_in, (unsigned long long)h->max_nx); return CSDR_ERR_SIZE; }
+    if (h->q_count == CSDR_CHAIN_INFLIGHT) { set_error("chain: %d chunks already in flight (collect first)", CSDR_CHAIN_INFLIGHT); return CSDR_ERR_BUSY; }
+    DevGuard guard(h->device);
+    if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
+    int r;
+    if ((r = chain_host_init(h))) return r;
+    csdr_chain::HostSlot &sl = h->slot[(h->q_head + h->q_count) % CSDR_CHAIN_INFLIGHT];
+    sl.user_out = out; sl.n_out = 0; sl.out_bytes = 0; sl.staged_out = false;
+    if (n_in) {
+        const size_t in_bytes = sizeof(float2) * (size_t)n_in, out_max = (size_t)h->C * h->max_nf * 8;
+        if (!sl.d_in && ((r = dev_alloc(&sl.d_in, h->max_nx)))) return r;
+        if (!sl.d_out) { CSDR_HIP(hipMalloc(&sl.d_out, out_max)); }
+        const void *src = in;
+        if (!is_pinned(in)) {                               // pageable caller memory: one host copy into the slot's page-locked buffer
+            if (!sl.h_in) { CSDR_HIP(hipHostMalloc(&sl.h_in, sizeof(float2) * h->max_nx, hipHostMallocDefault)); }
+            memcpy(sl.h_in, in, in_bytes);
+            src = sl.h_in;
+        }
+        CSDR_HIP(hipMemcpyAsync(sl.d_in, src, in_bytes, hipMemcpyHostToDevice, h->s_in));
+        CSDR_HIP(hipEventRecord(sl.e_in, h->s_in));
+        CSDR_HIP(hipStreamWaitEvent(h->s_k, sl.e_in, 0));
+        // the slot's device output was last read by its own previous D2H copy
+        CSDR_HIP(hipStreamWaitEvent(h->s_k, sl.e_out, 0));
+        uint32_t no = 0;
+        if ((r = csdr_chain_process_device(h, sl.d_in, n_in, sl.d_out, &no, h->s_k))) return r;
+        CSDR_HIP(hipEventRecord(sl.e_k, h->s_k));
+        sl.n_out = no; sl.out_bytes = (size_t)no * csdr_chain_out_elem_size(h);
+        void *dst = out;
+        if (!is_pinned(out)) {
+            if (!sl.h_out) { CSDR_HIP(hipHostMalloc(&sl.h_out, out_max, hipHostMallocDefault)); }
+            dst = sl.h_out; sl.staged_out = true;
+        }
+        CSDR_HIP(hipStreamWaitEvent(h->s_out, sl.e_k, 0));
+        CSDR_HIP(hipMemcpyAsync(dst, sl.d_out, sl.out_bytes, hipMemcpyDeviceToHost, h->s_out));
+        CSDR_HIP(hipEventRecord(sl.e_out, h->s_out));
+    }
+    h->q_count++;
+    return CSDR_OK;
+}
+
+int csdr_chain_collect(csdr_chain *h, uint32_t *n_out)
+{
+    if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
+    if (n_out) *n_out = 0;
+    if (!h->q_count) { set_error("chain: nothing submitted"); return CSDR_ERR_INVALID; }
+    DevGuard guard(h->device);
+    csdr_chain::HostSlot &sl = h->slot[h->q_head];
+    h->q_head = (h->q_head + 1) % CSDR_CHAIN_INFLIGHT; h->q_count--;
+    if (sl.out_bytes) {
+        CSDR_HIP(hipEventSynchronize(sl.e_out));
+        if (sl.staged_out) memcpy(sl.user_out, sl.h_out, sl.out_bytes);
+    }
+    if (n_out) *n_out = sl.n_out;
+    return CSDR_OK;
+}
+
 int csdr_chain_process(csdr_chain *h, const float *in, uint32_t n_in, void *out, uint32_t *n_out)
 {
     if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
     if (n_out) *n_out = 0;
     if (n_in == 0) return CSDR_OK;
-    if (!in || !out) { set_error("chain: null buffer"); return CSDR_ERR_INVALID; }
-    if (n_in % h->M) { set_error("chain: n_in=%u is not a multiple of channels=%u (the reference misbehaves here; Liquid.chs:832-862)", n_in, h->M); return CSDR_ERR_SIZE; }
-    if (n_in > h->max_nx) { set_error("chain: n_in=%u exceeds max_frames*channels=%llu", n_in, (unsigned long long)h->max_nx); return CSDR_ERR_SIZE; }
-    DevGuard guard(h->device);
-    if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
+    if (h->q_count) { set_error("chain: csdr_chain_process with chunks still in flight (collect them first)"); return CSDR_ERR_BUSY; }
     int r;
-    const size_t out_max = (size_t)h->C * h->max_nf * 8;
-    if (!h->d_in_stage && ((r = dev_alloc(&h->d_in_stage, h->max_nx)))) return r;
-    if (!h->d_out_stage) { CSDR_HIP(hipMalloc(&h->d_out_stage, out_max)); }
-    CSDR_HIP(hipMemcpy(h->d_in_stage, in, sizeof(float2) * (size_t)n_in, hipMemcpyHostToDevice));
-    uint32_t no = 0;
-    if ((r = csdr_chain_process_device(h, h->d_in_stage, n_in, h->d_out_stage, &no, nullptr))) return r;
-    CSDR_HIP(hipMemcpy(out, h->d_out_stage, (size_t)no * csdr_chain_out_elem_size(h), hipMemcpyDeviceToHost));
-    if (h->fused) {
-        unsigned st = 0;
-        if ((r = fused_status(h->fused, &st))) return r;
-        if (st) { set_error("chain: inter-workgroup wait timed out on the device (status 0x%x)", st); return CSDR_ERR_HIP; }
+    if (is_pinned(in) && is_pinned(out)) {
+        if ((r = csdr_chain_submit(h, in, n_in, out))) return r;
+        if ((r = csdr_chain_collect(h, n_out))) return r;
+    } else {
+        // pageable caller memory: the runtime's own staged hipMemcpy beats a hand-made copy into page-locked memory
+        if (!in || !out) { set_error("chain: null buffer"); return CSDR_ERR_INVALID; }
+        if (n_in % h->M) { set_error("chain: n_in=%u is not a multiple of channels=%u (the reference misbehaves here; Liquid.chs:832-862)", n_in, h->M); return CSDR_ERR_SIZE; }
+        if (n_in > h->max_nx) { set_error("chain: n_in=%u exceeds max_frames*channels=%llu", n_in, (unsigned long long)h->max_nx); return CSDR_ERR_SIZE; }
+        DevGuard guard(h->device);
+        if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
+        if ((r = chain_host_init(h))) return r;
+        csdr_chain::HostSlot &sl = h->slot[0];
+        if (!sl.d_in && ((r = dev_alloc(&sl.d_in, h->max_nx)))) return r;
+        if (!sl.d_out) { CSDR_HIP(hipMalloc(&sl.d_out, (size_t)h->C * h->max_nf * 8)); }
+        CSDR_HIP(hipMemcpy(sl.d_in, in, sizeof(float2) * (size_t)n_in, hipMemcpyHostToDevice));
+        uint32_t no = 0;
+        if ((r = csdr_chain_process_device(h, sl.d_in, n_in, sl.d_out, &no, h->s_k))) return r;
+        CSDR_HIP(hipStreamSynchronize(h->s_k));
+        CSDR_HIP(hipMemcpy(out, sl.d_out, (size_t)no * csdr_chain_out_elem_size(h), hipMemcpyDeviceToHost));
+        if (n_out) *n_out = no;
     }
-    if (n_out) *n_out = no;
+    if ((r = chain_device_status(h))) return r;
     return CSDR_OK;
 }
 
@@ -981,10 +1105,12 @@ int csdr_chain_reset(csdr_chain *h)
 {
     if (!h) return CSDR_ERR_INVALID;
     DevGuard guard(h->device);
+    CSDR_HIP(hipDeviceSynchronize());                  // chunks still in flight are abandoned
+    h->q_head = 0; h->q_count = 0;
     int r = chain_init_state(h, nullptr);
     if (r) return r;
     CSDR_HIP(hipDeviceSynchronize());
-    return CSDR_OK;
+    return chain_device_status(h);
 }
 
 int csdr_chain_seek_frames(csdr_chain *h, uint64_t frames)
@@ -1056,9 +1182,17 @@ int csdr_chain_destroy(csdr_chain *h)
     if (h->agc_tail) agc_tail_destroy(h->agc_tail);
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
-                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_in_stage, h->d_out_stage, h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1],
+                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1],
                     h->d_wbf, h->d_wbo, h->d_wbh, h->d_wbhist[0], h->d_wbhist[1], h->d_wbst[0], h->d_wbst[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &sl : h->slot) {
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        for (hipEvent_t e : {sl.e_in, sl.e_k, sl.e_out}) if (e) (void)hipEventDestroy(e);
+    }
+    for (hipStream_t st : {h->s_in, h->s_k, h->s_out}) if (st) (void)hipStreamDestroy(st);
     delete h;
     return CSDR_OK;
 }

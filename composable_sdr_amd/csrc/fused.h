@@ -27,7 +27,7 @@ int  fused_reset(FusedPlan *plan, hipStream_t s);
 int  fused_process(FusedPlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
 const char *fused_name(const FusedPlan *plan);
 void fused_seek(FusedPlan *plan, uint64_t frames);   // after fused_reset: global frame index of the next frame
-// sticky device-side error word (bit0/bit1: an inter-workgroup wait hit its spin limit); synchronises
+// sticky device-side error word (bit0/bit1: an inter-workgroup wait hit its spin limit); reads, then clears it; synchronises
 int  fused_status(FusedPlan *plan, unsigned *status);
 // CSDR_TRACE=1: per-tile s_memtime stamps (16 per tile) of the last launches; returns tiles copied
 int  fused_trace(FusedPlan *plan, unsigned long long *out, uint32_t ntiles);
@@ -66,6 +66,8 @@ int  dctile_create(const DcParams &dc, uint64_t max_samples, DcTilePlan **out);
 int  dctile_reset(DcTilePlan *plan, hipStream_t s);
 int  dctile_process(DcTilePlan *plan, const float2 *x, float2 *y, uint32_t n, bool do_mix, const NcoParams &nco,
                     const float2 *nco_tab, hipStream_t s);
+// sticky device-side error word (a look-back wait hit its spin limit); reads, then clears it; synchronises
+int  dctile_status(DcTilePlan *plan, unsigned *status);
 void dctile_destroy(DcTilePlan *plan);
 
 }  // namespace csdr

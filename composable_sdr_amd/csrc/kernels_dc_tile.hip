@@ -198,6 +198,13 @@ struct DcTilePlan {
     DcTileArgs proto;
 };
 
+int dctile_status(DcTilePlan *p, unsigned *status)
+{
+    CSDR_HIP(hipMemcpy(status, p->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (*status) CSDR_HIP(hipMemset(p->d_status, 0, sizeof(unsigned)));
+    return 0;
+}
+
 void dctile_destroy(DcTilePlan *p)
 {
     if (!p) return;

@@ -900,6 +900,7 @@ int fused_trace(FusedPlan *p, unsigned long long *out, uint32_t ntiles)
 int fused_status(FusedPlan *p, unsigned *status)
 {
     CSDR_HIP(hipMemcpy(status, p->d_status, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (*status) CSDR_HIP(hipMemset(p->d_status, 0, sizeof(unsigned)));     // sticky until reported once
     return 0;
 }
 

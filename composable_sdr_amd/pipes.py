@@ -320,6 +320,30 @@ class Chain:
                                               C.byref(n_out), C.c_void_p(stream)))
         return n_out.value
 
+    # ---- asynchronous host-buffer entry point (csdr_chain_submit / csdr_chain_collect)
+    def submit(self, x, out=None):
+        """Queue one chunk; `x` / `out` should come from host_array() (page-locked) for full PCIe speed.  Returns `out`,
+        which is valid after the matching collect()."""
+        x = _c64(x)
+        if out is None:
+            out = np.empty(self.out_shape(x.size), dtype=self.out_dtype)
+        check(lib().csdr_chain_submit(self.h, _ptr(x), x.size, _ptr(out)))
+        self._pending = getattr(self, "_pending", [])
+        self._pending.append((x, out))                   # keep the buffers alive until collect
+        return out
+
+    def collect(self):
+        """Wait for the oldest submitted chunk; returns its output array."""
+        n_out = C.c_uint32()
+        check(lib().csdr_chain_collect(self.h, C.byref(n_out)))
+        x, out = self._pending.pop(0)
+        assert n_out.value == out.size or x.size == 0, (n_out.value, out.size)
+        return out
+
+    def status(self):
+        """raises CsdrError if a device-side inter-workgroup wait timed out since the last check"""
+        check(lib().csdr_chain_status(self.h))
+
     def kernel_time(self):
         ms, n = C.c_double(), C.c_uint32()
         name = lib().csdr_chain_kernel_time(self.h, C.byref(ms), C.byref(n))
@@ -340,6 +364,27 @@ class Chain:
 
     def close(self):
         self._h.close()
+
+
+class host_array:
+    """numpy view of page-locked host memory from csdr_host_alloc (freed with the object)."""
+
+    def __init__(self, shape, dtype):
+        self.dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * self.dtype.itemsize
+        self.p = lib().csdr_host_alloc(n)
+        if not self.p:
+            raise CsdrError(_lib.ERR_NOMEM, "csdr_host_alloc failed")
+        buf = (C.c_char * n).from_address(self.p)
+        self.a = np.frombuffer(buf, dtype=self.dtype).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self.p:
+                lib().csdr_host_free(self.p)
+                self.p = None
+        except Exception:
+            pass
 
 
 def firpfbchChannelizer(n, **kw):

@@ -29,6 +29,7 @@
 #ifndef CSDR_H
 #define CSDR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -42,6 +43,7 @@ extern "C" {
 #define CSDR_ERR_SIZE     (-4)  /* chunk length not a multiple of the channel count, or
                                    larger than the handle was created for                */
 #define CSDR_ERR_NOMEM    (-5)
+#define CSDR_ERR_BUSY     (-6)  /* csdr_chain_submit: CSDR_CHAIN_INFLIGHT chunks already pending */
 
 #define CSDR_DEMOD_NONE 0u      /* DeNo: per-channel CF32 out (SoapySDR.hs:236-243)      */
 #define CSDR_DEMOD_FM   1u      /* DeNBFM kf: freqdem, F32 out (SoapySDR.hs:244-251)     */
@@ -213,6 +215,24 @@ int  csdr_chain_create(const csdr_chain_cfg *cfg, csdr_chain **out);
 int  csdr_chain_process(csdr_chain *h, const float *in_cf32, uint32_t n_in, void *out, uint32_t *n_out);
 int  csdr_chain_process_device(csdr_chain *h, const void *d_in_cf32, uint32_t n_in,
                                void *d_out, uint32_t *n_out, void *stream);
+/* Asynchronous host-buffer entry point (what a streaming caller such as the reference's fold uses; replaces the blocking
+ * firpfbch/analyzer call at Liquid.chs:845 and the caller-owned buffers of Liquid.chs:82, :292): up to
+ * CSDR_CHAIN_INFLIGHT chunks are in flight, H2D copy, kernels and D2H copy run on three streams so that the copies of
+ * neighbouring chunks overlap the kernels.  `submit` returns as soon as the work is queued (CSDR_ERR_BUSY when
+ * CSDR_CHAIN_INFLIGHT chunks are already pending); `collect` waits for the OLDEST submitted chunk, whose result is then
+ * in the `out` given to its submit.  Buffers from csdr_host_alloc (page-locked) are copied from / to directly; any
+ * other buffer is staged through page-locked memory owned by the handle (one extra host memcpy each way).  The
+ * buffers of a chunk must stay valid until its collect.  csdr_chain_process = submit + collect. */
+#define CSDR_CHAIN_INFLIGHT 3
+void *csdr_host_alloc(size_t bytes);            /* page-locked host memory (hipHostMalloc); NULL on failure */
+void  csdr_host_free(void *p);
+int  csdr_chain_submit(csdr_chain *h, const float *in_cf32, uint32_t n_in, void *out);
+int  csdr_chain_collect(csdr_chain *h, uint32_t *n_out);
+/* Device-side health of the handle since the last check: CSDR_ERR_HIP (text in csdr_last_error) when an
+ * inter-workgroup wait of the small-chunk kernels hit its spin limit (their output is then invalid), CSDR_OK
+ * otherwise.  Synchronises the device; csdr_chain_process and csdr_chain_reset call it themselves, callers of the
+ * device / async entry points call it at their own sync points. */
+int  csdr_chain_status(csdr_chain *h);
 int  csdr_chain_reset(csdr_chain *h);      /* back to the state right after create        */
 /* Reset, then place the stream position at frame `frames` (n = frames*channels samples in):
  * the NCO pre-mix phase becomes what it would be there.  Used by time-striped multi-GPU runs,

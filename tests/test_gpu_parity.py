@@ -238,6 +238,44 @@ def test_chain_chunk_size_invariance():
     assert np.quantile(np.abs(d), 0.999) < 2e-5
 
 
+@pytest.mark.parametrize("M,demod", [(256, "fm"), (20, "none")])
+def test_chain_async_submit_collect_matches_blocking(M, demod):
+    """csdr_chain_submit / csdr_chain_collect (page-locked buffers, three chunks in flight, copies and kernels on separate
+    streams) produce bit for bit what the blocking csdr_chain_process does, state carried across the in-flight chunks; a
+    fourth submit without a collect is refused, pageable buffers are staged."""
+    from composable_sdr_amd.pipes import host_array
+    nfs = [512, 512, 256, 512, 128, 512, 512]
+    x = synth_cf32(M * sum(nfs), M, seed=77)
+    a = cs.Chain(channels=M, demod=demod, kf=0.3, max_frames=512)
+    b = cs.Chain(channels=M, demod=demod, kf=0.3, max_frames=512)
+    want, pos = [], 0
+    for nf in nfs:
+        want.append(a.process(x[pos:pos + nf * M])); pos += nf * M
+    ins = [host_array((512 * M,), np.complex64) for _ in range(3)]
+    outs = [host_array((M, 512), want[0].dtype) for _ in range(3)]
+    got, pend, pos = [], [], 0
+    for i, nf in enumerate(nfs):
+        if len(pend) == 3:
+            got.append(b.collect().copy()); pend.pop(0)
+        k = i % 3
+        ins[k].a[:nf * M] = x[pos:pos + nf * M]; pos += nf * M
+        if i == 4:                                           # a pageable pair in the middle of the stream
+            o = b.submit(ins[k].a[:nf * M].copy())
+        else:
+            o = b.submit(ins[k].a[:nf * M], outs[k].a.reshape(-1)[:M * nf].reshape(M, nf))
+        pend.append(o)
+        if i == 2:
+            with pytest.raises(cs.CsdrError) as e:
+                b.submit(ins[0].a[:M * 16])
+            assert e.value.code == -6
+    while pend:
+        got.append(b.collect().copy()); pend.pop(0)
+    b.status()
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and np.array_equal(g.view(np.uint32), w.view(np.uint32))
+    a.close(); b.close()
+
+
 def test_chain_reset_restores_initial_state():
     M = 16
     x = synth_cf32(M * 50, M, seed=2)
