@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--kf", type=float, default=0.3)
     ap.add_argument("--agc", type=float, default=0.0, help="squelch threshold dB (0 = AGC off)")
     ap.add_argument("--mix", action="store_true", help="--mix: sum the channels (configs[4] shape)")
+    ap.add_argument("--shard", default="time", choices=["time", "channel"],
+                    help="multi-GPU partition: time stripes (weak scaling, no collective; default) or interleaved channel "
+                         "ownership k = rank (mod N) with a pruned DFT per rank (strong scaling; --mix adds one RCCL all-reduce per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agc-variant", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -108,10 +111,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libcsdr_hip has no CPU fallback)")
+    # test hook (tests/test_gpu_parity.py::test_bench_channel_shard_two_ranks_one_gpu): all ranks on device 0 over gloo,
+    # which exercises the N > 1 code path on a one-GPU box; the driver's runs use one GPU per rank over RCCL ("nccl")
+    one_gpu = os.environ.get("CSDR_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if use_dist:
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if one_gpu else "nccl", rank=rank, world_size=world)
 
     import composable_sdr_amd as cs
     from composable_sdr_amd import _lib
@@ -122,15 +130,31 @@ def main():
     out_elem = 4 if a.demod == "fm" else 8
     # two input buffers (> the 256 MiB Infinity Cache together) alternate between steps;
     # rank r's stripe is a different stretch of the stream (different seed offset)
-    xs = [synth_cf32_torch(nx, M, dev, seed=20260101 + 7919 * (2 * rank + i)) for i in range(2)]
+    chan = a.shard == "channel" and world > 1
+    if chan and M % world:
+        raise SystemExit(f"--shard channel needs --gpus | --channels ({world} does not divide {M})")
+    # time stripes: rank r's stripe is a different stretch of the stream (different seed offset);
+    # channel shards: every rank sees the SAME stream (in production: broadcast over xGMI) and owns channels rank, rank + N, ...
+    xs = [synth_cf32_torch(nx, M, dev, seed=20260101 + 7919 * (2 * (0 if chan else rank) + i)) for i in range(2)]
     out = torch.empty(M * nf * out_elem // 4, dtype=torch.float32, device=dev)
-    chain = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local,
-                     flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
-    chain.seek_frames(rank * a.steps * nf)      # rank r's stripe of one long stream
+    flags = _lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS
+    if chan:
+        from composable_sdr_amd.pipes import ChainConfig
+        from composable_sdr_amd.sharded import ShardedChain
+        sc = ShardedChain(ChainConfig(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=flags),
+                          mode="channel", interleave=True)
+        chain = sc.chain
+    else:
+        chain = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=flags)
+        chain.seek_frames(rank * a.steps * nf)      # rank r's stripe of one long stream
     stream = torch.cuda.current_stream().cuda_stream
+    xv = [x.view(-1) for x in xs]
 
     def step(i):
-        chain.process_device(xs[i & 1].data_ptr(), nx, out.data_ptr(), stream)
+        if chan and a.mix:
+            sc.process_device_mix(xv[i & 1], out[: nf * out_elem // 4], stream)    # partial mix + one RCCL all-reduce(SUM) on the tensor
+        else:
+            chain.process_device(xs[i & 1].data_ptr(), nx, out.data_ptr(), stream)
 
     def barrier():
         if use_dist:
@@ -157,7 +181,7 @@ def main():
         dist.destroy_process_group()
         return
 
-    total_samples = float(nx) * a.steps * world
+    total_samples = float(nx) * a.steps * (1 if chan else world)     # channel shards: every rank works on the same samples
     value = total_samples / dt / 1e6
     alg_bytes_per_sample = 8 + (out_elem / M if a.mix else out_elem)   # read CF32 once + write W
     kavg_ms = kms / max(klaunches, 1)
@@ -178,13 +202,18 @@ def main():
     res = {
         "metric": "MS/s CF32 throughput, 256-ch PFB+FM pipeline", "value": round(value, 1), "unit": "MS/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if chan else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"cfg3: {M}-ch firpfbch(m=7,As=80)+dcBlocker+freqdem(kf={a.kf}) on synthetic CF32, "
                                f"AGC {'off (-a 0)' if a.agc == 0 else a.agc}, {nf} frames/step "
                                f"({nx * 8 / 2**20:.0f} MiB in, {M * nf * out_elem / 2**20:.0f} MiB out), HBM-resident",
                    "channels": M, "frames_per_step": nf, "demod": a.demod, "kf": a.kf, "agc_db": a.agc, "mix": bool(a.mix),
-                   "path": chain.path, "sharding": "time stripes, 1 per rank" if world > 1 else "none"},
-        "hbm_roofline_frac_whole_step": round(value * 1e6 * alg_bytes_per_sample / 1e9 / (HBM_PEAK_GBS * world), 4),
+                   "path": chain.path,
+                   "sharding": ("none" if world == 1 else
+                                (f"channel-interleaved: rank g owns channels g + {world} m, pruned DFT (fold + {M // world}-point)" if chan
+                                 else "time stripes, 1 per rank")),
+                   "collective": (f"RCCL all-reduce(SUM) of {nf} {'F32' if a.demod == 'fm' else 'CF32'} per step" if (chan and a.mix) else "none"),
+                   "rccl_ranks": (dist.get_world_size() if use_dist else 1)},
+        "hbm_roofline_frac_whole_step": round(value * 1e6 * alg_bytes_per_sample / 1e9 / (HBM_PEAK_GBS * (1 if chan else world)), 4),
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                      "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4) if achieved else None,

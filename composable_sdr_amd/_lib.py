@@ -25,6 +25,7 @@ class ChainCfg(C.Structure):
         ("kf", C.c_float), ("mix", C.c_uint32), ("chan_first", C.c_uint32), ("chan_count", C.c_uint32),
         ("device", C.c_int32), ("max_frames", C.c_uint32), ("flags", C.c_uint32),
         ("pfb_m", C.c_uint32), ("pfb_as", C.c_float), ("wbfm_decim", C.c_uint32), ("deemph_fc", C.c_float),
+        ("chan_stride", C.c_uint32),
     ]
 
 

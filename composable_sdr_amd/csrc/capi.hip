@@ -117,6 +117,8 @@ struct csdr_chain {
     // device memory
     float *d_taps = nullptr;
     float2 *d_tw = nullptr, *d_nco_tab = nullptr, *d_dcstate = nullptr, *d_scratch = nullptr;
+    uint32_t G = 1;                  // chan_stride: interleaved shard g = c0 of G (generic route, pruned DFT)
+    float2 *d_tw_g = nullptr, *d_fold_ph = nullptr, *d_fold = nullptr;   // (M/G)-point twiddles, fold phasors, folded frames
     float2 *d_u = nullptr, *d_hist_tmp = nullptr, *d_A = nullptr, *d_B = nullptr;
     AgcState *d_agc = nullptr;
     float2 *d_rp[2] = {nullptr, nullptr}; int rp_cur = 0;
@@ -647,14 +649,21 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     if (cfg->dc_block && !(cfg->dc_alpha > 0.f && cfg->dc_alpha < 1.f)) { set_error("chain: dc_alpha out of (0,1)"); return CSDR_ERR_INVALID; }
     const uint32_t M = cfg->channels;
     uint32_t c0 = cfg->chan_first, C = cfg->chan_count ? cfg->chan_count : M - c0;
-    if (c0 >= M || C == 0 || c0 + C > M) { set_error("chain: channel shard [%u,+%u) outside 0..%u", c0, C, M); return CSDR_ERR_INVALID; }
+    const uint32_t G = cfg->chan_stride > 1 ? cfg->chan_stride : 1;
+    if (G > 1) {
+        if (M % G || c0 >= G || (cfg->chan_count && cfg->chan_count != M / G)) {
+            set_error("chain: interleaved shard %u of %u needs chan_stride | channels (%u), chan_first < chan_stride, chan_count 0 or channels/chan_stride", c0, G, M);
+            return CSDR_ERR_INVALID;
+        }
+        C = M / G;
+    } else if (c0 >= M || C == 0 || c0 + C > M) { set_error("chain: channel shard [%u,+%u) outside 0..%u", c0, C, M); return CSDR_ERR_INVALID; }
     int dev; int r = check_device(cfg->device, &dev); if (r) return r;
     DevGuard guard(dev);
     if (!guard.ok) { set_error("chain: cannot select device %d", dev); return CSDR_ERR_HIP; }
 
     csdr_chain *h = new (std::nothrow) csdr_chain();
     if (!h) return CSDR_ERR_NOMEM;
-    h->cfg = *cfg; h->device = dev; h->M = M; h->C = C; h->c0 = c0;
+    h->cfg = *cfg; h->device = dev; h->M = M; h->C = C; h->c0 = c0; h->G = G;
     { int cus = 256; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); h->n_cus = (uint32_t)cus; }
     const uint32_t m = cfg->pfb_m ? cfg->pfb_m : 7;
     const float As = cfg->pfb_as > 0.f ? cfg->pfb_as : 80.0f;
@@ -697,7 +706,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     // Path selection: the fused kernels cover M = 256 (DC blocker + pre-mix + PFB [+ freqdem]).
     // With the AGC on, the fused kernel stops at the channel-major CF32 samples and the
     // exactly-sequential per-channel AGC tail (one lane per channel) + freqdem + mix follow.
-    const bool want_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC);
+    const bool want_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && G == 1;   // interleaved shards: any-M route, pruned DFT
     h->use_fused = want_fused && (fused_supported(M, h->p) || small_supported(M, h->p) || (big_supported(M, h->p) && !getenv("CSDR_NO_RUN1024")));
     if (h->use_fused) {
         const bool agc_on = cfg->agc_threshold_db != 0.0f;
@@ -726,13 +735,26 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         }
     } else {
         h->path = "generic";
-        h->timed_kernel = M > 1 ? ((pfb1024_supported(M, h->p) && !(cfg->mix && cfg->agc_threshold_db == 0.0f) && !getenv("CSDR_NO_PFB1024")) ? "k_pfb1024" : "k_pfb_fir") : "k_dc_apply";
-        if (pfb1024_supported(M, h->p) && !(cfg->mix && cfg->agc_threshold_db == 0.0f) && !getenv("CSDR_NO_PFB1024")) h->path = "generic+pfb1024";
+        const bool use1024 = G == 1 && pfb1024_supported(M, h->p) && !(cfg->mix && cfg->agc_threshold_db == 0.0f) && !getenv("CSDR_NO_PFB1024");
+        h->timed_kernel = M > 1 ? (use1024 ? "k_pfb1024" : "k_pfb_fir") : "k_dc_apply";
+        if (use1024) h->path = "generic+pfb1024";
         if (M > 1) {
             if ((r = dev_alloc(&h->d_u, (size_t)(h->p - 1) * M + h->max_nx)) || (r = dev_alloc(&h->d_hist_tmp, (size_t)(h->p - 1) * M))) return fail(r);
         }
         if ((r = dev_alloc(&h->d_A, h->max_nx)) || (r = dev_alloc(&h->d_B, h->max_nx))) return fail(r);
         if (M > 1 && cfg->dc_block && (r = dctile_create(h->dc, h->max_nx, &h->dctile))) return fail(r);
+        if (G > 1) {
+            const uint32_t Mg = M / G;
+            std::vector<float2> twg(Mg), ph(G + Mg);
+            const double tp = -2.0 * 3.14159265358979323846;
+            for (uint32_t i = 0; i < Mg; i++) twg[i] = make_float2((float)std::cos(tp * i / Mg), (float)std::sin(tp * i / Mg));
+            for (uint32_t j2 = 0; j2 < G; j2++) ph[j2] = make_float2((float)std::cos(tp * ((uint64_t)j2 * c0 % G) / G), (float)std::sin(tp * ((uint64_t)j2 * c0 % G) / G));
+            for (uint32_t j1 = 0; j1 < Mg; j1++) ph[G + j1] = make_float2((float)std::cos(tp * ((uint64_t)j1 * c0 % M) / M), (float)std::sin(tp * ((uint64_t)j1 * c0 % M) / M));
+            if ((r = dev_alloc(&h->d_tw_g, Mg)) || (r = dev_alloc(&h->d_fold_ph, G + Mg)) || (r = dev_alloc(&h->d_fold, (size_t)Mg * h->max_nf))) return fail(r);
+            if (hipMemcpy(h->d_tw_g, twg.data(), sizeof(float2) * Mg, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(h->d_fold_ph, ph.data(), sizeof(float2) * (G + Mg), hipMemcpyHostToDevice) != hipSuccess) { set_error("chain: fold table upload failed"); return fail(CSDR_ERR_HIP); }
+            h->path = "generic+pruned-dft";
+        }
     }
     if (am) {
         h->am = true; h->am_mix = am_mix;
@@ -808,7 +830,7 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
         if (r) return r;
         // M = 1024: FIR + DFT + transpose [+ freqdem] in one kernel (no X / Y round trips through HBM); the frame-major
         // mix tails without AGC still want Y in HBM and keep the three-kernel route
-        const bool fused1024 = pfb1024_supported(M, h->p) && !(mixo && !agc) && !getenv("CSDR_NO_PFB1024");
+        const bool fused1024 = h->G == 1 && pfb1024_supported(M, h->p) && !(mixo && !agc) && !getenv("CSDR_NO_PFB1024");
         if ((r = h->timer.begin(s))) return r;
         if (fused1024) {
             const bool fm_here = fm && !agc;                     // with the AGC on the tail does the freqdem
@@ -840,21 +862,26 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
         }
         // DeNo --mix over all channels: the frame sum happens inside the DFT kernel, Y never goes to HBM
         const bool fused_mix = !agc && !fm && mixo && C == M && dft_mix_supported(M);
-        if (fused_mix) r = launch_dft_mix(h->d_A, (float2 *)d_out, h->d_tw, M, nf, s);
+        if (h->G > 1) {
+            // interleaved shard: fold the G sub-blocks of every frame, then an (M/G)-point DFT: d_B = Y[t][c0 + G m]
+            if ((r = launch_fold(h->d_A, h->d_fold, h->d_fold_ph, M, h->G, nf, s))) return r;
+            r = launch_dft(h->d_fold, h->d_B, h->d_tw_g, M / h->G, nf, s);
+        } else if (fused_mix) r = launch_dft_mix(h->d_A, (float2 *)d_out, h->d_tw, M, nf, s);
         else r = launch_dft(h->d_A, h->d_B, h->d_tw, M, nf, s);
         if (r) return r;
         h->theta += nx * h->d_theta;
         if (h->tab_len) h->tab_pos = (uint32_t)(((uint64_t)h->tab_pos + nx) % h->tab_len);
         if (fused_mix) return 0;
+        const uint32_t Mw = M / h->G, cw = h->G > 1 ? 0u : h->c0;     // width of a DFT output frame, first owned bin in it
         if (!agc && (fm || mixo)) {
             // frame-major tails: no transpose in front of freqdem / mix
-            if (mixo) r = launch_mix_frames(h->d_B, d_out, fm, M, nf, h->c0, C, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s);
-            else r = launch_transpose_fm(h->d_B, (float *)d_out, M, nf, h->c0, C, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s);
+            if (mixo) r = launch_mix_frames(h->d_B, d_out, fm, Mw, nf, cw, C, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s);
+            else r = launch_transpose_fm(h->d_B, (float *)d_out, Mw, nf, cw, C, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s);
             if (r) return r;
             if (fm) h->rp_cur ^= 1;
             return 0;
         }
-        if ((r = launch_transpose(h->d_B, Z, M, nf, h->c0, C, s))) return r;
+        if ((r = launch_transpose(h->d_B, Z, Mw, nf, cw, C, s))) return r;
     } else {
         if ((r = h->timer.begin(s))) return r;
         if ((r = launch_dc_mix(d_in, Z, nx, h->cfg.dc_block != 0, h->dc, h->d_dcstate, h->d_scratch, false, nco, nullptr, s))) return r;
@@ -1182,7 +1209,7 @@ int csdr_chain_destroy(csdr_chain *h)
     if (h->agc_tail) agc_tail_destroy(h->agc_tail);
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
-                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1],
+                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1], h->d_tw_g, h->d_fold_ph, h->d_fold,
                     h->d_wbf, h->d_wbo, h->d_wbh, h->d_wbhist[0], h->d_wbhist[1], h->d_wbst[0], h->d_wbst[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &sl : h->slot) {

@@ -83,6 +83,9 @@ int launch_pfb_fir(const float2 *u, const float *taps, float2 *X, uint32_t M, ui
                    uint32_t nf, hipStream_t s);
 // forward M-point DFT of every frame: Y[t][k].  tw: e^{-j 2 pi i/M}, i<M.
 int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s);
+// interleaved channel shard g of G: Z[t][j1] = W_M^{j1 g} sum_{j2 < G} X[t][j1 + (M/G) j2] W_G^{j2 g}; the (M/G)-point DFT of Z[t]
+// is Y[t][g + G m].  ph: G phasors W_G^{j2 g} followed by M/G phasors W_M^{j1 g}
+int launch_fold(const float2 *X, float2 *Z, const float2 *ph, uint32_t M, uint32_t G, uint32_t nf, hipStream_t s);
 // out[t] = sum_k DFT(X[t])[k] in k_mix_frames' summation order, without materialising Y (M = 1024, 4096, all channels)
 bool dft_mix_supported(uint32_t M);
 int launch_dft_mix(const float2 *X, float2 *out, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s);

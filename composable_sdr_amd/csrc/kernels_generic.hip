@@ -449,6 +449,37 @@ int launch_dft(const float2 *X, float2 *Y, const float2 *tw, uint32_t M, uint32_
     return 0;
 }
 
+// Pruned DFT for an interleaved channel shard (channels g, g + G, ...): Y[g + G m] = sum_{j1 < M/G} z[j1] W_{M/G}^{j1 m} with
+// z[j1] = W_M^{j1 g} sum_{j2 < G} X[j1 + (M/G) j2] W_G^{j2 g}.  This kernel makes z (one thread per (frame, j1)); the
+// (M/G)-point DFT follows as an ordinary launch_dft.  ph: G phasors W_G^{j2 g}, then M/G phasors W_M^{j1 g}.
+__global__ __launch_bounds__(256) void k_fold(const float2 *__restrict__ X, float2 *__restrict__ Z, const float2 *__restrict__ ph,
+                                             uint32_t M, uint32_t G, uint64_t total)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t Mg = M / G;
+    const uint64_t t = i / Mg;
+    const uint32_t j1 = (uint32_t)(i - t * Mg);
+    const float2 *x = X + t * M + j1;
+    float2 acc = make_float2(0.f, 0.f);
+    for (uint32_t j2 = 0; j2 < G; j2++) {
+        const float2 v = x[(size_t)j2 * Mg], w = ph[j2];
+        acc.x = fmaf(v.x, w.x, fmaf(-v.y, w.y, acc.x));
+        acc.y = fmaf(v.x, w.y, fmaf(v.y, w.x, acc.y));
+    }
+    const float2 w = ph[G + j1];
+    Z[i] = make_float2(acc.x * w.x - acc.y * w.y, acc.x * w.y + acc.y * w.x);
+}
+
+int launch_fold(const float2 *X, float2 *Z, const float2 *ph, uint32_t M, uint32_t G, uint32_t nf, hipStream_t s)
+{
+    const uint64_t total = (uint64_t)(M / G) * nf;
+    if (!total) return 0;
+    hipLaunchKernelGGL(k_fold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, X, Z, ph, M, G, total);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
 // DFT of every frame folded over all M channels: out[t] = sum_k Y[t][k] (DeNo --mix, Trans.hs:119-122), M = 1024 / 4096
 bool dft_mix_supported(uint32_t M) { return M == 1024 || M == 4096; }
 int launch_dft_mix(const float2 *X, float2 *out, const float2 *tw, uint32_t M, uint32_t nf, hipStream_t s)

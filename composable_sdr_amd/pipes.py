@@ -242,6 +242,7 @@ class ChainConfig:
     mix: bool = False
     chan_first: int = 0
     chan_count: int = 0
+    chan_stride: int = 0        # G > 1: interleaved ownership, channels chan_first + G*m (pruned DFT)
     device: int = -1
     max_frames: int = 4096
     flags: int = _lib.FLAG_QUIET
@@ -264,13 +265,14 @@ class Chain:
         c.wbfm_decim, c.deemph_fc = cfg.decim, cfg.deemph_fc
         c.kf, c.mix = cfg.kf, int(cfg.mix)
         c.chan_first, c.chan_count = cfg.chan_first, cfg.chan_count
+        c.chan_stride = cfg.chan_stride
         c.device, c.max_frames, c.flags = cfg.device, cfg.max_frames, cfg.flags
         c.pfb_m, c.pfb_as = cfg.pfb_m, cfg.pfb_as
         h = C.c_void_p()
         check(lib().csdr_chain_create(C.byref(c), C.byref(h)))
         self._h = _Handle(h, lib().csdr_chain_destroy)
         self.M = cfg.channels
-        self.C = cfg.chan_count or (cfg.channels - cfg.chan_first)
+        self.C = cfg.channels // cfg.chan_stride if cfg.chan_stride > 1 else (cfg.chan_count or (cfg.channels - cfg.chan_first))
         self.mixed = bool(cfg.mix) and self.M > 1
         self.out_dtype = np.float32 if cfg.demod in ("fm", "am", "wbfm") else np.complex64
         self.decim = cfg.decim if cfg.demod == "wbfm" else 1

@@ -14,6 +14,12 @@ Two partitions of the reference's `-c M` channelizer:
                   [chan_first, chan_first+chan_count) -- what the per-channel AGC/squelch/demod
                   tails and the per-channel sinks need.  `--mix` = local left-fold over the owned
                   channels + one all-reduce(SUM) of nf elements per chunk (latency-bound, 16-32 KiB).
+                  interleave=True: rank g owns the channels g, g+G, g+2G, ...; the
+                  C ABI prunes the M-point DFT of a frame to one length-G fold + one M/G-point DFT, so
+                  a rank does 1/G of the DFT, transpose and tail work (DC blocker, pre-mix and FIR
+                  still run on every branch: they are the part channel sharding cannot divide).
+                  With GPU-resident buffers the all-reduce runs on the output tensor itself
+                  (process_device_mix: RCCL, no host hop).
 
 Outputs stay on the rank that made them (per-channel files are written per rank); gather()
 collects them on rank 0 for tests.
@@ -48,7 +54,7 @@ def channel_bounds(M, world, rank):
 
 
 class ShardedChain:
-    def __init__(self, cfg: ChainConfig, mode="time", rank=None, world=None, group=None, chain_factory=Chain):
+    def __init__(self, cfg: ChainConfig, mode="time", rank=None, world=None, group=None, chain_factory=Chain, interleave=False):
         import torch.distributed as dist
         self.dist = dist if dist.is_available() and dist.is_initialized() else None
         self.rank = rank if rank is not None else (self.dist.get_rank(group) if self.dist else 0)
@@ -63,10 +69,17 @@ class ShardedChain:
                 raise ValueError("time stripes do not warm the %s tail's memory; use mode='channel'" % cfg.demod)
             self.chain = chain_factory(cfg)
         elif mode == "channel":
-            c0, cn = channel_bounds(cfg.channels, self.world, self.rank)
-            self.c0, self.cn = c0, cn
-            # the rank's partial mix is reduced across ranks afterwards
-            self.chain = chain_factory(replace(cfg, chan_first=c0, chan_count=cn)) if cn else None
+            self.interleave = bool(interleave) and self.world > 1
+            if self.interleave:
+                if cfg.channels % self.world:
+                    raise ValueError("interleaved channel ownership needs world | channels")
+                self.c0, self.cn = self.rank, cfg.channels // self.world
+                self.chain = chain_factory(replace(cfg, chan_first=self.rank, chan_count=0, chan_stride=self.world))
+            else:
+                c0, cn = channel_bounds(cfg.channels, self.world, self.rank)
+                self.c0, self.cn = c0, cn
+                # the rank's partial mix is reduced across ranks afterwards
+                self.chain = chain_factory(replace(cfg, chan_first=c0, chan_count=cn)) if cn else None
         else:
             raise ValueError(mode)
 
@@ -109,6 +122,15 @@ class ShardedChain:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy().view(partial.dtype).reshape(partial.shape)
 
+    def process_device_mix(self, x_dev, out_dev, stream=0):
+        """channel mode + mix with GPU-resident tensors (torch, on this rank's device): the chain writes the rank's partial
+        mix straight into `out_dev`, then ONE all-reduce(SUM) on that tensor over RCCL/xGMI -- no host copy.  `x_dev`:
+        the chunk (interleaved CF32 as float32), the same on every rank; returns the number of output elements."""
+        n = self.chain.process_device(x_dev.data_ptr(), x_dev.numel() // 2, out_dev.data_ptr(), stream)
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(out_dev, op=self.dist.ReduceOp.SUM, group=self.group)
+        return n
+
     def gather(self, local):
         """Collect every rank's output on rank 0 (time mode: concatenated in time; channel mode:
         stacked by channel).  Returns None on other ranks."""
@@ -118,5 +140,10 @@ class ShardedChain:
         self.dist.gather_object(local, objs, dst=0, group=self.group)
         if self.rank != 0:
             return None
+        if self.mode == "channel" and getattr(self, "interleave", False):
+            full = np.empty((self.cfg.channels,) + objs[0].shape[1:], dtype=objs[0].dtype)
+            for g, o in enumerate(objs):
+                full[g::self.world] = o                  # row m of rank g is channel g + G*m
+            return full
         objs = [o for o in objs if o is not None and o.size]
         return np.concatenate(objs, axis=-1 if self.mode == "time" else 0)

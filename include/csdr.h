@@ -208,6 +208,12 @@ typedef struct csdr_chain_cfg {
     float    pfb_as;            /* stop-band attenuation, 0 = 80 dB (Liquid.chs:813)     */
     uint32_t wbfm_decim;        /* DeWBFM decim (SoapySDR.hs:252-259); 0 = 4             */
     float    deemph_fc;         /* DeWBFM de-emphasis corner 5000/quadRate (Liquid.chs:655); 0 = 0.025 */
+    uint32_t chan_stride;       /* G > 1: interleaved channel ownership for channel-sharded multi-GPU runs
+                                 * (SURVEY 8e(A)): this handle produces the channels chan_first, chan_first + G, ...
+                                 * (chan_first < G, G divides channels, chan_count 0 or channels/G); output row m is
+                                 * channel chan_first + G*m.  The M-point DFT of a frame is pruned to one length-G fold
+                                 * plus one (channels/G)-point DFT, so a shard does 1/G of the DFT and tail work
+                                 * (DC blocker, pre-mix and FIR still see every branch).  0 / 1 = contiguous shard. */
 } csdr_chain_cfg;
 
 void csdr_chain_cfg_default(csdr_chain_cfg *cfg, uint32_t channels);

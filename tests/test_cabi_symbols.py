@@ -33,7 +33,7 @@ def test_cfg_struct_matches_header_layout():
     from composable_sdr_amd import _lib
     cfg = _lib.ChainCfg()
     _lib.lib().csdr_chain_cfg_default(C.byref(cfg), 256)
-    assert cfg.struct_size == C.sizeof(_lib.ChainCfg) == 68
+    assert cfg.struct_size == C.sizeof(_lib.ChainCfg) == 72
     assert (cfg.channels, cfg.dc_block, cfg.max_frames, cfg.pfb_m) == (256, 1, 4096, 7)
     assert abs(cfg.dc_alpha - 0.0005) < 1e-9 and abs(cfg.pfb_as - 80.0) < 1e-6 and cfg.device == -1
 

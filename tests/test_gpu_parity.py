@@ -11,6 +11,8 @@ inputs.  Tolerances (north_star: "within a stated float tolerance"):
   mix                      : the HIP path folds channels in the reference's left-to-right
                              order: same tolerance as the unmixed output times sqrt(M)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -224,6 +226,54 @@ def test_chain_channel_shard_equals_slice_of_full():
     part = cs.Chain(channels=M, demod="fm", chan_first=8, chan_count=12).process(x)
     assert part.shape == (12, 80)
     assert np.array_equal(part, full[8:20])
+
+
+@pytest.mark.parametrize("M,G,demod,agc,mix", [(256, 8, "fm", 0.0, False), (256, 2, "none", 0.0, False), (64, 4, "fm", 11.0, False),
+                                               (20, 4, "none", 0.0, False), (20, 2, "fm", 0.0, True), (4096, 8, "none", 0.0, True),
+                                               (1024, 8, "fm", 0.0, False)])
+def test_chain_interleaved_shard_pruned_dft_equals_rows_of_full(M, G, demod, agc, mix):
+    """chan_stride = G: shard g produces the channels g, g + G, ... through one length-G fold + one M/G-point DFT per frame
+    (SURVEY 8e(A)); every shard must equal those rows of the oracle's full output, and the mixed shards must add up to the
+    full mix (what the multi-GPU all-reduce does)."""
+    frames = [96, 40, 7] if M >= 1024 else [700, 300, 41]
+    x = synth_cf32(M * sum(frames), M, seed=900 + M)
+    want_full = O.Chain(M, demod=demod, kf=0.3, agc_db=agc, mix=False)
+    wf, pos = [], 0
+    for f in frames:
+        wf.append(want_full.process(x[pos * M:(pos + f) * M])); pos += f
+    wf = np.concatenate(wf, axis=1)
+    acc = None
+    for g in sorted({0, 1, G - 1}) if not mix else range(G):
+        ch = cs.Chain(channels=M, demod=demod, kf=0.3, agc=agc, mix=mix, chan_first=g, chan_stride=G, max_frames=max(frames))
+        assert "pruned-dft" in ch.path
+        got, pos = [], 0
+        for f in frames:
+            got.append(ch.process(x[pos * M:(pos + f) * M])); pos += f
+        got = np.concatenate(got, axis=-1)
+        ch.close()
+        if mix:
+            acc = got.astype(np.complex128 if demod == "none" else np.float64) if acc is None else acc + got
+            continue
+        want = wf[g::G]
+        assert got.shape == want.shape
+        if demod == "fm":
+            d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / 0.3))
+            if agc:
+                assert int(np.sum((got == 0) != (want == 0))) == 0
+                assert np.median(d[want != 0]) < 2e-5
+            else:
+                tone = (np.arange(g, M, G) % 4) == 1
+                assert np.median(d) < 2e-5 and (not tone.any() or np.quantile(d[tone], 0.999) < 5e-5)
+        else:
+            # relative to the whole band: a shard may hold only the weak (noise-only) channels, while the f32 rounding
+            # of a frame's DFT scales with its strongest bins
+            e = np.sqrt(np.mean(np.abs(got.astype(np.complex128) - want) ** 2)) / np.sqrt(np.mean(np.abs(wf) ** 2))
+            assert e < 1e-5, e
+    if mix:
+        wm = wf.astype(np.complex128 if demod == "none" else np.float64).sum(axis=0)
+        scale = np.abs(wm).max() + np.abs(wf).max()
+        print(f"interleaved shards M={M} G={G} {demod} mix: max |sum of shards - full mix| = {np.abs(acc - wm).max():.3e} of {scale:.2f}")
+        assert np.abs(acc - wm).max() < 2e-4 * scale * (np.sqrt(M) if demod == "fm" else 1.0)
 
 
 def test_chain_chunk_size_invariance():
@@ -450,10 +500,39 @@ def test_sharded_two_ranks_on_one_gpu(mode):
     full = np.concatenate([cs.Chain(channels=M, max_frames=nf).process(x)], axis=1)
     parts = [ShardedChain(cfg, mode=mode, rank=r, world=2).process_stream(x) for r in range(2)]
     got = np.concatenate(parts, axis=1 if mode == "time" else 0)
+    if mode == "channel":
+        il = [ShardedChain(cfg, mode=mode, rank=r, world=2, interleave=True).process_stream(x) for r in range(2)]
+        gi = np.empty_like(got); gi[0::2], gi[1::2] = il[0], il[1]
+        print("interleaved channel shards vs contiguous rel-rms", rel_rms(gi, got))
+        assert rel_rms(gi, got) < 1e-6
     assert got.shape == full.shape
     print(mode, "sharded vs single rel-rms", rel_rms(got, full))
     assert rel_rms(got, full) < (2e-6 if mode == "time" else 1e-7)
     assert np.array_equal(want, full[:, :512]) or rel_rms(want, full[:, :512]) < 1e-6
+
+
+@pytest.mark.parametrize("shard,mix", [("channel", True), ("channel", False), ("time", False)])
+def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
+    """bench.py's N > 1 paths end to end under torch.distributed.run with two ranks (both on this box's only GPU, gloo
+    instead of RCCL: CSDR_BENCH_ONE_GPU): the JSON line names the partition, the collective and the rank count."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CSDR_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "8192",
+           "--shard", shard, "--demod", "none", "--no-cpu-baseline", "--no-agc-variant"] + (["--mix"] if mix else [])
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["rccl_ranks"] == 2 and r["value"] > 0
+    if shard == "channel":
+        assert r["scaling"] == "strong" and "channel-interleaved" in r["config"]["sharding"] and "pruned-dft" in r["config"]["path"]
+        assert ("all-reduce" in r["config"]["collective"]) == mix
+    else:
+        assert r["scaling"] == "weak" and "time stripes" in r["config"]["sharding"] and r["config"]["collective"] == "none"
 
 
 def test_seek_frames_sets_premix_phase():

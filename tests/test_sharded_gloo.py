@@ -25,10 +25,12 @@ class OracleChain:
         self.full = O.Chain(cfg.channels, dc_block=cfg.dc_block, agc_db=cfg.agc, demod=cfg.demod, kf=cfg.kf, mix=False)
         self.c0 = cfg.chan_first
         self.cn = cfg.chan_count or cfg.channels - cfg.chan_first
+        self.G = cfg.chan_stride if cfg.chan_stride > 1 else 1
         self.O = O
 
     def process(self, x):
-        y = self.full.process(x)[self.c0:self.c0 + self.cn]
+        y = self.full.process(x)
+        y = y[self.c0::self.G] if self.G > 1 else y[self.c0:self.c0 + self.cn]
         if self.cfg.mix and self.cfg.channels > 1:
             return self.O.mix_f32(y) if y.dtype == np.float32 else y.sum(axis=0).astype(y.dtype)
         return y
@@ -42,7 +44,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, mix, q, demod="fm"):
+def _worker(rank, world, port, mode, mix, q, demod="fm", interleave=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -53,7 +55,7 @@ def _worker(rank, world, port, mode, mix, q, demod="fm"):
         M, nf = 16, 6000
         x = synth_cf32(M * nf, M, seed=42)
         cfg = ChainConfig(channels=M, demod=demod, kf=0.3, mix=mix, max_frames=1024)
-        sc = ShardedChain(cfg, mode=mode, chain_factory=OracleChain)
+        sc = ShardedChain(cfg, mode=mode, chain_factory=OracleChain, interleave=interleave)
         local = sc.process_stream(x)
         if mode == "channel" and mix:
             local = sc.mix_allreduce(local)
@@ -67,11 +69,11 @@ def _worker(rank, world, port, mode, mix, q, demod="fm"):
         dist.destroy_process_group()
 
 
-def _run(mode, mix, demod="fm"):
+def _run(mode, mix, demod="fm", interleave=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, mix, q, demod)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, mix, q, demod, interleave)) for r in range(2)]
     for p in procs:
         p.start()
     full, want = q.get(timeout=120)
@@ -106,6 +108,16 @@ def test_channel_shards_mix_allreduce_world2():
     assert full.shape == want.shape
     # per-rank left folds + one SUM: same terms, different association
     assert np.max(np.abs(full - want)) < 1e-4
+
+
+def test_interleaved_channel_shards_world2():
+    """rank g owns channels g, g + 2, ...: gather puts the rows back in channel order; the mixed variant reduces the two
+    partial left folds with one all-reduce"""
+    full, want = _run("channel", False, "fm", interleave=True)
+    assert np.array_equal(full, want)
+    full, want = _run("channel", True, "none", interleave=True)
+    assert full.shape == want.shape
+    assert np.max(np.abs(full - want)) < 1e-4 * max(1.0, np.abs(want).max())
 
 
 def test_bounds_helpers():
