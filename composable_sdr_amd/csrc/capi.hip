@@ -119,6 +119,8 @@ struct csdr_chain {
     float2 *d_tw = nullptr, *d_nco_tab = nullptr, *d_dcstate = nullptr, *d_scratch = nullptr;
     uint32_t G = 1;                  // chan_stride: interleaved shard g = c0 of G (generic route, pruned DFT)
     float2 *d_tw_g = nullptr, *d_fold_ph = nullptr, *d_fold = nullptr;   // (M/G)-point twiddles, fold phasors, folded frames
+    bool mix_identity = false;       // DeNo --mix over all channels: M * (branch-0 FIR) instead of bank + DFT + sum
+    float2 *d_u0 = nullptr, *d_u0hist = nullptr;     // branch-0 samples of the call behind p - 1 of history; history between calls
     float2 *d_u = nullptr, *d_hist_tmp = nullptr, *d_A = nullptr, *d_B = nullptr;
     AgcState *d_agc = nullptr;
     float2 *d_rp[2] = {nullptr, nullptr}; int rp_cur = 0;
@@ -606,6 +608,7 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
     h->theta = 0; h->tab_pos = 0; h->rp_cur = 0;
     CSDR_HIP(hipMemsetAsync(h->d_dcstate, 0, sizeof(float2), s));
     if (h->d_u) CSDR_HIP(hipMemsetAsync(h->d_u, 0, sizeof(float2) * (size_t)(h->p - 1) * h->M, s));
+    if (h->d_u0hist) CSDR_HIP(hipMemsetAsync(h->d_u0hist, 0, sizeof(float2) * (h->p - 1), s));
     if (h->d_agc) { int r = launch_agc_init(h->d_agc, h->C, s); if (r) return r; }
     if (h->d_rp[0]) {
         CSDR_HIP(hipMemsetAsync(h->d_rp[0], 0, sizeof(float2) * h->C, s));
@@ -743,6 +746,12 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         }
         if ((r = dev_alloc(&h->d_A, h->max_nx)) || (r = dev_alloc(&h->d_B, h->max_nx))) return fail(r);
         if (M > 1 && cfg->dc_block && (r = dctile_create(h->dc, h->max_nx, &h->dctile))) return fail(r);
+        h->mix_identity = M > 1 && G == 1 && C == M && cfg->mix && cfg->demod == CSDR_DEMOD_NONE && cfg->agc_threshold_db == 0.0f &&
+                          h->dctile && !(cfg->flags & CSDR_FLAG_NO_MIX_IDENTITY) && !am;
+        if (h->mix_identity) {
+            if ((r = dev_alloc(&h->d_u0, (size_t)(h->p - 1) + h->max_nf)) || (r = dev_alloc(&h->d_u0hist, h->p - 1))) return fail(r);
+            h->path = "generic+mix-identity"; h->timed_kernel = "k_dc_tile";
+        }
         if (G > 1) {
             const uint32_t Mg = M / G;
             std::vector<float2> twg(Mg), ph(G + Mg);
@@ -824,6 +833,18 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
     if (M > 1) {
         const size_t hist = (size_t)(h->p - 1) * M;
         nco.theta0 = h->theta; nco.d_theta = h->d_theta; nco.tab_len = h->tab_len; nco.tab_pos = h->tab_pos; nco.up = 0;
+        if (h->mix_identity) {
+            // sum over ALL channels of a frame = M * X_t[0]: DC blocker + pre-mix on the whole stream, every M-th sample kept,
+            // then the 2m-tap FIR of polyphase branch 0 (no bank, no DFT, no channel sum; 8 B read per input sample)
+            CSDR_HIP(hipMemcpyAsync(h->d_u0, h->d_u0hist, sizeof(float2) * (h->p - 1), hipMemcpyDeviceToDevice, s));
+            if ((r = h->timer.begin(s))) return r;
+            if ((r = dctile_process(h->dctile, d_in, h->d_u0 + (h->p - 1), nx, true, nco, h->d_nco_tab, s, M))) return r;
+            if ((r = h->timer.end(s))) return r;
+            if ((r = launch_branch0_fir(h->d_u0, h->d_taps, (float2 *)d_out, h->d_u0hist, M, h->p, nf, s))) return r;
+            h->theta += nx * h->d_theta;
+            if (h->tab_len) h->tab_pos = (uint32_t)(((uint64_t)h->tab_pos + nx) % h->tab_len);
+            return 0;
+        }
         float2 *u_new = h->d_u + hist;
         if (h->dctile) r = dctile_process(h->dctile, d_in, u_new, nx, true, nco, h->d_nco_tab, s);
         else r = launch_dc_mix(d_in, u_new, nx, h->cfg.dc_block != 0, h->dc, h->d_dcstate, h->d_scratch, true, nco, h->d_nco_tab, s);
@@ -1209,7 +1230,7 @@ int csdr_chain_destroy(csdr_chain *h)
     if (h->agc_tail) agc_tail_destroy(h->agc_tail);
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
-                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1], h->d_tw_g, h->d_fold_ph, h->d_fold,
+                    h->d_agc, h->d_rp[0], h->d_rp[1], h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1], h->d_tw_g, h->d_fold_ph, h->d_fold, h->d_u0, h->d_u0hist,
                     h->d_wbf, h->d_wbo, h->d_wbh, h->d_wbhist[0], h->d_wbhist[1], h->d_wbst[0], h->d_wbst[1]};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &sl : h->slot) {

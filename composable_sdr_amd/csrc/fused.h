@@ -64,8 +64,11 @@ void big_destroy(BigPlan *plan);
 struct DcTilePlan;
 int  dctile_create(const DcParams &dc, uint64_t max_samples, DcTilePlan **out);
 int  dctile_reset(DcTilePlan *plan, hipStream_t s);
+// pick > 0: y receives only the samples whose index in this call is a multiple of `pick` (n / pick of them)
 int  dctile_process(DcTilePlan *plan, const float2 *x, float2 *y, uint32_t n, bool do_mix, const NcoParams &nco,
-                    const float2 *nco_tab, hipStream_t s);
+                    const float2 *nco_tab, hipStream_t s, uint32_t pick = 0);
+// out[t] = M sum_n taps[(M-1) + n M] u0[(p-1) + t - n]; hist_out <- the last p - 1 samples of u0 (the next call's history)
+int  launch_branch0_fir(const float2 *u0, const float *taps, float2 *out, float2 *hist_out, uint32_t M, uint32_t p, uint32_t nf, hipStream_t s);
 // sticky device-side error word (a look-back wait hit its spin limit); reads, then clears it; synchronises
 int  dctile_status(DcTilePlan *plan, unsigned *status);
 void dctile_destroy(DcTilePlan *plan);

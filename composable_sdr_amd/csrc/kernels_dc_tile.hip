@@ -18,6 +18,7 @@ struct DcTileArgs {
     unsigned *ticket; u64 *agg; unsigned *status;
     uint32_t epoch;
     NcoParams nco; const float2 *nco_tab; int do_mix;
+    uint32_t pick; float2 *ypick;   // pick > 0: store only the samples whose stream index is a multiple of `pick`, compacted (branch 0 of every frame)
     float alpha, beta;
     float wtile[LOOKBACK + 2], b16[16], b256[17], bj[16];
 };
@@ -151,8 +152,12 @@ __global__ __launch_bounds__(256) void k_dc_tile(DcTileArgs D)
         for (int it = 0; it < 8; it++) {
             const float sa = D.nco.up ? ca[it].y : -ca[it].y, sb = D.nco.up ? cb[it].y : -cb[it].y;
             const float4 v = yv[it];
-            reinterpret_cast<float4 *>(D.y)[(size_t)b * 2048 + dst[it]] =
-                make_float4(v.x * ca[it].x - v.y * sa, v.x * sa + v.y * ca[it].x, v.z * cb[it].x - v.w * sb, v.z * sb + v.w * cb[it].x);
+            const float4 o = make_float4(v.x * ca[it].x - v.y * sa, v.x * sa + v.y * ca[it].x, v.z * cb[it].x - v.w * sb, v.z * sb + v.w * cb[it].x);
+            if (D.pick) {
+                const uint32_t s0 = n0 + 2u * dst[it];                       // stream index of the pair's first sample
+                if (s0 % D.pick == 0) D.ypick[s0 / D.pick] = make_float2(o.x, o.y);
+                if ((s0 + 1) % D.pick == 0) D.ypick[(s0 + 1) / D.pick] = make_float2(o.z, o.w);
+            } else reinterpret_cast<float4 *>(D.y)[(size_t)b * 2048 + dst[it]] = o;
         }
     } else {
         const float4 *R4 = reinterpret_cast<const float4 *>(R);
@@ -181,13 +186,151 @@ __global__ __launch_bounds__(256) void k_dc_tile(DcTileArgs D)
                     yy = make_float2(yy.x * c_ - yy.y * s_, yy.x * s_ + yy.y * c_);
                 }
             }
-            if (s0 + 1 < nleft) reinterpret_cast<float4 *>(D.y)[(size_t)b * 2048 + 8 * q + i] = make_float4(y0.x, y0.y, y1.x, y1.y);
+            if (D.pick) {
+                if ((n0 + s0) % D.pick == 0) D.ypick[(n0 + s0) / D.pick] = y0;
+                if (s0 + 1 < nleft && (n0 + s0 + 1) % D.pick == 0) D.ypick[(n0 + s0 + 1) / D.pick] = y1;
+            } else if (s0 + 1 < nleft) reinterpret_cast<float4 *>(D.y)[(size_t)b * 2048 + 8 * q + i] = make_float4(y0.x, y0.y, y1.x, y1.y);
             else D.y[n0 + s0] = y0;
         }
     }
 }
 
+// Lean variant for pick = a multiple of 4096 (the 4096-channel --mix shape): only the DC-blocker state in front of every tile
+// is needed, so a tile is folded straight out of the coalesced loads (decayed sum with per-lane weights: no LDS staging, no
+// per-sample scan, no store), the aggregates go through the same decoupled look-back, and one lane emits the tile's
+// first sample y0 = x0 - alpha v, pre-mixed.  8 B read per sample, nothing else.
+constexpr int PICK_T = 8;        // tiles per workgroup (one global ticket per 8 tiles: a single ticket word hands out ~90 per microsecond)
+__global__ __launch_bounds__(256) void k_dc_pick_tile(DcTileArgs D, float l2beta)
+{
+    __shared__ float2 red[4];
+    __shared__ float2 carry_s;
+    __shared__ unsigned tile_s;
+    const int tid = threadIdx.x;
+    if (tid == 0) tile_s = atomicAdd(D.ticket, 1u);
+    __syncthreads();
+    const unsigned b0 = tile_s * PICK_T;
+    if (b0 >= D.nb) return;
+    const unsigned b1 = min(D.nb, b0 + PICK_T);
+    float w0[8], w1[8];
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
+            const int i = (slot & 7) ^ ((q >> 1) & 7);
+            const int n = 16 * q + 2 * i;
+            w0[it] = exp2f((float)(4095 - n) * l2beta); w1[it] = exp2f((float)(4094 - n) * l2beta);
+        }
+    }
+    // pass 1: the zero-state aggregates of my tiles depend on nothing: fold and publish all of them first (a workgroup that
+    // waited for its predecessors before publishing would chain the whole launch)
+    float4 raw[8], nxt[8];
+    tile_load(reinterpret_cast<const float4 *>(D.x) + (size_t)b0 * 2048, 256, raw, tid);
+    float2 aggs[PICK_T];
+#pragma unroll
+    for (int u = 0; u < PICK_T; u++) {
+        const unsigned b = b0 + u;
+        aggs[u] = make_float2(0.f, 0.f);
+        if (b < b1) {
+            if (b + 1 < b1) tile_load(reinterpret_cast<const float4 *>(D.x) + (size_t)(b + 1) * 2048, 256, nxt, tid);
+            float2 p = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                p = cfma(make_float2(raw[it].x, raw[it].y), w0[it], p);
+                p = cfma(make_float2(raw[it].z, raw[it].w), w1[it], p);
+            }
+            const float2 agg = wg_sum(p, red, tid);                 // v after the tile from a zero state
+            aggs[u] = agg;
+            if (tid == 0) {
+                __hip_atomic_store(&D.agg[2 * (size_t)b], ((u64)D.epoch << 32) | __float_as_uint(agg.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&D.agg[2 * (size_t)b + 1], ((u64)D.epoch << 32) | __float_as_uint(agg.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int it = 0; it < 8; it++) raw[it] = nxt[it];
+        }
+    }
+    // pass 2: state in front of my first tile from the ten tiles before it, then one picked sample per tile
+    if (tid < 64) {
+        const unsigned b = b0;
+        const int k = tid;
+        float2 cb = make_float2(0.f, 0.f);
+        const bool need = (k >= 1 && k <= LOOKBACK && (int)b - k >= 0);
+        u64 g0 = 0, g1 = 0;
+        unsigned spins = 0;
+        bool ok = !need;
+        while (true) {
+            if (need && !ok) {
+                g0 = __hip_atomic_load(&D.agg[2 * (size_t)(b - k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                g1 = __hip_atomic_load(&D.agg[2 * (size_t)(b - k) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(g0 >> 32) == D.epoch && (unsigned)(g1 >> 32) == D.epoch;
+            }
+            if (__all(ok)) break;
+            if (++spins > SPIN_LIMIT) { if (k == 0) atomicOr(D.status, 4u); break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        if (need) cb = make_float2(__uint_as_float((unsigned)g0) * D.wtile[k - 1], __uint_as_float((unsigned)g1) * D.wtile[k - 1]);
+        if (k == 0 && b <= LOOKBACK) { const float2 v = D.vend_in[0]; cb = make_float2(v.x * D.wtile[b], v.y * D.wtile[b]); }
+        cb = cadd(cb, dpp2<0x111>(cb)); cb = cadd(cb, dpp2<0x112>(cb));
+        cb = cadd(cb, dpp2<0x114>(cb)); cb = cadd(cb, dpp2<0x118>(cb));
+        if (k == 15) carry_s = cb;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float2 c = carry_s;                                            // v before tile b0
+#pragma unroll
+        for (int u = 0; u < PICK_T; u++) {
+            const unsigned b = b0 + u;
+            if (b >= b1) break;
+            const uint32_t n0 = b * 4096u;
+            if (n0 % D.pick == 0) {
+                const float2 x0 = D.x[n0];
+                float2 y = make_float2(fmaf(-D.alpha, c.x, x0.x), fmaf(-D.alpha, c.y, x0.y));
+                if (D.do_mix) {
+                    float c_, s_;
+                    if (D.nco.tab_len) { const float2 cs = D.nco_tab[(D.nco.tab_pos + n0) % D.nco.tab_len]; c_ = cs.x; s_ = cs.y; }
+                    else {
+                        const uint32_t theta = D.nco.theta0 + n0 * D.nco.d_theta;
+                        sincosf((float)(6.283185307179586 * (double)(float)theta / 4294967296.0), &s_, &c_);
+                    }
+                    if (!D.nco.up) s_ = -s_;
+                    y = make_float2(y.x * c_ - y.y * s_, y.x * s_ + y.y * c_);
+                }
+                D.ypick[n0 / D.pick] = y;
+            }
+            c = cfma(c, D.wtile[1], aggs[u]);                       // v before the next tile
+            if (b == D.nb - 1) D.vend_out[0] = c;
+        }
+    }
+}
+
+// DeNo --mix over ALL channels of an M-channel bank (Trans.hs:119-122 after Liquid.chs:843): sum_k Y_t[k] = M X_t[0], because
+// sum_k W_M^{jk} = M delta[j]: only polyphase branch 0 of every frame survives the channel sum.  u0[13 + t] = DC-blocked,
+// pre-mixed sample t*M of the stream (13 samples of history in front); out[t] = M sum_n h[(M-1) + n M] u0[13 + t - n].
+__global__ __launch_bounds__(256) void k_branch0_fir(const float2 *__restrict__ u0, const float *__restrict__ taps, float2 *__restrict__ out,
+                                                    float2 *__restrict__ hist_out, uint32_t M, uint32_t p, uint32_t nf)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < nf) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (uint32_t n = p; n-- > 0;) {                 // oldest tap first, like the bank's dot product
+            const float h = taps[(M - 1) + (size_t)n * M];
+            const float2 v = u0[(p - 1) + t - n];
+            acc.x = fmaf(v.x, h, acc.x); acc.y = fmaf(v.y, h, acc.y);
+        }
+        out[t] = make_float2(acc.x * (float)M, acc.y * (float)M);
+    }
+    if (t < p - 1) hist_out[t] = u0[nf + t];              // the last p - 1 branch-0 samples: history of the next call
+}
+
 }  // namespace
+
+int launch_branch0_fir(const float2 *u0, const float *taps, float2 *out, float2 *hist_out, uint32_t M, uint32_t p, uint32_t nf, hipStream_t s)
+{
+    if (!nf) return 0;
+    hipLaunchKernelGGL(k_branch0_fir, dim3((nf + 255) / 256), dim3(256), 0, s, u0, taps, out, hist_out, M, p, nf);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
 
 struct DcTilePlan {
     uint32_t max_nb = 0, epoch = 0;
@@ -249,15 +392,19 @@ int dctile_reset(DcTilePlan *p, hipStream_t s)
 }
 
 int dctile_process(DcTilePlan *p, const float2 *x, float2 *y, uint32_t n, bool do_mix, const NcoParams &nco,
-                   const float2 *nco_tab, hipStream_t s)
+                   const float2 *nco_tab, hipStream_t s, uint32_t pick)
 {
     if (!n) return 0;
     DcTileArgs D = p->proto;
     D.x = x; D.y = y; D.n = n; D.nb = (n + 4095) / 4096;
+    D.pick = pick; D.ypick = y;                          // pick > 0: y receives n / pick samples (calls start on a multiple of pick)
     D.vend_in = p->d_vend[p->cur]; D.vend_out = p->d_vend[p->cur ^ 1];
     if (++p->epoch == 0) p->epoch = 1;
     D.epoch = p->epoch; D.nco = nco; D.nco_tab = nco_tab; D.do_mix = do_mix ? 1 : 0;
     CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
+    if (pick && pick % 4096u == 0 && n % 4096u == 0 && D.beta > 0.f)
+        hipLaunchKernelGGL(k_dc_pick_tile, dim3((D.nb + PICK_T - 1) / PICK_T), dim3(256), 0, s, D, (float)std::log2((double)D.beta));
+    else
     hipLaunchKernelGGL(k_dc_tile, dim3(D.nb), dim3(256), 0, s, D);
     CSDR_HIP(hipGetLastError());
     p->cur ^= 1;

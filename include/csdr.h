@@ -61,6 +61,10 @@ extern "C" {
 #define CSDR_FLAG_AGC_SEQUENTIAL 8u /* run the per-channel AGC as one lane per channel instead of
                                        the time-parallel verified tail; both give bit-identical
                                        output (for A/B tests)                                */
+#define CSDR_FLAG_NO_MIX_IDENTITY 16u /* DeNo --mix over all channels of the any-M route: sum_k Y[k] = M * X[0] (the sum of all
+                                        * DFT bins of a frame is M times its first input), so the product path computes the
+                                        * DC blocker on the whole stream and the FIR of polyphase branch 0 only.  Set this flag
+                                        * to run the full bank + DFT + channel sum instead (same result to f32 rounding).      */
 
 const char *csdr_last_error(void);
 int  csdr_device_count(void);

@@ -276,6 +276,34 @@ def test_chain_interleaved_shard_pruned_dft_equals_rows_of_full(M, G, demod, agc
         assert np.abs(acc - wm).max() < 2e-4 * scale * (np.sqrt(M) if demod == "fm" else 1.0)
 
 
+@pytest.mark.parametrize("M", [4096, 8192, 20, 64, 7])
+def test_chain_deno_mix_identity_equals_full_bank(M):
+    """DeNo --mix over all channels: sum_k Y_t[k] = M X_t[0] (the sum of all DFT bins is M times the first input), so the
+    product path runs the DC blocker on the stream and the FIR of polyphase branch 0 only.  It must agree with the full
+    bank + DFT + channel sum (CSDR_FLAG_NO_MIX_IDENTITY) and with the oracle's left fold, across calls."""
+    from composable_sdr_amd import _lib
+    frames = [48, 16, 5, 31] if M >= 1024 else [900, 300, 41, 1]          # 100 tiles at M = 4096: beyond the 10-tile look-back
+    x = synth_cf32(M * sum(frames), M, seed=700 + M, dc=0.2 - 0.1j)
+    fl = _lib.FLAG_QUIET | _lib.FLAG_FORCE_GENERIC
+    a = cs.Chain(channels=M, demod="none", mix=True, max_frames=max(frames), flags=fl)
+    b = cs.Chain(channels=M, demod="none", mix=True, max_frames=max(frames), flags=fl | _lib.FLAG_NO_MIX_IDENTITY)
+    assert "mix-identity" in a.path and "mix-identity" not in b.path
+    orc = O.Chain(M, demod="none", mix=True)
+    ga, gb, wo, pos = [], [], [], 0
+    for f in frames:
+        xa = x[pos * M:(pos + f) * M]; pos += f
+        ga.append(a.process(xa)); gb.append(b.process(xa)); wo.append(orc.process(xa))
+    ga, gb, wo = np.concatenate(ga), np.concatenate(gb), np.concatenate(wo)
+    # the full sum carries the rounding of M terms of size max|Y| (the identity does not): tolerance scaled by that
+    ymax = float(np.abs(O.Chain(M).process(x)).max())
+    tol = max(4e-7 * ymax * M, 1e-5 * float(np.abs(wo).max()))
+    print(f"mix identity M={M}: vs full bank max {np.abs(ga - gb).max():.3e}, vs oracle max {np.abs(ga - wo).max():.3e} (tolerance {tol:.3e}, |out| max {np.abs(wo).max():.2f})")
+    assert ga.shape == gb.shape == wo.shape
+    # the oracle's f32 DC blocker adds ulp(|v|)/2 of cancellation noise per sample at |DC| = 0.22 (see test_fused256_dc_state...)
+    assert np.abs(ga - gb).max() < tol and np.abs(ga - wo).max() < max(tol, 3e-4 * float(np.abs(wo).max()))
+    a.close(); b.close()
+
+
 def test_chain_chunk_size_invariance():
     M = 64
     x = synth_cf32(M * 300, M, seed=21)

@@ -7,6 +7,8 @@ TAG=${1:-run}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
+# keep only what tools/collect_profile.py reads (gpurun copies back at most 64 MiB)
+prune() { find $OUT -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" ! -name "args.txt" -delete; find $OUT -name "*.log" -size +200k -delete; }
 ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-agc-variant $*"
 KRE='k_'
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
@@ -18,3 +20,4 @@ rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$KRE" -f csv -d $OUT/pmc3 -o 
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$KRE" -f csv -d $OUT/pmc4 -o p -- python3 bench.py $ARGS > $OUT/pmc4.log 2>&1
 echo "$ARGS" > $OUT/args.txt
 grep -h '"metric"' $OUT/trace.log | head -1
+prune
