@@ -187,7 +187,7 @@ __device__ __forceinline__ float fast_atan2f(float y, float x)
 // ref * atan2f(y, x) for the run kernel's tail: degree-15 odd minimax polynomial (f32 evaluation error
 // <= 1.2e-7 rad), coefficients pre-scaled by ref; hp = ref*pi/2, pi = ref*pi.  Same signed-zero
 // behaviour as fast_atan2f; inputs are finite by construction (no Inf guard).
-struct PhaseK { float c[8]; float hp, pi; };
+struct PhaseK { float c[8]; float hp, pi, ref; };
 __host__ __device__ __forceinline__ PhaseK phase_consts(float ref)
 {
     PhaseK k;
@@ -195,57 +195,54 @@ __host__ __device__ __forceinline__ PhaseK phase_consts(float ref)
                         9.642146528e-02f, -5.591168255e-02f, 2.186254039e-02f, -4.054457881e-03f};
 #pragma unroll
     for (int i = 0; i < 8; i++) k.c[i] = c[i] * ref;
-    k.hp = 1.57079632679489662f * ref; k.pi = 3.14159265358979324f * ref;
+    k.hp = 1.57079632679489662f * ref; k.pi = 3.14159265358979324f * ref; k.ref = ref;
     return k;
 }
+// Selects with the condition in an SGPR pair: on gfx950 the VCC form of v_cndmask (what hipcc emits for `c ? a : b`) costs
+// 16 cycles per wave, the SGPR-mask form 4.6 (tools/probes/issue_probe2.hip).
+__device__ __forceinline__ float sel_abs_gt(float a, float b, float t, float f)        // |a| > |b| ? t : f
+{
+    unsigned long long m; float r;
+    asm("v_cmp_gt_f32_e64 %0, |%1|, |%2|" : "=s"(m) : "v"(a), "v"(b));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float sel_neg(float a, float t, float f)                    // sign bit of a (incl. -0) ? t : f
+{
+    unsigned long long m; float r;
+    asm("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
+    return r;
+}
+// ref * atan2f(y, x): literal (unscaled) coefficients keep the polynomial on plain v_fmaak (3 cycles; an SGPR operand costs
+// 4.7), the scale goes onto a = min / max before the last product.  Same signed-zero behaviour as fast_atan2f.
 __device__ __forceinline__ float scaled_atan2f(float y, float x, const PhaseK &k)
 {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
     const float a = mn * __builtin_amdgcn_rcpf(mx);
     const float z = a * a;
-    float p = k.c[7];
-#pragma unroll
-    for (int i = 6; i >= 0; i--) p = fmaf(p, z, k.c[i]);
-    float r = p * a;
-    r = (ay > ax) ? k.hp - r : r;
-    r = (__float_as_int(x) < 0) ? k.pi - r : r;
-    return copysignf(r, y);
+    float p = -4.054457881e-03f;
+    p = fmaf(p, z, 2.186254039e-02f);
+    p = fmaf(p, z, -5.591168255e-02f);
+    p = fmaf(p, z, 9.642146528e-02f);
+    p = fmaf(p, z, -1.390860826e-01f);
+    p = fmaf(p, z, 1.994656026e-01f);
+    p = fmaf(p, z, -3.332985938e-01f);
+    p = fmaf(p, z, 9.999993443e-01f);
+    float t = p * (a * k.ref);
+    t = sel_abs_gt(y, x, k.hp - t, t);
+    t = sel_neg(x, k.pi - t, t);
+    return copysignf(t, y);
 }
 
-// 16 freqdem samples at once, staged "vertically" (every step over all samples before the next step) so that the
-// dependent packed FMAs of one polynomial are 8 instructions apart instead of back to back (hipcc puts a wait state
-// between dependent packed ops; scheduling sample by sample cost 92 s_nop per tile).  Same arithmetic as
-// scaled_atan2f(fmaf(rp.x, r.x, rp.y*r.y) ...) per sample.
+// 16 freqdem samples of one channel (k_run256's tail): the compiler interleaves the independent samples
 __device__ __forceinline__ void freqdem16(const float2 (&v)[16], float2 prev, const PhaseK &k, float (&m)[16])
 {
-    float re[16], im[16], a[16], z[16], p[16];
 #pragma unroll
     for (int f = 0; f < 16; f++) {
         const float2 rp = f ? v[f - 1] : prev, r = v[f];
-        re[f] = fmaf(rp.x, r.x, rp.y * r.y);
-        im[f] = fmaf(rp.x, r.y, -(rp.y * r.x));
-    }
-#pragma unroll
-    for (int f = 0; f < 16; f++) {
-        const float ax = fabsf(re[f]), ay = fabsf(im[f]);
-        const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
-        a[f] = mn * __builtin_amdgcn_rcpf(mx);
-    }
-#pragma unroll
-    for (int f = 0; f < 16; f++) { z[f] = a[f] * a[f]; p[f] = k.c[7]; }
-#pragma unroll
-    for (int i = 6; i >= 0; i--) {
-#pragma unroll
-        for (int f = 0; f < 16; f++) p[f] = fmaf(p[f], z[f], k.c[i]);
-        __builtin_amdgcn_sched_barrier(0);          // keep the steps apart: the scheduler would re-serialise the chains
-    }
-#pragma unroll
-    for (int f = 0; f < 16; f++) {
-        float r = p[f] * a[f];
-        r = (fabsf(im[f]) > fabsf(re[f])) ? k.hp - r : r;
-        r = (__float_as_int(re[f]) < 0) ? k.pi - r : r;
-        m[f] = copysignf(r, im[f]);
+        m[f] = scaled_atan2f(fmaf(rp.x, r.y, -(rp.y * r.x)), fmaf(rp.x, r.x, rp.y * r.y), k);
     }
 }
 

@@ -70,23 +70,6 @@ __device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, c
     }
 }
 
-// |a| > |b| ? t : f  and  (sign bit of a) ? t : f  with the condition in an SGPR pair (the VCC form of v_cndmask
-// costs 16 cycles per wave on gfx950, the SGPR form 4.6)
-__device__ __forceinline__ float sel_abs_gt(float a, float b, float t, float f)
-{
-    unsigned long long m; float r;
-    asm("v_cmp_gt_f32_e64 %0, |%1|, |%2|" : "=s"(m) : "v"(a), "v"(b));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
-    return r;
-}
-__device__ __forceinline__ float sel_neg(float a, float t, float f)
-{
-    unsigned long long m; float r;
-    asm("v_cmp_gt_i32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
-    return r;
-}
-
 // ref * arg(conj(rp) r): the degree-15 minimax polynomial of scaled_atan2f with literal coefficients (v_fmaak), the
 // scale applied to a = min/max before the last product; hp = ref pi/2, pi = ref pi, tiny = 1e-37 held in VGPRs
 struct FmK { float tiny, ref, hp, pi; };
