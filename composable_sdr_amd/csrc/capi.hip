@@ -173,7 +173,7 @@ int csdr_dcblock_create(float alpha, uint32_t max_samples, csdr_dcblock **out)
     h->device = dev; h->max_n = max_samples ? max_samples : 1u << 20; h->dc = make_dc(alpha);
     if ((r = dev_alloc(&h->d_state, 1)) || (r = dev_alloc(&h->d_scratch, 2 * (size_t)(h->max_n / DC_BLOCK + 2))) ||
         (r = dev_alloc(&h->d_x, h->max_n)) || (r = dev_alloc(&h->d_y, h->max_n))) { csdr_dcblock_destroy(h); return r; }
-    CSDR_HIP(hipMemset(h->d_state, 0, sizeof(float2)));
+    CSDR_HIP_CLEAN(hipMemset(h->d_state, 0, sizeof(float2)), csdr_dcblock_destroy(h));
     *out = h;
     return CSDR_OK;
 }
@@ -192,6 +192,8 @@ int csdr_dcblock_process(csdr_dcblock *h, const float *x, uint32_t n, float *y)
     if (!h || (n && (!x || !y))) { set_error("dcblock: null argument"); return CSDR_ERR_INVALID; }
     if (n > h->max_n) { set_error("dcblock: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
     if (!n) return CSDR_OK;
+    DevGuard guard(h->device);
+    if (!guard.ok) { set_error("dcblock: cannot select device %d", h->device); return CSDR_ERR_HIP; }
     CSDR_HIP(hipMemcpy(h->d_x, x, sizeof(float2) * n, hipMemcpyHostToDevice));
     int r = csdr_dcblock_process_device(h, h->d_x, n, h->d_y, nullptr);
     if (r) return r;
@@ -228,6 +230,8 @@ static int nco_mix(csdr_nco *h, const float *x, uint32_t n, float *y, int up)
     if (!h || (n && (!x || !y))) { set_error("nco: null argument"); return CSDR_ERR_INVALID; }
     if (n > h->max_n) { set_error("nco: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
     if (!n) return CSDR_OK;
+    DevGuard guard(h->device);
+    if (!guard.ok) { set_error("nco: cannot select device %d", h->device); return CSDR_ERR_HIP; }
     CSDR_HIP(hipMemcpy(h->d_x, x, sizeof(float2) * n, hipMemcpyHostToDevice));
     NcoParams nco{}; nco.theta0 = h->theta; nco.d_theta = h->d_theta; nco.up = up;
     DcParams dc{};
@@ -281,6 +285,8 @@ int csdr_agc_process(csdr_agc *h, const float *x, uint32_t n, float *y)
     if (!h || (n && (!x || !y))) { set_error("agc: null argument"); return CSDR_ERR_INVALID; }
     if (n > h->max_n) { set_error("agc: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
     if (!n) return CSDR_OK;
+    DevGuard guard(h->device);
+    if (!guard.ok) { set_error("agc: cannot select device %d", h->device); return CSDR_ERR_HIP; }
     const size_t bytes = sizeof(float2) * (size_t)h->C * n;
     CSDR_HIP(hipMemcpy(h->d_z, x, bytes, hipMemcpyHostToDevice));
     int r = launch_agc(h->d_z, h->C, n, h->d_st, h->p, nullptr);
@@ -312,8 +318,8 @@ int csdr_freqdem_create(float kf, uint32_t nchan, uint32_t max_samples, csdr_fre
         (r = dev_alloc(&h->d_z, (size_t)nchan * h->max_n)) || (r = dev_alloc(&h->d_f, (size_t)nchan * h->max_n))) {
         csdr_freqdem_destroy(h); return r;
     }
-    CSDR_HIP(hipMemset(h->d_rp[0], 0, sizeof(float2) * nchan));
-    CSDR_HIP(hipMemset(h->d_rp[1], 0, sizeof(float2) * nchan));
+    CSDR_HIP_CLEAN(hipMemset(h->d_rp[0], 0, sizeof(float2) * nchan), csdr_freqdem_destroy(h));
+    CSDR_HIP_CLEAN(hipMemset(h->d_rp[1], 0, sizeof(float2) * nchan), csdr_freqdem_destroy(h));
     *out = h;
     return CSDR_OK;
 }
@@ -322,6 +328,8 @@ int csdr_freqdem_process(csdr_freqdem *h, const float *x, uint32_t n, float *m)
     if (!h || (n && (!x || !m))) { set_error("freqdem: null argument"); return CSDR_ERR_INVALID; }
     if (n > h->max_n) { set_error("freqdem: %u samples > max %u", n, h->max_n); return CSDR_ERR_SIZE; }
     if (!n) return CSDR_OK;
+    DevGuard guard(h->device);
+    if (!guard.ok) { set_error("freqdem: cannot select device %d", h->device); return CSDR_ERR_HIP; }
     CSDR_HIP(hipMemcpy(h->d_z, x, sizeof(float2) * (size_t)h->C * n, hipMemcpyHostToDevice));
     int r = launch_fm(h->d_z, h->d_f, h->C, n, h->ref, h->d_rp[h->cur], h->d_rp[h->cur ^ 1], nullptr);
     if (r) return r;
@@ -351,7 +359,7 @@ int csdr_iirfilt_create(uint32_t order, float fc, float f0, float ap, float as_d
     h->device = dev; h->C = nchan; h->max_n = max_samples ? max_samples : 4096; h->p = design_butter2_lowpass(fc);
     if (hipMalloc(&h->d_x, sizeof(float) * (size_t)nchan * h->max_n) != hipSuccess || hipMalloc(&h->d_st[0], sizeof(float2) * nchan) != hipSuccess ||
         hipMalloc(&h->d_st[1], sizeof(float2) * nchan) != hipSuccess) { set_error("iirfilt: device allocation failed"); csdr_iirfilt_destroy(h); return CSDR_ERR_HIP; }
-    CSDR_HIP(hipMemset(h->d_st[0], 0, sizeof(float2) * nchan)); CSDR_HIP(hipMemset(h->d_st[1], 0, sizeof(float2) * nchan));
+    CSDR_HIP_CLEAN(hipMemset(h->d_st[0], 0, sizeof(float2) * nchan), csdr_iirfilt_destroy(h)); CSDR_HIP_CLEAN(hipMemset(h->d_st[1], 0, sizeof(float2) * nchan), csdr_iirfilt_destroy(h));
     *out = h;
     return CSDR_OK;
 }
@@ -387,8 +395,8 @@ int csdr_firdecim_create(uint32_t decim, uint32_t nchan, uint32_t max_samples, c
     if (hipMalloc(&h->d_x, sizeof(float) * (size_t)nchan * h->max_n) != hipSuccess || hipMalloc(&h->d_y, sizeof(float) * (size_t)nchan * (h->max_n / decim + 1)) != hipSuccess ||
         hipMalloc(&h->d_h, sizeof(float) * taps.size()) != hipSuccess || hipMalloc(&h->d_hist[0], sizeof(float) * hist) != hipSuccess ||
         hipMalloc(&h->d_hist[1], sizeof(float) * hist) != hipSuccess) { set_error("firdecim: device allocation failed"); csdr_firdecim_destroy(h); return CSDR_ERR_HIP; }
-    CSDR_HIP(hipMemcpy(h->d_h, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice));
-    CSDR_HIP(hipMemset(h->d_hist[0], 0, sizeof(float) * hist)); CSDR_HIP(hipMemset(h->d_hist[1], 0, sizeof(float) * hist));
+    CSDR_HIP_CLEAN(hipMemcpy(h->d_h, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice), csdr_firdecim_destroy(h));
+    CSDR_HIP_CLEAN(hipMemset(h->d_hist[0], 0, sizeof(float) * hist), csdr_firdecim_destroy(h)); CSDR_HIP_CLEAN(hipMemset(h->d_hist[1], 0, sizeof(float) * hist), csdr_firdecim_destroy(h));
     *out = h;
     return CSDR_OK;
 }
@@ -434,15 +442,15 @@ int csdr_resamp_create(float rate, float As, uint32_t max_in, csdr_resamp **out)
     for (uint32_t s = 0; s <= K; s++) {
         h->H[s] = s < K ? 4 * h->d.m_hb[s] + 1 : P + 1;
         if ((r = dev_alloc(&h->d_buf[s], (size_t)h->H[s] + cap + 2))) return fail(r);
-        CSDR_HIP(hipMemset(h->d_buf[s], 0, sizeof(float2) * ((size_t)h->H[s] + cap + 2)));
+        CSDR_HIP_CLEAN(hipMemset(h->d_buf[s], 0, sizeof(float2) * ((size_t)h->H[s] + cap + 2)), csdr_resamp_destroy(h));
         if (s < K) {
             if (hipMalloc(&h->d_h[s], sizeof(float) * h->d.h_hb[s].size()) != hipSuccess) { set_error("resamp: allocation failed"); return fail(CSDR_ERR_HIP); }
-            CSDR_HIP(hipMemcpy(h->d_h[s], h->d.h_hb[s].data(), sizeof(float) * h->d.h_hb[s].size(), hipMemcpyHostToDevice));
+            CSDR_HIP_CLEAN(hipMemcpy(h->d_h[s], h->d.h_hb[s].data(), sizeof(float) * h->d.h_hb[s].size(), hipMemcpyHostToDevice), csdr_resamp_destroy(h));
             cap = cap / 2 + 1;
         }
     }
     if (hipMalloc(&h->d_pfb, sizeof(float) * h->d.pfb.size()) != hipSuccess) { set_error("resamp: allocation failed"); return fail(CSDR_ERR_HIP); }
-    CSDR_HIP(hipMemcpy(h->d_pfb, h->d.pfb.data(), sizeof(float) * h->d.pfb.size(), hipMemcpyHostToDevice));
+    CSDR_HIP_CLEAN(hipMemcpy(h->d_pfb, h->d.pfb.data(), sizeof(float) * h->d.pfb.size(), hipMemcpyHostToDevice), csdr_resamp_destroy(h));
     if ((r = dev_alloc(&h->d_out, (size_t)csdr_resamp_max_out(h, h->max_in)))) return fail(r);
     if (!getenv("CSDR_QUIET")) {
         // what msresamp_crcf_print shows in the reference ("Using resampler:", Liquid.chs:105-106)
@@ -555,8 +563,8 @@ int csdr_ampdem_create(float mod_index, uint32_t nchan, uint32_t max_samples, cs
         set_error("ampdem: device allocation failed");
         csdr_ampdem_destroy(h); return r ? r : CSDR_ERR_HIP;
     }
-    CSDR_HIP(hipMemset(h->d_q[0], 0, sizeof(float) * nchan));
-    CSDR_HIP(hipMemset(h->d_q[1], 0, sizeof(float) * nchan));
+    CSDR_HIP_CLEAN(hipMemset(h->d_q[0], 0, sizeof(float) * nchan), csdr_ampdem_destroy(h));
+    CSDR_HIP_CLEAN(hipMemset(h->d_q[1], 0, sizeof(float) * nchan), csdr_ampdem_destroy(h));
     *out = h;
     return CSDR_OK;
 }
@@ -688,12 +696,12 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         h->d_theta = nco_freq_word(pfb_premix_freq(M));
         h->tab_len = nco_period(h->d_theta, 1u << 17);
         if ((r = dev_alloc(&h->d_taps, h->taps.size()))) return fail(r);
-        CSDR_HIP(hipMemcpy(h->d_taps, h->taps.data(), sizeof(float) * h->taps.size(), hipMemcpyHostToDevice));
+        CSDR_HIP_CLEAN(hipMemcpy(h->d_taps, h->taps.data(), sizeof(float) * h->taps.size(), hipMemcpyHostToDevice), csdr_chain_destroy(h));
         if (h->tab_len) {
             std::vector<float2> tab(h->tab_len);
             for (uint32_t i = 0; i < h->tab_len; i++) { float c, s; nco_phasor(i * h->d_theta, &c, &s); tab[i] = make_float2(c, s); }
             if ((r = dev_alloc(&h->d_nco_tab, h->tab_len))) return fail(r);
-            CSDR_HIP(hipMemcpy(h->d_nco_tab, tab.data(), sizeof(float2) * h->tab_len, hipMemcpyHostToDevice));
+            CSDR_HIP_CLEAN(hipMemcpy(h->d_nco_tab, tab.data(), sizeof(float2) * h->tab_len, hipMemcpyHostToDevice), csdr_chain_destroy(h));
         }
         std::vector<float2> tw(M);
         for (uint32_t i = 0; i < M; i++) {
@@ -701,7 +709,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             tw[i] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
         if ((r = dev_alloc(&h->d_tw, M))) return fail(r);
-        CSDR_HIP(hipMemcpy(h->d_tw, tw.data(), sizeof(float2) * M, hipMemcpyHostToDevice));
+        CSDR_HIP_CLEAN(hipMemcpy(h->d_tw, tw.data(), sizeof(float2) * M, hipMemcpyHostToDevice), csdr_chain_destroy(h));
     }
     if (cfg->agc_threshold_db != 0.0f && (r = dev_alloc(&h->d_agc, C))) return fail(r);
     if (cfg->demod == CSDR_DEMOD_FM && ((r = dev_alloc(&h->d_rp[0], C)) || (r = dev_alloc(&h->d_rp[1], C)))) return fail(r);
@@ -750,7 +758,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
                           h->dctile && !(cfg->flags & CSDR_FLAG_NO_MIX_IDENTITY) && !am;
         if (h->mix_identity) {
             if ((r = dev_alloc(&h->d_u0, (size_t)(h->p - 1) + h->max_nf)) || (r = dev_alloc(&h->d_u0hist, h->p - 1))) return fail(r);
-            h->path = "generic+mix-identity"; h->timed_kernel = "k_dc_tile";
+            h->path = "generic+mix-identity"; h->timed_kernel = (M % 4096u == 0) ? "k_dc_pick_tile" : "k_dc_tile";
         }
         if (G > 1) {
             const uint32_t Mg = M / G;
@@ -768,8 +776,8 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     if (am) {
         h->am = true; h->am_mix = am_mix;
         if ((r = dev_alloc(&h->d_amz, (size_t)C * h->max_nf))) return fail(r);
-        if (am_mix) { CSDR_HIP(hipMalloc(&h->d_amf, sizeof(float) * (size_t)C * h->max_nf)); }
-        CSDR_HIP(hipMalloc(&h->d_amq[0], sizeof(float) * C)); CSDR_HIP(hipMalloc(&h->d_amq[1], sizeof(float) * C));
+        if (am_mix) { CSDR_HIP_CLEAN(hipMalloc(&h->d_amf, sizeof(float) * (size_t)C * h->max_nf), csdr_chain_destroy(h)); }
+        CSDR_HIP_CLEAN(hipMalloc(&h->d_amq[0], sizeof(float) * C), csdr_chain_destroy(h)); CSDR_HIP_CLEAN(hipMalloc(&h->d_amq[1], sizeof(float) * C), csdr_chain_destroy(h));
         h->path += "+am";
     }
     if (wbfm) {
@@ -785,7 +793,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             hipMalloc(&h->d_wbhist[0], sizeof(float) * hist) != hipSuccess || hipMalloc(&h->d_wbhist[1], sizeof(float) * hist) != hipSuccess ||
             hipMalloc(&h->d_wbst[0], sizeof(float2) * C) != hipSuccess || hipMalloc(&h->d_wbst[1], sizeof(float2) * C) != hipSuccess ||
             (wbfm_mix && hipMalloc(&h->d_wbo, sizeof(float) * rows) != hipSuccess)) { set_error("chain: WBFM tail allocation failed"); return fail(CSDR_ERR_HIP); }
-        CSDR_HIP(hipMemcpy(h->d_wbh, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice));
+        CSDR_HIP_CLEAN(hipMemcpy(h->d_wbh, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice), csdr_chain_destroy(h));
         h->path += "+wbfm";
     }
     if (h->d_agc && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL)) {
@@ -793,7 +801,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         h->path += h->use_fused ? "-spec" : "+agc-spec";
     }
     if ((r = chain_init_state(h, nullptr))) return fail(r);
-    CSDR_HIP(hipDeviceSynchronize());
+    CSDR_HIP_CLEAN(hipDeviceSynchronize(), csdr_chain_destroy(h));
 
     if (!(cfg->flags & CSDR_FLAG_QUIET)) {
         // what the reference prints at create (Liquid.chs:577-579, 814-820, 714-716, 319-321)

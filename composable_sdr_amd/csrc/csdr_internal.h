@@ -17,6 +17,17 @@ int  hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (e__ != hipSuccess) return ::csdr::hip_fail(e__, #call, __FILE__, __LINE__); \
     } while (0)
 
+// same, for create functions: run `cleanup` (the object's destroy) before returning the error
+#define CSDR_HIP_CLEAN(call, cleanup)                                           \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) {                                                \
+            const int rc__ = ::csdr::hip_fail(e__, #call, __FILE__, __LINE__); \
+            cleanup;                                                            \
+            return rc__;                                                        \
+        }                                                                       \
+    } while (0)
+
 // ---- host-side design (design.cpp) -----------------------------------------
 // Kaiser prototype of firpfbch_crcf_create_kaiser(ANALYZER, M, m, As)
 // (reference call: Liquid.chs:813).  Returns the M*2m taps the bank uses.

@@ -46,7 +46,8 @@ for sub in ("pmc3", "pmc4"):
         for row in csv.DictReader(open(f)):
             acc[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
         for (k, c), v in acc.items():
-            vals[k][c] = sum(v) / len(v)
+            v = sorted(v)
+            vals[k][c] = v[len(v) // 2]                 # median: the first launch after create is not representative (AGC repairs)
 tj_path = os.path.join(dst, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
 
@@ -58,6 +59,8 @@ def short_name(k):
     first = targs.split(",")[0].strip(" >")
     if first in ("true", "false") and (base.startswith("k_run") or base.startswith("k_tile")):
         return base + ("<FM>" if first == "true" else "<CF32>")
+    if base == "k_pfb1024" and "," in targs and targs.split(",")[1].strip(" >") == "true":
+        return "k_run1024" + ("<FM>" if first == "true" else "<CF32>")     # k_pfb1024<FM, DC = true> is what the C side calls k_run1024
     return base
 
 
@@ -69,7 +72,7 @@ for k, c in vals.items():
         tj[f"{short_name(k)}|M={M}|nf={nf}"] = {
             "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
             "fetch_size_kib_raw": c["FETCH_SIZE"], "write_size_kib_raw": c["WRITE_SIZE"],
-            "note": "FETCH_SIZE x2 (gfx950 wide-load under-count), WRITE_SIZE as reported", "source": f"profiles/{tag}_rocprofv3_summary.txt"}
+            "note": "median over the launches of one run; FETCH_SIZE x2 (gfx950 wide-load under-count), WRITE_SIZE as reported", "source": f"profiles/{tag}_rocprofv3_summary.txt"}
 json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, f"{tag}_rocprofv3_summary.txt")).read()[:1500])
 print(json.dumps(tj, indent=1))
