@@ -752,7 +752,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         if (M > 1) {
             if ((r = dev_alloc(&h->d_u, (size_t)(h->p - 1) * M + h->max_nx)) || (r = dev_alloc(&h->d_hist_tmp, (size_t)(h->p - 1) * M))) return fail(r);
         }
-        if ((r = dev_alloc(&h->d_A, h->max_nx)) || (r = dev_alloc(&h->d_B, h->max_nx))) return fail(r);
+        if ((r = dev_alloc(&h->d_A, h->max_nx)) || (r = dev_alloc(&h->d_B, use1024 && h->max_nx < 2048 ? 2048 : h->max_nx))) return fail(r);   // k_pfb1024 keeps yfirst|ylast (2 x nruns x 1024) in d_B
         if (M > 1 && cfg->dc_block && (r = dctile_create(h->dc, h->max_nx, &h->dctile))) return fail(r);
         h->mix_identity = M > 1 && G == 1 && C == M && cfg->mix && cfg->demod == CSDR_DEMOD_NONE && cfg->agc_threshold_db == 0.0f &&
                           h->dctile && !(cfg->flags & CSDR_FLAG_NO_MIX_IDENTITY) && !am;
