@@ -990,7 +990,7 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         FusedCall fcall{};
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         if (h->small) { if ((r = small_process(h->small, fcall, s, &h->timer))) return r; }
-        else if (h->big) { if ((r = big_process(h->big, fcall, s, &h->timer))) return r; }
+        else if (h->big) { if ((r = big_process(h->big, fcall, s, &h->timer))) return r; h->timed_kernel = big_name(h->big); }   // k_run1024v2 or k_run1024, by call
         else if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
         h->theta += n_in * h->d_theta;
         if (agc_on && h->agc_tail) {

@@ -59,6 +59,21 @@ void big_seek(BigPlan *plan, uint64_t frames);
 const char *big_name(const BigPlan *plan);
 void big_destroy(BigPlan *plan);
 
+// k_run1024v2 (kernels_run1024_v2.hip): whole-band M = 1024 calls with nf % 4 == 0; same state buffers as k_run1024
+struct Run1024v2Host {
+    const float2 *x; void *out;
+    const float4 *taps_q;       // [4][4][256] float4: taps of branch 256 q + j (14) + its even-frame pre-mix phasor
+    const float2 *tw;
+    const float2 *uhist_in; float2 *uhist_out; const float2 *vend_in; float2 *vend_out; const float2 *rp_in; float2 *rp_out;
+    float2 *yfirst, *ylast;     // [nruns][1024] each
+    uint32_t nf, nruns, parity0;
+    bool dc_block;
+    double beta;
+    float fm_ref;
+};
+uint32_t run1024_v2_runs(uint32_t nf, uint32_t cus);    // 0: call too short for the kernel
+int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTimer *timer);
+
 
 // single-pass DC blocker + NCO mix for whole chunks of the generic path (kernels_dc_tile.hip)
 struct DcTilePlan;

@@ -450,7 +450,8 @@ struct BigPlan {
     uint32_t cus = 256;
     uint64_t frames_done = 0;
     float *d_taps = nullptr;
-    float4 *d_taps_t = nullptr;
+    float4 *d_taps_t = nullptr, *d_taps_q = nullptr;
+    bool v2_ok = false, v2_last = false;      // k_run1024v2 usable (whole band, not disabled); used by the last call
     float2 *d_tw = nullptr, *d_wpre = nullptr;
     float2 *d_uhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
     float2 *d_scratch = nullptr;     // yfirst | ylast
@@ -463,7 +464,7 @@ bool big_supported(uint32_t M, uint32_t p) { return M == (uint32_t)PM && p == (u
 void big_destroy(BigPlan *p)
 {
     if (!p) return;
-    void *ptrs[] = {p->d_taps, p->d_taps_t, p->d_tw, p->d_wpre, p->d_uhist[0], p->d_uhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0], p->d_rp[1],
+    void *ptrs[] = {p->d_taps, p->d_taps_t, p->d_taps_q, p->d_tw, p->d_wpre, p->d_uhist[0], p->d_uhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0], p->d_rp[1],
                     p->d_scratch, p->d_premix};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
@@ -483,6 +484,7 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
 #define ALLOC(ptr, bytes) do { hipError_t e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 1); if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__)); } while (0)
     ALLOC(p->d_taps, sizeof(float) * PM * PP);
     ALLOC(p->d_taps_t, sizeof(float) * PM * 16);
+    ALLOC(p->d_taps_q, sizeof(float) * PM * 18);
     ALLOC(p->d_tw, sizeof(float2) * PM);
     ALLOC(p->d_wpre, sizeof(float2) * 2 * PM);
     for (int i = 0; i < 2; i++) {
@@ -490,7 +492,7 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         ALLOC(p->d_vend[i], sizeof(float2));
         ALLOC(p->d_rp[i], sizeof(float2) * cfg.C);
     }
-    ALLOC(p->d_scratch, sizeof(float2) * 2 * (size_t)p->cus * PM);
+    ALLOC(p->d_scratch, sizeof(float2) * 2 * (size_t)(2 * p->cus) * PM);      // k_run1024v2: two runs per CU
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
 #undef ALLOC
     CSDR_HIP(hipMemcpy(p->d_taps, cfg.taps, sizeof(float) * PM * PP, hipMemcpyHostToDevice));
@@ -511,6 +513,21 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
     }
     CSDR_HIP(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
     CSDR_HIP(hipMemcpy(p->d_wpre, wpre.data(), sizeof(float2) * wpre.size(), hipMemcpyHostToDevice));
+    {
+        // k_run1024v2's table: [q][piece][j] float4 = floats 4 piece .. 4 piece + 3 of the row (14 taps, even-frame phasor) of
+        // branch 256 q + j; behind it [q][j] float2: the odd-frame phasor (the f32 phases of the two are not exact negatives)
+        std::vector<float> tq((size_t)PM * 16 + (size_t)PM * 2, 0.f);
+        for (int r = 0; r < PM; r++) {
+            const int q = r >> 8, j = r & 255;
+            float row[16];
+            for (int n = 0; n < PP; n++) row[n] = cfg.taps[(PM - 1 - r) + n * PM];
+            row[14] = wpre[r].x; row[15] = wpre[r].y;
+            for (int e = 0; e < 16; e++) tq[((size_t)(q * 4 + (e >> 2)) * 256 + j) * 4 + (e & 3)] = row[e];
+            tq[(size_t)PM * 16 + 2 * (size_t)r] = wpre[PM + r].x; tq[(size_t)PM * 16 + 2 * (size_t)r + 1] = wpre[PM + r].y;
+        }
+        CSDR_HIP(hipMemcpy(p->d_taps_q, tq.data(), sizeof(float) * tq.size(), hipMemcpyHostToDevice));
+        p->v2_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && !getenv("CSDR_RUN1024_V1");
+    }
     *out = p;
     return 0;
 }
@@ -527,7 +544,11 @@ int big_reset(BigPlan *p, hipStream_t s)
 }
 
 void big_seek(BigPlan *p, uint64_t frames) { p->frames_done = frames; }
-const char *big_name(const BigPlan *p) { return p->cfg.fm ? "k_run1024<FM>" : "k_run1024<CF32>"; }
+const char *big_name(const BigPlan *p)
+{
+    if (p->v2_last) return p->cfg.fm ? "k_run1024v2<FM>" : "k_run1024v2<CF32>";
+    return p->cfg.fm ? "k_run1024<FM>" : "k_run1024<CF32>";
+}
 
 int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *timer)
 {
@@ -535,6 +556,25 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     const uint32_t nf = call.nf;
     if (!nf) return 0;
     int r;
+    const uint32_t v2runs = (p->v2_ok && (nf & 3u) == 0 && (uint64_t)nf * 2040u < (1ull << 32)) ? run1024_v2_runs(nf, p->cus) : 0;
+    p->v2_last = v2runs != 0;
+    if (v2runs) {
+        Run1024v2Host H{};
+        H.x = call.d_in; H.out = c.mix ? p->d_premix : call.d_out; H.taps_q = p->d_taps_q; H.tw = p->d_tw;
+        H.uhist_in = p->d_uhist[p->cur]; H.uhist_out = p->d_uhist[p->cur ^ 1];
+        H.vend_in = p->d_vend[p->cur]; H.vend_out = p->d_vend[p->cur ^ 1];
+        H.rp_in = p->d_rp[p->cur]; H.rp_out = p->d_rp[p->cur ^ 1];
+        H.yfirst = p->d_scratch; H.ylast = p->d_scratch + (size_t)v2runs * PM;
+        H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
+        H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
+        if ((r = run1024_v2_launch(H, c.fm, s, timer))) return r;
+        p->cur ^= 1;
+        p->frames_done += nf;
+        if (c.mix) {
+            if ((r = launch_mix((const float *)p->d_premix, (float *)call.d_out, c.C, c.fm ? nf : 2 * nf, s))) return r;
+        }
+        return 0;
+    }
     Pfb1024Args A{};
     A.u = call.d_in; A.taps = p->d_taps; A.taps_t = p->d_taps_t; A.tw = p->d_tw; A.wpre = p->d_wpre;
     A.out = c.mix ? p->d_premix : call.d_out;

@@ -1240,6 +1240,47 @@ def test_pfb1024_fused_kernel_matches_three_kernel_route_and_oracle(demod, agc, 
     a.close(); a2.close(); b.close()
 
 
+@pytest.mark.parametrize("demod", ["fm", "none"])
+def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatch):
+    """k_run1024v2 (256 threads, 4-frame tiles, two workgroups per CU: whole-band calls with nf % 4 == 0) against k_run1024
+    (CSDR_RUN1024_V1) and the oracle: a 5-frame call first (odd: first-generation kernel, leaves the NCO parity odd and a
+    non-trivial DC state, window and r'), then 4096 frames (64 runs with warm-up, halo and fix-up), then 512."""
+    M = 1024
+    frames = [5, 4096, 512]
+    nf = sum(frames)
+    x = synth_cf32(M * nf, M, seed=77)
+    x = (x + np.complex64(0.01 - 0.005j)).astype(np.complex64)    # a DC offset the blocker has to remove across run starts
+    kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames))
+    a = cs.Chain(**kw)
+    monkeypatch.setenv("CSDR_RUN1024_V1", "1")
+    b = cs.Chain(**kw)
+    monkeypatch.delenv("CSDR_RUN1024_V1")
+    orc = O.Chain(M, demod=demod, kf=0.3)
+    ga, gb, wo, pos, names = [], [], [], 0, []
+    for f in frames:
+        xa = x[pos * M:(pos + f) * M]
+        ga.append(a.process(xa)); gb.append(b.process(xa)); wo.append(orc.process(xa)); pos += f
+        names.append((a.kernel_time()[0], b.kernel_time()[0]))
+    print("kernels:", names)
+    assert "v2" not in names[0][0] and "k_run1024v2" in names[1][0] and "k_run1024v2" in names[2][0]
+    assert all("v2" not in n[1] for n in names)
+    ga, gb, wo = [np.concatenate(v, axis=1) for v in (ga, gb, wo)]
+    if demod == "none":
+        print(f"run1024v2 DeNo: vs v1 {rel_rms(ga, gb):.2e}, vs oracle {rel_rms(ga, wo):.2e}")
+        assert rel_rms(ga, gb) < 2e-6 and rel_rms(ga, wo) < 1e-5
+        assert rel_rms(ga[:, 5:5 + 64], wo[:, 5:5 + 64]) < 1e-5 and rel_rms(ga[:, -64:], wo[:, -64:]) < 1e-5
+    else:
+        d1 = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / 0.3))
+        d2 = np.abs(wrap_pm(ga.astype(np.float64) - wo, 1.0 / 0.3))
+        print(f"run1024v2 FM: vs v1 median {np.median(d1):.2e} p99.9 {np.quantile(d1, 0.999):.2e}; vs oracle median {np.median(d2):.2e} p99.9 {np.quantile(d2, 0.999):.2e}")
+        # the run starts (first sample of a run = fix-up kernel) are where a wrong carry would show: every 64th-ish frame
+        assert np.median(d1) < 2e-6 and np.median(d2) < 2e-5
+        assert np.quantile(d1, 0.999) < 5e-5
+        starts = d1[:, 5::64]                                    # 4096 frames / 64 runs: every run start is in here
+        assert np.quantile(starts, 0.999) < 5e-5
+    a.close(); b.close()
+
+
 # --------------------------------------------------------------------------- full-size properties of the cfg4 / cfg5 shapes
 
 
