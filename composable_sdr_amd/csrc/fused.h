@@ -66,6 +66,7 @@ struct Run1024v2Host {
     const float2 *tw;
     const float2 *uhist_in; float2 *uhist_out; const float2 *vend_in; float2 *vend_out; const float2 *rp_in; float2 *rp_out;
     float2 *yfirst, *ylast;     // [nruns][1024] each
+    char *stage;                // [nruns] output staging blocks of 128 KiB
     uint32_t nf, nruns, parity0;
     bool dc_block;
     double beta;

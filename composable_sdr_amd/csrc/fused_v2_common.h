@@ -17,6 +17,8 @@ __device__ __forceinline__ float opaque_v(float x) { asm volatile("" : "+v"(x));
 
 // HBM -> LDS without registers: lane l of wave instruction `it` fills 16-byte slot 64 (4 it + wave) + l of the RAW image.
 // Spelled in asm so that hipcc does not count it: with the builtin it drains vmcnt(0) in front of the next LDS read.
+// s_nop 4: the hazard recognizer does not look into inline asm, and a scalar operand that hipcc has just reloaded from a
+// spill lane (v_readlane = a VALU write of an SGPR) must be five wait states old before a VMEM instruction reads it.
 // The kernel waits for it by hand (s_waitcnt vmcnt(0) in front of the tile's output stores);
 // lds_wave: LDS byte address of my wave's first slot.
 // goff: byte offset of my first piece inside a tile; piece `it` lies 4096 bytes further (the swizzle term (q >> 1) & 7 of
@@ -34,7 +36,7 @@ __device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, u
         const unsigned dst = lds_wave + 4096u * (unsigned)it;
         const float4 *src = tile_base + 256 * it;
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(goff), "s"(dst), "s"(src) : "memory");
     }
 }

@@ -455,6 +455,7 @@ struct BigPlan {
     float2 *d_tw = nullptr, *d_wpre = nullptr;
     float2 *d_uhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
     float2 *d_scratch = nullptr;     // yfirst | ylast
+    char *d_stage = nullptr;         // k_run1024v2: 128 KiB of output staging per run
     void *d_premix = nullptr;
     int cur = 0;
 };
@@ -465,7 +466,7 @@ void big_destroy(BigPlan *p)
 {
     if (!p) return;
     void *ptrs[] = {p->d_taps, p->d_taps_t, p->d_taps_q, p->d_tw, p->d_wpre, p->d_uhist[0], p->d_uhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0], p->d_rp[1],
-                    p->d_scratch, p->d_premix};
+                    p->d_scratch, p->d_premix, p->d_stage};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -493,6 +494,7 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         ALLOC(p->d_rp[i], sizeof(float2) * cfg.C);
     }
     ALLOC(p->d_scratch, sizeof(float2) * 2 * (size_t)(2 * p->cus) * PM);      // k_run1024v2: two runs per CU
+    ALLOC(p->d_stage, (size_t)(2 * p->cus) * 131072u);
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
 #undef ALLOC
     CSDR_HIP(hipMemcpy(p->d_taps, cfg.taps, sizeof(float) * PM * PP, hipMemcpyHostToDevice));
@@ -556,7 +558,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     const uint32_t nf = call.nf;
     if (!nf) return 0;
     int r;
-    const uint32_t v2runs = (p->v2_ok && (nf & 3u) == 0 && (uint64_t)nf * 2040u < (1ull << 32)) ? run1024_v2_runs(nf, p->cus) : 0;
+    const uint32_t v2runs = (p->v2_ok && (nf & 3u) == 0 && (uint64_t)nf * 8192u < (1ull << 31)) ? run1024_v2_runs(nf, p->cus) : 0;
     p->v2_last = v2runs != 0;
     if (v2runs) {
         Run1024v2Host H{};
@@ -564,7 +566,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.uhist_in = p->d_uhist[p->cur]; H.uhist_out = p->d_uhist[p->cur ^ 1];
         H.vend_in = p->d_vend[p->cur]; H.vend_out = p->d_vend[p->cur ^ 1];
         H.rp_in = p->d_rp[p->cur]; H.rp_out = p->d_rp[p->cur ^ 1];
-        H.yfirst = p->d_scratch; H.ylast = p->d_scratch + (size_t)v2runs * PM;
+        H.yfirst = p->d_scratch; H.ylast = p->d_scratch + (size_t)v2runs * PM; H.stage = p->d_stage;
         H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
         if ((r = run1024_v2_launch(H, c.fm, s, timer))) return r;

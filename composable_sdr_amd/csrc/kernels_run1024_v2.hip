@@ -13,7 +13,13 @@
 //   --pass 3, thread kk = k1 + 16 k2: radix 4 over d for all four frames--> Y[kk + 256 k3], frames 0..3 in registers.
 // Passes 1 and 2 read and write only their wave's frame block (an LDS image a wave writes and then reads needs no
 // barrier), so a tile takes 4 barriers.  The tail thread holds four consecutive frames of four channels: the previous
-// frame of a channel is a register (no stash, no DPP), an F32 row piece leaves as one 16-byte store.
+// frame of a channel is a register-wide read of the stash (no DPP).
+// OUTPUT.  A tile holds 16 (F32) / 32 (CF32) bytes of every one of the 1024 channel rows; stored as such, 512 workgroups keep
+// 64 MiB of 128-byte lines half-written and the L2s (32 MiB) evict them piecemeal: 401 us (F32) / 550 us (CF32) per 67 M
+// samples against 300 / 275 us with the same bytes stored contiguously.  So a tile's results go, fully coalesced, into a
+// 128 KiB per-workgroup staging block [tile][channel][piece] (L2 / Infinity-Cache resident), and once a block spans a whole line per row
+// (8 tiles F32, 4 tiles CF32; runs start on 8-tile boundaries) the workgroup reads it back transposed and writes every
+// row's 128 bytes with eight lanes of one store instruction.
 // The 56 taps of a thread's four branches do not fit next to the window: they are re-read per tile from a 64 KiB table
 // (L2-resident, fully coalesced 16-byte loads; the row of a branch ends with its even-frame pre-mix phasor, the odd-frame one
 // comes from a second table) at the top of the tile and
@@ -21,7 +27,15 @@
 #include "fused_v2_common.h"
 
 #ifndef B2_ABLATE
-#define B2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem
+#define B2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores (staging and rows), 4 no freqdem, 8 no tap loads, 16 no FIR,
+                         // 32 no DFT passes 1-2, 64 no DC scan, 128 no window shift, 256 block flush without its loads, 512 without its stores, 1024 no flush
+#endif
+
+#ifndef B2_STORE_MOD
+#define B2_STORE_MOD ""  // cache policy bits of the output stores (experiments: " nt", " sc1", " sc0 sc1")
+#endif
+#ifndef B2_VOFF
+#define B2_VOFF voff     // experiments: joff_t = rows 16 bytes apart (fully coalesced, wrong place)
 #endif
 
 namespace csdr {
@@ -44,6 +58,7 @@ struct Run1024v2Args {
     const float2 *vend_in; float2 *vend_out;      // DC blocker state v1
     const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r'
     float2 *yfirst, *ylast;     // [nruns][1024]
+    char *stage;                // [nruns] staging blocks of 128 KiB
     uint32_t nf, nb, nruns, parity0, out_stride;
     float alpha, beta, l2beta, fm_ref, tiny;
     float b16[16];              // beta^(16 r)
@@ -51,10 +66,12 @@ struct Run1024v2Args {
     PhaseK pk;
 };
 
-__device__ __forceinline__ void run_bounds(const Run1024v2Args &A, unsigned w, unsigned &first, unsigned &last)
+// runs start on 8-tile boundaries (an output block = one 128-byte line of every F32 row); the last run takes the remainder
+__host__ __device__ __forceinline__ void run_bounds(uint32_t nb, uint32_t nruns, unsigned w, unsigned &first, unsigned &last)
 {
-    first = (unsigned)((unsigned long long)w * A.nb / A.nruns);
-    last = (unsigned)((unsigned long long)(w + 1) * A.nb / A.nruns);
+    const unsigned long long U = nb / 8u;
+    first = 8u * (unsigned)((unsigned long long)w * U / nruns);
+    last = (w + 1 == nruns) ? nb : 8u * (unsigned)((unsigned long long)(w + 1) * U / nruns);
 }
 
 template <bool FM>
@@ -65,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
     const int tid = threadIdx.x, j = tid;
     const unsigned w = blockIdx.x;
     unsigned first, last;
-    run_bounds(A, w, first, last);
+    run_bounds(A.nb, A.nruns, w, first, last);
     const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
 
@@ -154,8 +171,6 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
     // two 16-bit LDS / table offsets per register, unpacked next to their use: the window leaves no VGPRs for nine of them
     const unsigned pk0 = raw_a0 | (x_a0 << 16), pk1 = z1r0 | (z1w0 << 16), pk2 = z2w | (z2r << 16), pk3 = goff | (joff << 16);
     const uint32_t esz = FM ? 4u : 8u;
-    const uint32_t voff = (uint32_t)tid * A.out_stride * esz;                   // my row kk; + 256 k3 rows, + 4 b frames
-    const size_t row256 = (size_t)256 * A.out_stride * esz;
 
     auto tile = [&](unsigned b_, const int par, const bool warm) {
         unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)b_);            // keep the tile index (store / DMA bases) in SGPRs
@@ -171,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
         // scheduler from hoisting them.  The next tile's DMA is only issued after the last of them has been used: the
         // compiler's waits count vmcnt in order and would otherwise wait for the DMA as well.
         auto load_taps = [&](v4f (&t)[4], v2f &wodd, const int qq) {
+            if (B2_ABLATE & 8) { for (int p = 0; p < 4; p++) t[p] = (v4f){kJ, kJ, kJ, kJ}; wodd = (v2f){kJ, kJ}; return; }
 #pragma unroll
             for (int p = 0; p < 4; p++) {               // buffer load: resource + 32-bit lane offset + scalar offset (one VGPR for all twenty loads)
                 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -191,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
         const float na = opaque_v(-A.alpha), be = opaque_v(A.beta);             // VGPR copies for the scan only (an SGPR operand costs an issue slot more)
         v4f xr[8];
         float2 s = make_float2(0.f, 0.f);
+        if (!(B2_ABLATE & 64)) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             xr[i] = *reinterpret_cast<const v4f *>(B + (raw_a ^ (unsigned)(i << 4)));
@@ -214,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             y.z = fmaf(s.x, na, xr[i].z); y.w = fmaf(s.y, na, xr[i].w);
             s = make_float2(fmaf(s.x, be, xr[i].z), fmaf(s.y, be, xr[i].w));
             *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = y;
+        }
         }
         bar();                                          // B_c: y' (group carry still missing) and the group totals are visible
         // ---- column layout: nw[4 f + qq] = sample of frame f, branch j + 256 qq; group state chain V[g] (uniform), a frame
@@ -253,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             const float h[16] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w, t[2].x, t[2].y, t[2].z, t[2].w, t[3].x, t[3].y, 0.f, 0.f};
             v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-            for (int n = P - 1; n >= 0; n--) {
+            for (int n = ((B2_ABLATE & 16) ? 0 : P - 1); n >= 0; n--) {
 #pragma unroll
                 for (int f = 0; f < 4; f++) {
                     const int i = f - n;
@@ -278,10 +296,12 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
         asm volatile("" ::: "memory");
         if (!(B2_ABLATE & 1) && b + 1 < last) dma_tile(x4 + (size_t)(b + 1) * 2048, goff_t, lds_wave + (unsigned)(par ^ 1) * (B2_BUF * 8u));
         // the window moves on by four frames
+        if (!(B2_ABLATE & 128)) {
 #pragma unroll
-        for (int i = 0; i < 36; i++) hist[i] = hist[i + 16];
+            for (int i = 0; i < 36; i++) hist[i] = hist[i + 16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) hist[36 + i] = nw[i];
+            for (int i = 0; i < 16; i++) hist[36 + i] = nw[i];
+        }
         if (warm) return;
         bar();                                          // B_d: X complete
         // ---- DFT pass 1: wave f, lane b1: radix 16 over a (n = 64 a + b1); Z1 goes back into the frame block, nobody else reads it
@@ -289,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
         unpack(pk1, z1r, z1w);
         unpack(pk2, z2w_t, z2r_t);
         v2f vv[16];
+        if (!(B2_ABLATE & 32)) {
 #pragma unroll
         for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B + fb + 512 * a + (x_a ^ (unsigned)((a & 3) << 5))));
         fft16_v(vv);
@@ -309,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
         }
 #pragma unroll
         for (int i = 0; i < 16; i++) *reinterpret_cast<float2 *>(B + z2w_t + 512 * XIDX(i)) = to_f2(vv[i]);
+        }
         bar();                                          // B_h: Z2 of all four frames complete
         // ---- DFT pass 3 + tail: thread kk = k1 + 16 k2, all four frames; Y[f][k3] = channel kk + 256 k3
         v2f y[4][4];
@@ -319,13 +341,16 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             y[f][0] = (v2f){v0.x, v0.y}; y[f][1] = (v2f){v0.z, v0.w}; y[f][2] = (v2f){v1.x, v1.y}; y[f][3] = (v2f){v1.z, v1.w};
             bfly4_v(y[f][0], y[f][1], y[f][2], y[f][3]);
         }
-        char *obase = reinterpret_cast<char *>(A.out) + (size_t)4 * b * esz;
+        // ---- tail: results into slot ts of the staging block (each store instruction: 1 KiB contiguous)
+        constexpr unsigned TB = FM ? 8u : 4u, PB = FM ? 16u : 32u;              // tiles per block, bytes per (tile, row) piece
+        const unsigned ts = b & (TB - 1u);
+        const char *sbase = A.stage + (size_t)w * 131072u + (size_t)ts * (1024u * PB);
         if (FM) {
             if (b == first && w > 0) {                  // scalar base + lane offset: a 64-bit lane address would sit in the spill area all loop long
 #pragma unroll
                 for (int k3 = 0; k3 < 4; k3++) {
                     const float2 *yf = A.yfirst + (size_t)w * B2_M + 256 * k3;
-                    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(joff_t >> 1), "v"(y[0][k3]), "s"(yf) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" :: "v"(joff_t >> 1), "v"(y[0][k3]), "s"(yf) : "memory");
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile image: nothing else is outstanding
@@ -347,20 +372,44 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
                 if (B2_ABLATE & 4) { mq[0] = rp[0].x + rr[0].y; mq[1] = rp[1].y + rr[1].x; mq[2] = rp[2].x + rr[2].y; mq[3] = rp[3].y + rr[3].x; }
                 else fm_quad(rp, rr, fkt, mq);
                 const v4f mv = {mq[0], mq[1], mq[2], mq[3]};
-                const char *rowp = obase + (size_t)k3 * row256;
-                if (B2_ABLATE & 2) asm volatile("" :: "v"(mv), "s"(rowp));
-                else asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(voff), "v"(mv), "s"(rowp) : "memory");
+                const char *sp = sbase + k3 * (256 * 16);
+                if (B2_ABLATE & 2) asm volatile("" :: "v"(mv), "s"(sp));
+                else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"(joff_t), "v"(mv), "s"(sp) : "memory");
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int k3 = 0; k3 < 4; k3++) {
                 const v4f lo = {y[0][k3].x, y[0][k3].y, y[1][k3].x, y[1][k3].y}, hi = {y[2][k3].x, y[2][k3].y, y[3][k3].x, y[3][k3].y};
-                const char *rowp = obase + (size_t)k3 * row256;
-                if (B2_ABLATE & 2) asm volatile("" :: "v"(lo), "v"(hi), "s"(rowp));
+                const char *sp = sbase + k3 * (256 * 32);
+                if (B2_ABLATE & 2) asm volatile("" :: "v"(lo), "v"(hi), "s"(sp));
                 else {
-                    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(voff), "v"(lo), "s"(rowp) : "memory");
-                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:16" :: "v"(voff), "v"(hi), "s"(rowp) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"(2u * joff_t), "v"(lo), "s"(sp) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16" :: "v"(2u * joff_t), "v"(hi), "s"(sp) : "memory");
+                }
+            }
+        }
+        // ---- a block is complete (or the run ends): every row's 128 bytes leave in one piece
+        if ((ts == TB - 1u || b + 1 == last) && !(B2_ABLATE & (2 | 1024))) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // the workgroup's staging stores are in L2 (one CU: same L1)
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(A.stage) + (size_t)w * 131072u, 0, 131072, 0x00020000);
+            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)(1024u * A.out_stride * esz), 0x00020000);
+            const unsigned lane = joff_t >> 4 & 63u, u = lane & 7u, rowl = 8u * wave_u + (lane >> 3);    // 16-byte unit of the line, row in a group of 32
+            const unsigned tsrc = FM ? u : (u >> 1);                            // the tile my unit comes from
+            const unsigned ld = FM ? (u * 1024u + rowl) * 16u : ((u >> 1) * 1024u + rowl) * 32u + (u & 1u) * 16u;
+            const unsigned st = rowl * A.out_stride * esz + u * 16u;
+            const unsigned o0 = 4u * (b - ts) * esz;                            // the block's first frame in a row
+            const bool mine = tsrc <= ts;
+#pragma unroll 1
+            for (unsigned g = 0; g < 4; g++) {
+                v4u v[8];
+#pragma unroll
+                for (unsigned i = 0; i < 8; i++) v[i] = (B2_ABLATE & 256) ? (v4u){ld, st, g, i} : __builtin_amdgcn_raw_buffer_load_b128(srs, (int)ld, (int)((8u * g + i) * 32u * PB), 0);
+                if (B2_ABLATE & 512) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7])); }
+                else if (mine) {
+#pragma unroll
+                    for (unsigned i = 0; i < 8; i++) __builtin_amdgcn_raw_buffer_store_b128(v[i], ors, (int)st, (int)(o0 + (8u * g + i) * 32u * A.out_stride * esz), 0);
                 }
             }
         }
@@ -401,12 +450,12 @@ __global__ __launch_bounds__(1024) void k_run1024v2_fixup(Run1024v2Args A)
 {
     const unsigned w = blockIdx.x + 1, k = threadIdx.x;
     unsigned first, last;
-    run_bounds(A, w, first, last);
+    run_bounds(A.nb, A.nruns, w, first, last);
     if (first >= last) return;
     unsigned wp = w - 1;
     for (;;) {                                          // the run before w that is not empty
         unsigned f0, l0;
-        run_bounds(A, wp, f0, l0);
+        run_bounds(A.nb, A.nruns, wp, f0, l0);
         if (f0 < l0 || wp == 0) break;
         wp--;
     }
@@ -423,7 +472,7 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
     Run1024v2Args A{};
     A.x = h.x; A.out = h.out; A.taps_q = h.taps_q; A.tw = h.tw;
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
-    A.rp_in = h.rp_in; A.rp_out = h.rp_out; A.yfirst = h.yfirst; A.ylast = h.ylast;
+    A.rp_in = h.rp_in; A.rp_out = h.rp_out; A.yfirst = h.yfirst; A.ylast = h.ylast; A.stage = h.stage;
     A.nf = h.nf; A.nb = h.nf / B2_T4; A.nruns = h.nruns; A.parity0 = h.parity0; A.out_stride = h.nf;
     const double beta = h.dc_block ? h.beta : 0.0;
     A.alpha = h.dc_block ? (float)(1.0 - beta) : 0.0f; A.beta = (float)beta; A.l2beta = h.dc_block ? (float)std::log2(beta) : -1000.0f;
@@ -444,9 +493,11 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
 
 uint32_t run1024_v2_runs(uint32_t nf, uint32_t cus)
 {
-    // two workgroups per CU; a run >= 1 spends 6 read-only + 4 halo tiles on its start state: at least 16 tiles per run
+    // two workgroups per CU; a run >= 1 spends 6 read-only + 4 halo tiles on its start state and starts on an 8-tile boundary:
+    // at least 16 tiles per run
     const uint32_t nb = nf / B2_T4;
     uint32_t nruns = 2 * cus;
+    if (const char *e = getenv("CSDR_RUN1024_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
     if (nruns > nb / 16) nruns = nb / 16;
     return nruns;                                       // 0: too short for this kernel
 }
