@@ -528,7 +528,9 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
             tq[(size_t)PM * 16 + 2 * (size_t)r] = wpre[PM + r].x; tq[(size_t)PM * 16 + 2 * (size_t)r + 1] = wpre[PM + r].y;
         }
         CSDR_HIP(hipMemcpy(p->d_taps_q, tq.data(), sizeof(float) * tq.size(), hipMemcpyHostToDevice));
-        p->v2_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && !getenv("CSDR_RUN1024_V1");
+        // CF32 output (DeNo, AGC / AM tails) stays with k_run1024: staged through HBM twice, k_run1024v2<CF32> moves 2.3 GB per
+        // 67 M samples and takes 405-415 us against 384 us (FM: 366 against 454); CSDR_RUN1024_V2_ALL=1 selects it anyway
+        p->v2_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && !getenv("CSDR_RUN1024_V1") && (cfg.fm || getenv("CSDR_RUN1024_V2_ALL"));
     }
     *out = p;
     return 0;

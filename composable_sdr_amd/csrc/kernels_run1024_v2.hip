@@ -31,6 +31,9 @@
                          // 32 no DFT passes 1-2, 64 no DC scan, 128 no window shift, 256 block flush without its loads, 512 without its stores, 1024 no flush
 #endif
 
+#ifndef B2_DIRECT
+#define B2_DIRECT 0      // 1: every tile stores its 16 / 32-byte row pieces straight into the rows (no staging block): the measured alternative
+#endif
 #ifndef B2_STORE_MOD
 #define B2_STORE_MOD ""  // cache policy bits of the output stores (experiments: " nt", " sc1", " sc0 sc1")
 #endif
@@ -373,7 +376,9 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
                 else fm_quad(rp, rr, fkt, mq);
                 const v4f mv = {mq[0], mq[1], mq[2], mq[3]};
                 const char *sp = sbase + k3 * (256 * 16);
+                const char *rowp = reinterpret_cast<const char *>(A.out) + (size_t)4 * b * esz + (size_t)k3 * 256 * A.out_stride * esz;
                 if (B2_ABLATE & 2) asm volatile("" :: "v"(mv), "s"(sp));
+                else if (B2_DIRECT) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(mv), "s"(rowp) : "memory");
                 else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"(joff_t), "v"(mv), "s"(sp) : "memory");
             }
         } else {
@@ -382,15 +387,19 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             for (int k3 = 0; k3 < 4; k3++) {
                 const v4f lo = {y[0][k3].x, y[0][k3].y, y[1][k3].x, y[1][k3].y}, hi = {y[2][k3].x, y[2][k3].y, y[3][k3].x, y[3][k3].y};
                 const char *sp = sbase + k3 * (256 * 32);
+                const char *rowp = reinterpret_cast<const char *>(A.out) + (size_t)4 * b * esz + (size_t)k3 * 256 * A.out_stride * esz;
                 if (B2_ABLATE & 2) asm volatile("" :: "v"(lo), "v"(hi), "s"(sp));
-                else {
+                else if (B2_DIRECT) {
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(lo), "s"(rowp) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(hi), "s"(rowp) : "memory");
+                } else {
                     asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"(2u * joff_t), "v"(lo), "s"(sp) : "memory");
                     asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16" :: "v"(2u * joff_t), "v"(hi), "s"(sp) : "memory");
                 }
             }
         }
         // ---- a block is complete (or the run ends): every row's 128 bytes leave in one piece
-        if ((ts == TB - 1u || b + 1 == last) && !(B2_ABLATE & (2 | 1024))) {
+        if ((ts == TB - 1u || b + 1 == last) && !(B2_ABLATE & (2 | 1024)) && !B2_DIRECT) {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // the workgroup's staging stores are in L2 (one CU: same L1)
             typedef unsigned v4u __attribute__((ext_vector_type(4)));
             const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(A.stage) + (size_t)w * 131072u, 0, 131072, 0x00020000);
@@ -401,15 +410,22 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             const unsigned st = rowl * A.out_stride * esz + u * 16u;
             const unsigned o0 = 4u * (b - ts) * esz;                            // the block's first frame in a row
             const bool mine = tsrc <= ts;
+#ifndef B2_FLUSH_BATCH
+#define B2_FLUSH_BATCH 8                // 16 is no faster (the write-back is bandwidth-, not latency-bound), 32 spills
+#endif
 #pragma unroll 1
-            for (unsigned g = 0; g < 4; g++) {
-                v4u v[8];
+            for (unsigned g = 0; g < 32u / B2_FLUSH_BATCH; g++) {                 // loads of a batch go out together: one memory latency per batch
+                v4u v[B2_FLUSH_BATCH];
 #pragma unroll
-                for (unsigned i = 0; i < 8; i++) v[i] = (B2_ABLATE & 256) ? (v4u){ld, st, g, i} : __builtin_amdgcn_raw_buffer_load_b128(srs, (int)ld, (int)((8u * g + i) * 32u * PB), 0);
-                if (B2_ABLATE & 512) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7])); }
-                else if (mine) {
+                for (unsigned i = 0; i < B2_FLUSH_BATCH; i++)
+                    v[i] = (B2_ABLATE & 256) ? (v4u){ld, st, g, i} : __builtin_amdgcn_raw_buffer_load_b128(srs, (int)ld, (int)((B2_FLUSH_BATCH * g + i) * 32u * PB), 0);
+                if (B2_ABLATE & 512) {
 #pragma unroll
-                    for (unsigned i = 0; i < 8; i++) __builtin_amdgcn_raw_buffer_store_b128(v[i], ors, (int)st, (int)(o0 + (8u * g + i) * 32u * A.out_stride * esz), 0);
+                    for (unsigned i = 0; i < B2_FLUSH_BATCH; i++) asm volatile("" :: "v"(v[i]));
+                } else if (mine) {
+#pragma unroll
+                    for (unsigned i = 0; i < B2_FLUSH_BATCH; i++)
+                        __builtin_amdgcn_raw_buffer_store_b128(v[i], ors, (int)st, (int)(o0 + (B2_FLUSH_BATCH * g + i) * 32u * A.out_stride * esz), 0);
                 }
             }
         }

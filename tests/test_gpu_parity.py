@@ -1251,7 +1251,9 @@ def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatc
     x = synth_cf32(M * nf, M, seed=77)
     x = (x + np.complex64(0.01 - 0.005j)).astype(np.complex64)    # a DC offset the blocker has to remove across run starts
     kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames))
+    monkeypatch.setenv("CSDR_RUN1024_V2_ALL", "1")               # the CF32 variant is not the default (k_run1024 is faster there)
     a = cs.Chain(**kw)
+    monkeypatch.delenv("CSDR_RUN1024_V2_ALL")
     monkeypatch.setenv("CSDR_RUN1024_V1", "1")
     b = cs.Chain(**kw)
     monkeypatch.delenv("CSDR_RUN1024_V1")
