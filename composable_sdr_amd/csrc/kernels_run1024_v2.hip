@@ -18,7 +18,7 @@
 // 64 MiB of 128-byte lines half-written and the L2s (32 MiB) evict them piecemeal: 401 us (F32) / 550 us (CF32) per 67 M
 // samples against 300 / 275 us with the same bytes stored contiguously.  So a tile's results go, fully coalesced, into a
 // 128 KiB per-workgroup staging block [tile][channel][piece] (L2 / Infinity-Cache resident), and once a block spans a whole line per row
-// (8 tiles F32, 4 tiles CF32; runs start on 8-tile boundaries) the workgroup reads it back transposed and writes every
+// (8 tiles F32, 4 tiles CF32, aligned to absolute tile indices; a run that starts or ends inside a block writes partial lines there) the workgroup reads it back transposed and writes every
 // row's 128 bytes with eight lanes of one store instruction.
 // The 56 taps of a thread's four branches do not fit next to the window: they are re-read per tile from a 64 KiB table
 // (L2-resident, fully coalesced 16-byte loads; the row of a branch ends with its even-frame pre-mix phasor, the odd-frame one
@@ -62,19 +62,27 @@ struct Run1024v2Args {
     const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r'
     float2 *yfirst, *ylast;     // [nruns][1024]
     char *stage;                // [nruns] staging blocks of 128 KiB
-    uint32_t nf, nb, nruns, parity0, out_stride;
+    uint32_t nf, nb, nruns, n0, parity0, out_stride;   // n0: tiles of the first half of the runs (0: even split)
     float alpha, beta, l2beta, fm_ref, tiny;
     float b16[16];              // beta^(16 r)
     float b256[17];             // beta^(256 g)
     PhaseK pk;
 };
 
-// runs start on 8-tile boundaries (an output block = one 128-byte line of every F32 row); the last run takes the remainder
-__host__ __device__ __forceinline__ void run_bounds(uint32_t nb, uint32_t nruns, unsigned w, unsigned &first, unsigned &last)
+// Run w of a launch.  nruns = two per CU: the first half (the workgroups dispatched first, the older ones of their CUs) win the
+// issue arbitration and get n0 of the nb tiles, the second half the rest (k_run256v2: both end together at about 1.2 : 0.8).
+// Output blocks are aligned to absolute tile indices, so a run may start and end inside a block (partial lines there).
+__host__ __device__ __forceinline__ void run_bounds(uint32_t nb, uint32_t nruns, uint32_t n0, unsigned w, unsigned &first, unsigned &last)
 {
-    const unsigned long long U = nb / 8u;
-    first = 8u * (unsigned)((unsigned long long)w * U / nruns);
-    last = (w + 1 == nruns) ? nb : 8u * (unsigned)((unsigned long long)(w + 1) * U / nruns);
+    if (n0 == 0 || (nruns & 1u)) {
+        first = (unsigned)((unsigned long long)w * nb / nruns);
+        last = (unsigned)((unsigned long long)(w + 1) * nb / nruns);
+        return;
+    }
+    const unsigned half = nruns / 2, s = w / half, i = w - s * half;
+    const unsigned base = s ? n0 : 0u, tiles = s ? nb - n0 : n0;
+    first = base + (unsigned)((unsigned long long)i * tiles / half);
+    last = base + (unsigned)((unsigned long long)(i + 1) * tiles / half);
 }
 
 template <bool FM>
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
     const int tid = threadIdx.x, j = tid;
     const unsigned w = blockIdx.x;
     unsigned first, last;
-    run_bounds(A.nb, A.nruns, w, first, last);
+    run_bounds(A.nb, A.nruns, A.n0, w, first, last);
     const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
 
@@ -409,7 +417,8 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             const unsigned ld = FM ? (u * 1024u + rowl) * 16u : ((u >> 1) * 1024u + rowl) * 32u + (u & 1u) * 16u;
             const unsigned st = rowl * A.out_stride * esz + u * 16u;
             const unsigned o0 = 4u * (b - ts) * esz;                            // the block's first frame in a row
-            const bool mine = tsrc <= ts;
+            const unsigned ts_lo = (b - ts < first) ? (first & (TB - 1u)) : 0u;   // a run may start inside a block
+            const bool mine = tsrc <= ts && tsrc >= ts_lo;
 #ifndef B2_FLUSH_BATCH
 #define B2_FLUSH_BATCH 8                // 16 is no faster (the write-back is bandwidth-, not latency-bound), 32 spills
 #endif
@@ -466,12 +475,12 @@ __global__ __launch_bounds__(1024) void k_run1024v2_fixup(Run1024v2Args A)
 {
     const unsigned w = blockIdx.x + 1, k = threadIdx.x;
     unsigned first, last;
-    run_bounds(A.nb, A.nruns, w, first, last);
+    run_bounds(A.nb, A.nruns, A.n0, w, first, last);
     if (first >= last) return;
     unsigned wp = w - 1;
     for (;;) {                                          // the run before w that is not empty
         unsigned f0, l0;
-        run_bounds(A.nb, A.nruns, wp, f0, l0);
+        run_bounds(A.nb, A.nruns, A.n0, wp, f0, l0);
         if (f0 < l0 || wp == 0) break;
         wp--;
     }
@@ -490,6 +499,10 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
     A.rp_in = h.rp_in; A.rp_out = h.rp_out; A.yfirst = h.yfirst; A.ylast = h.ylast; A.stage = h.stage;
     A.nf = h.nf; A.nb = h.nf / B2_T4; A.nruns = h.nruns; A.parity0 = h.parity0; A.out_stride = h.nf;
+    {
+        static const double wt = getenv("CSDR_RUN1024_WEIGHT") ? atof(getenv("CSDR_RUN1024_WEIGHT")) : 1.2;   // share of the older workgroup of a CU (1 = even)
+        A.n0 = (h.nruns >= 2 && !(h.nruns & 1u) && wt > 1.0 && wt < 1.5) ? (uint32_t)std::llround(0.5 * wt * (double)A.nb) : 0u;
+    }
     const double beta = h.dc_block ? h.beta : 0.0;
     A.alpha = h.dc_block ? (float)(1.0 - beta) : 0.0f; A.beta = (float)beta; A.l2beta = h.dc_block ? (float)std::log2(beta) : -1000.0f;
     for (int i = 0; i < 16; i++) A.b16[i] = (float)std::pow(beta, 16.0 * i);
@@ -509,12 +522,13 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
 
 uint32_t run1024_v2_runs(uint32_t nf, uint32_t cus)
 {
-    // two workgroups per CU; a run >= 1 spends 6 read-only + 4 halo tiles on its start state and starts on an 8-tile boundary:
-    // at least 16 tiles per run
+    // two workgroups per CU; a run >= 1 spends 6 read-only + 4 halo tiles on its start state; the shorter (younger) runs get
+    // up to 1/4 less than the average: at least 24 tiles per run on average (>= 16 for every one)
     const uint32_t nb = nf / B2_T4;
     uint32_t nruns = 2 * cus;
     if (const char *e = getenv("CSDR_RUN1024_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
-    if (nruns > nb / 16) nruns = nb / 16;
+    if (nruns > nb / 24) nruns = nb / 24;
+    if (nruns > 2) nruns &= ~1u;
     return nruns;                                       // 0: too short for this kernel
 }
 

@@ -1246,7 +1246,7 @@ def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatc
     (CSDR_RUN1024_V1) and the oracle: a 5-frame call first (odd: first-generation kernel, leaves the NCO parity odd and a
     non-trivial DC state, window and r'), then 4096 frames (64 runs with warm-up, halo and fix-up), then 512."""
     M = 1024
-    frames = [5, 4096, 512]
+    frames = [5, 4096, 512, 1200]
     nf = sum(frames)
     x = synth_cf32(M * nf, M, seed=77)
     x = (x + np.complex64(0.01 - 0.005j)).astype(np.complex64)    # a DC offset the blocker has to remove across run starts
