@@ -353,7 +353,12 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             bfly4_v(y[f][0], y[f][1], y[f][2], y[f][3]);
         }
         // ---- tail: results into slot ts of the staging block (each store instruction: 1 KiB contiguous)
-        constexpr unsigned TB = FM ? 8u : 4u, PB = FM ? 16u : 32u;              // tiles per block, bytes per (tile, row) piece
+#ifndef B2_HALF_LINES
+#define B2_HALF_LINES 0  // 1: blocks of half a line per row (4 / 2 tiles, 64 KiB of staging per workgroup): measured, slower
+#endif
+        constexpr unsigned PB = FM ? 16u : 32u;                                  // bytes per (tile, row) piece
+        constexpr unsigned TB = (FM ? 8u : 4u) >> B2_HALF_LINES;                 // tiles per block
+        constexpr unsigned UL = TB * PB / 16u;                                   // 16-byte units (= lanes) per row piece of a block: 8 or 4
         const unsigned ts = b & (TB - 1u);
         const char *sbase = A.stage + (size_t)w * 131072u + (size_t)ts * (1024u * PB);
         if (FM) {
@@ -412,7 +417,8 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             typedef unsigned v4u __attribute__((ext_vector_type(4)));
             const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(A.stage) + (size_t)w * 131072u, 0, 131072, 0x00020000);
             const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)(1024u * A.out_stride * esz), 0x00020000);
-            const unsigned lane = joff_t >> 4 & 63u, u = lane & 7u, rowl = 8u * wave_u + (lane >> 3);    // 16-byte unit of the line, row in a group of 32
+            constexpr unsigned RW = 64u / UL, RS = 4u * RW, NS = 1024u / RS;       // rows per wave instruction, per step of the workgroup; steps
+            const unsigned lane = joff_t >> 4 & 63u, u = lane & (UL - 1u), rowl = RW * wave_u + lane / UL;    // 16-byte unit of the piece, row in a group of RS
             const unsigned tsrc = FM ? u : (u >> 1);                            // the tile my unit comes from
             const unsigned ld = FM ? (u * 1024u + rowl) * 16u : ((u >> 1) * 1024u + rowl) * 32u + (u & 1u) * 16u;
             const unsigned st = rowl * A.out_stride * esz + u * 16u;
@@ -423,18 +429,18 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
 #define B2_FLUSH_BATCH 8                // 16 is no faster (the write-back is bandwidth-, not latency-bound), 32 spills
 #endif
 #pragma unroll 1
-            for (unsigned g = 0; g < 32u / B2_FLUSH_BATCH; g++) {                 // loads of a batch go out together: one memory latency per batch
+            for (unsigned g = 0; g < NS / B2_FLUSH_BATCH; g++) {                 // loads of a batch go out together: one memory latency per batch
                 v4u v[B2_FLUSH_BATCH];
 #pragma unroll
                 for (unsigned i = 0; i < B2_FLUSH_BATCH; i++)
-                    v[i] = (B2_ABLATE & 256) ? (v4u){ld, st, g, i} : __builtin_amdgcn_raw_buffer_load_b128(srs, (int)ld, (int)((B2_FLUSH_BATCH * g + i) * 32u * PB), 0);
+                    v[i] = (B2_ABLATE & 256) ? (v4u){ld, st, g, i} : __builtin_amdgcn_raw_buffer_load_b128(srs, (int)ld, (int)((B2_FLUSH_BATCH * g + i) * RS * PB), 0);
                 if (B2_ABLATE & 512) {
 #pragma unroll
                     for (unsigned i = 0; i < B2_FLUSH_BATCH; i++) asm volatile("" :: "v"(v[i]));
                 } else if (mine) {
 #pragma unroll
                     for (unsigned i = 0; i < B2_FLUSH_BATCH; i++)
-                        __builtin_amdgcn_raw_buffer_store_b128(v[i], ors, (int)st, (int)(o0 + (B2_FLUSH_BATCH * g + i) * 32u * A.out_stride * esz), 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(v[i], ors, (int)st, (int)(o0 + (B2_FLUSH_BATCH * g + i) * RS * A.out_stride * esz), 0);
                 }
             }
         }
