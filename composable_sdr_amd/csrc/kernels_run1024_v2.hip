@@ -31,9 +31,15 @@
                          // 32 no DFT passes 1-2, 64 no DC scan, 128 no window shift, 256 block flush without its loads, 512 without its stores, 1024 no flush
 #endif
 
+#ifndef B2_FM_PACKED
+#define B2_FM_PACKED 1    // freqdem on packed pairs (fm_quad) or one sample at a time (fm_sample)
+#endif
 #ifndef B2_DIRECT
 #define B2_DIRECT 0      // 1: every tile stores its 16 / 32-byte row pieces straight into the rows (no staging block): the measured alternative
 #endif
+// Every asm store of more than 64 bits ends with s_nop 1: the store reads its data VGPRs for two more wait states, hipcc pads
+// that for its own stores but cannot see one inside inline asm (it reused the registers in the very next instruction: lanes
+// 12..15 of every row of 16 lost the second dword).
 #ifndef B2_STORE_MOD
 #define B2_STORE_MOD ""  // cache policy bits of the output stores (experiments: " nt", " sc1", " sc0 sc1")
 #endif
@@ -60,7 +66,6 @@ struct Run1024v2Args {
     const float2 *uhist_in; float2 *uhist_out;    // [13][1024] pre-mixed, DC-blocked window before / after the call
     const float2 *vend_in; float2 *vend_out;      // DC blocker state v1
     const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r'
-    float2 *yfirst, *ylast;     // [nruns][1024]
     char *stage;                // [nruns] staging blocks of 128 KiB
     uint32_t nf, nb, nruns, n0, parity0, out_stride;   // n0: tiles of the first half of the runs (0: even split)
     float alpha, beta, l2beta, fm_ref, tiny;
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
     const unsigned pk0 = raw_a0 | (x_a0 << 16), pk1 = z1r0 | (z1w0 << 16), pk2 = z2w | (z2r << 16), pk3 = goff | (joff << 16);
     const uint32_t esz = FM ? 4u : 8u;
 
-    auto tile = [&](unsigned b_, const int par, const bool warm) {
+    auto tile = [&](unsigned b_, const int par, const bool warm, const bool mute) {
         unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)b_);            // keep the tile index (store / DMA bases) in SGPRs
         asm volatile("" : "+s"(b));
         char *B = reinterpret_cast<char *>(L) + par * (B2_BUF * 8);             // this tile's buffer
@@ -361,20 +366,14 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
         constexpr unsigned UL = TB * PB / 16u;                                   // 16-byte units (= lanes) per row piece of a block: 8 or 4
         const unsigned ts = b & (TB - 1u);
         const char *sbase = A.stage + (size_t)w * 131072u + (size_t)ts * (1024u * PB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tile image: nothing else is outstanding
         if (FM) {
-            if (b == first && w > 0) {                  // scalar base + lane offset: a 64-bit lane address would sit in the spill area all loop long
-#pragma unroll
-                for (int k3 = 0; k3 < 4; k3++) {
-                    const float2 *yf = A.yfirst + (size_t)w * B2_M + 256 * k3;
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" :: "v"(joff_t >> 1), "v"(y[0][k3]), "s"(yf) : "memory");
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile image: nothing else is outstanding
             char *stp = reinterpret_cast<char *>(ST) + z2r_t;      // my 32 bytes of the stash: [kk][k3]
             const v4f p01 = *reinterpret_cast<const v4f *>(stp), p23 = *reinterpret_cast<const v4f *>(stp + 16);
             const float2 prev[4] = {make_float2(p01.x, p01.y), make_float2(p01.z, p01.w), make_float2(p23.x, p23.y), make_float2(p23.z, p23.w)};
             *reinterpret_cast<v4f *>(stp) = (v4f){y[3][0].x, y[3][0].y, y[3][1].x, y[3][1].y};
             *reinterpret_cast<v4f *>(stp + 16) = (v4f){y[3][2].x, y[3][2].y, y[3][3].x, y[3][3].y};
+            if (mute) return;                           // the tile in front of the run: only its last frame was wanted (freqdem history)
             // tile-local copies of the uniform scalings: as loop invariants they end up as VGPRs in the spill area
             FmK2 fkt = fk;
             asm volatile("" : "+s"(fkt.ref), "+s"(fkt.hp), "+s"(fkt.pi), "+s"(fkt.tiny));
@@ -386,16 +385,21 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
                 const float2 rr[4] = {to_f2(y[0][k3]), to_f2(y[1][k3]), to_f2(y[2][k3]), to_f2(y[3][k3])};
                 float mq[4];
                 if (B2_ABLATE & 4) { mq[0] = rp[0].x + rr[0].y; mq[1] = rp[1].y + rr[1].x; mq[2] = rp[2].x + rr[2].y; mq[3] = rp[3].y + rr[3].x; }
-                else fm_quad(rp, rr, fkt, mq);
+                else if (B2_FM_PACKED) fm_quad(rp, rr, fkt, mq);
+                else {
+                    const FmK k1s = {fkt.tiny, fkt.ref, fkt.hp, fkt.pi};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) mq[u] = fm_sample(rp[u], rr[u], k1s);
+                }
                 const v4f mv = {mq[0], mq[1], mq[2], mq[3]};
                 const char *sp = sbase + k3 * (256 * 16);
                 const char *rowp = reinterpret_cast<const char *>(A.out) + (size_t)4 * b * esz + (size_t)k3 * 256 * A.out_stride * esz;
                 if (B2_ABLATE & 2) asm volatile("" :: "v"(mv), "s"(sp));
-                else if (B2_DIRECT) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(mv), "s"(rowp) : "memory");
-                else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"(joff_t), "v"(mv), "s"(sp) : "memory");
+                else if (B2_DIRECT) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(mv), "s"(rowp) : "memory");
+                else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"(joff_t), "v"(mv), "s"(sp) : "memory");
             }
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (mute) return;
 #pragma unroll
             for (int k3 = 0; k3 < 4; k3++) {
                 const v4f lo = {y[0][k3].x, y[0][k3].y, y[1][k3].x, y[1][k3].y}, hi = {y[2][k3].x, y[2][k3].y, y[3][k3].x, y[3][k3].y};
@@ -403,11 +407,11 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
                 const char *rowp = reinterpret_cast<const char *>(A.out) + (size_t)4 * b * esz + (size_t)k3 * 256 * A.out_stride * esz;
                 if (B2_ABLATE & 2) asm volatile("" :: "v"(lo), "v"(hi), "s"(sp));
                 else if (B2_DIRECT) {
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(lo), "s"(rowp) : "memory");
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(hi), "s"(rowp) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(lo), "s"(rowp) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16" "\n\ts_nop 1" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(hi), "s"(rowp) : "memory");
                 } else {
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" :: "v"(2u * joff_t), "v"(lo), "s"(sp) : "memory");
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16" :: "v"(2u * joff_t), "v"(hi), "s"(sp) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"(2u * joff_t), "v"(lo), "s"(sp) : "memory");
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16" "\n\ts_nop 1" :: "v"(2u * joff_t), "v"(hi), "s"(sp) : "memory");
                 }
             }
         }
@@ -446,27 +450,32 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
         }
     };
 
-    if (tile_begin < last) dma_tile(x4 + (size_t)tile_begin * 2048, goff, lds_wave);
+    // Buffer parity: the main loop starts in buffer 1.  A run >= 1 walks three halo tiles (window and DC state only: buffers 0, 1, 0)
+    // and then enters the main loop one tile early, muted: tile first - 1 goes through FIR and DFT for its last frame, the
+    // freqdem history of the run's first sample (the window behind that frame is complete: 15 halo frames).
+    if (tile_begin < last) dma_tile(x4 + (size_t)tile_begin * 2048, goff, lds_wave + (w == 0 ? (unsigned)(B2_BUF * 8u) : 0u));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (unsigned b = tile_begin; b < first; b += 2) {   // halo tiles (an even number): DC blocker, pre-mix and the window only
-        tile(b, 0, true);
+    unsigned bm = first;
+    if (w > 0) {
+        tile(tile_begin, 0, true, false);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        tile(b + 1, 1, true);
+        tile(tile_begin + 1, 1, true, false);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tile(tile_begin + 2, 0, true, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bm = first - 1;
     }
-    for (unsigned b = first; b < last; b += 2) {
-        tile(b, 0, false);
+    for (unsigned b = bm; b < last; b += 2) {
+        tile(b, 1, false, b < first);
         if (b + 1 >= last) break;
-        tile(b + 1, 1, false);
+        tile(b + 1, 0, false, false);
     }
 
     // ------------------------------------------------------------------ state after the run
     if (FM) {                                           // a thread reads back what it wrote
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++) {
-            const float2 pv = ST[4 * tid + k3];
-            A.ylast[(size_t)w * B2_M + tid + 256 * k3] = pv;
-            if (last == A.nb) A.rp_out[tid + 256 * k3] = pv;
+            if (last == A.nb) A.rp_out[tid + 256 * k3] = ST[4 * tid + k3];
         }
     }
     if (last == A.nb) {
@@ -476,34 +485,15 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
     }
 }
 
-// first freqdem sample of every run w >= 1
-__global__ __launch_bounds__(1024) void k_run1024v2_fixup(Run1024v2Args A)
-{
-    const unsigned w = blockIdx.x + 1, k = threadIdx.x;
-    unsigned first, last;
-    run_bounds(A.nb, A.nruns, A.n0, w, first, last);
-    if (first >= last) return;
-    unsigned wp = w - 1;
-    for (;;) {                                          // the run before w that is not empty
-        unsigned f0, l0;
-        run_bounds(A.nb, A.nruns, A.n0, wp, f0, l0);
-        if (f0 < l0 || wp == 0) break;
-        wp--;
-    }
-    const float2 rp = A.ylast[(size_t)wp * B2_M + k], r = A.yfirst[(size_t)w * B2_M + k];
-    ((float *)A.out)[(size_t)k * A.out_stride + (size_t)first * B2_T4] =
-        scaled_atan2f(fmaf(rp.x, r.y, -(rp.y * r.x)), fmaf(rp.x, r.x, rp.y * r.y), A.pk);
-}
-
 }  // namespace
 
-// one timed launch + the fix-up of the run starts (called by big_process, kernels_pfb1024.hip)
+// one launch per call (called by big_process, kernels_pfb1024.hip); no fix-up kernel: a run computes the frame in front of it itself
 int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTimer *timer)
 {
     Run1024v2Args A{};
     A.x = h.x; A.out = h.out; A.taps_q = h.taps_q; A.tw = h.tw;
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
-    A.rp_in = h.rp_in; A.rp_out = h.rp_out; A.yfirst = h.yfirst; A.ylast = h.ylast; A.stage = h.stage;
+    A.rp_in = h.rp_in; A.rp_out = h.rp_out; A.stage = h.stage;
     A.nf = h.nf; A.nb = h.nf / B2_T4; A.nruns = h.nruns; A.parity0 = h.parity0; A.out_stride = h.nf;
     {
         static const double wt = getenv("CSDR_RUN1024_WEIGHT") ? atof(getenv("CSDR_RUN1024_WEIGHT")) : 1.2;   // share of the older workgroup of a CU (1 = even)
@@ -521,7 +511,6 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
     if (fm) hipLaunchKernelGGL(k_run1024v2<true>, dim3(h.nruns), dim3(256), 0, s, A);
     else hipLaunchKernelGGL(k_run1024v2<false>, dim3(h.nruns), dim3(256), 0, s, A);
     if (timer && (r = timer->end(s))) return r;
-    if (fm && h.nruns > 1) hipLaunchKernelGGL(k_run1024v2_fixup, dim3(h.nruns - 1), dim3(1024), 0, s, A);
     CSDR_HIP(hipGetLastError());
     return 0;
 }
