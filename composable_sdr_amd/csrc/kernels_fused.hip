@@ -849,7 +849,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         else if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), extra_lds, s, RA);
         else hipLaunchKernelGGL(k_run256<false>, dim3(nruns), dim3(256), extra_lds, s, RA);
         if (timer && (r = timer->end(s))) return r;
-        if (c.fm && nruns > 1)
+        if (c.fm && nruns > 1 && !v2)                            // k_run256v2 computes the frame in front of a run itself
             hipLaunchKernelGGL(k_run_fixup, dim3(nruns - 1), dim3(256), 0, s, p->d_yfirst, (const float2 *)p->d_ylast,
                                (float *)A.out, nf, RA.split, c.c0, c.C, c.fm_ref);
         const uint32_t rem = nf - nb_full * NB;

@@ -5,8 +5,7 @@
 //                                                                     828-862, 324-328)
 //
 // Same run structure as k_run256 (a workgroup walks a run of 16-frame tiles; FIR window, DC state and freqdem history
-// never leave the workgroup; read-only warm-up at the run start; k_run_fixup finishes the first freqdem sample of a
-// run), but the tile body is rebuilt around what tools/probes/issue_probe*.hip measured on gfx950:
+// never leave the workgroup; read-only warm-up at the run start), but the tile body is rebuilt around what tools/probes/issue_probe*.hip measured on gfx950:
 //   * every VALU instruction costs an issue slot of ~3 (plain VOP1/2/3 on VGPRs) to ~4.7 cycles (DPP, packed, SGPR
 //     operand, min/max/bfi), v_rcp 9 and a VCC-based v_cndmask 16; k_run256 spent 160 DPP + 190 v_mov + 32 VCC selects
 //     per tile and thread.  Here the DC blocker runs as a plain serial scan over 16 consecutive samples per thread out
@@ -65,6 +64,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 #pragma unroll
     for (int f = 0; f < NB; f++) { wa[f] = make_float2(0.f, 0.f); wb[f] = make_float2(0.f, 0.f); }
     float2 c;                                           // DC state v before the next tile (same in every lane)
+    float2 w2 = make_float2(0.f, 0.f);
 
     // ------------------------------------------------------------------ run start (as k_run256)
     if (w == 0) {
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         stage_and_scan(raw, R, E, Tt, A, tid);
 #pragma unroll
         for (int f = 3; f < NB; f++) wa[f] = R[256 * f + col_off];
+        w2 = R[256 * 2 + col_off];                      // FM: the 14th tap of the halo tile's last frame (freqdem history of the run)
         const float kj = -A.alpha * A.bj[j & 15];
         const float br = A.b16[tid & 15], bf = A.b256[tid >> 4];
         float2 vb, ve;
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         __syncthreads();
 #pragma unroll
         for (int f = 3; f < NB; f++) wa[f] = cfma(E[16 * f + (j >> 4)], kj, wa[f]);
+        w2 = cfma(E[16 * 2 + (j >> 4)], kj, w2);
     }
     const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
 #pragma unroll
@@ -135,6 +137,40 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     // freqdem history: stash[k1][i] = last Y frame of channel k1 + 16 XIDX(i)
     ST[(tid & 15) * 16 + XIDX(tid >> 4)] = (FM && w == 0) ? A.rp_in[tid] : make_float2(0.f, 0.f);
     __syncthreads();                                    // R, E free; stash visible
+    if (FM && w > 0) {
+        // The run's first freqdem sample needs the frame in front of it: the halo tile's last frame goes through the FIR and
+        // a one-frame DFT here (same arithmetic as the tile loop: pass 1 thread b1, pass 2 thread k1), instead of a fix-up
+        // kernel after the launch patching one float into every row.
+        w2 = cmul(w2, Wa);
+        v2f acc = {0.f, 0.f};
+#pragma unroll
+        for (int n = P - 1; n >= 0; n--) {
+            const float hn = A.taps[(M256 - 1 - j) + n * M256];
+            const float2 s2 = (n == P - 1) ? w2 : wa[NB - 1 - n];
+            acc = __builtin_elementwise_fma((v2f){s2.x, s2.y}, (v2f){hn, hn}, acc);
+        }
+        R[j] = to_f2(acc);
+        __syncthreads();
+        v2f vv[16];
+        if (tid < 16) {
+#pragma unroll
+            for (int a = 0; a < 16; a++) vv[a] = to_v(R[16 * a + tid]);
+            fft16_v(vv);
+#pragma unroll
+            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(A.tw[16 * XIDX(i) + tid]));
+#pragma unroll
+            for (int i = 0; i < 16; i++) E[16 * XIDX(i) + tid] = to_f2(vv[i]);     // Z[k1][b1]
+        }
+        __syncthreads();
+        if (tid < 16) {
+#pragma unroll
+            for (int b = 0; b < 16; b++) vv[b] = to_v(E[16 * tid + b]);
+            fft16_v(vv);                                // vv[i] = Y[tid + 16 XIDX(i)]
+#pragma unroll
+            for (int i = 0; i < 16; i++) ST[tid * 16 + i] = to_f2(vv[i]);
+        }
+        __syncthreads();
+    }
 
     // ------------------------------------------------------------------ per-thread constants of the tile loop
     float h[P];
@@ -281,10 +317,6 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         // ---- tail
         char *obase = reinterpret_cast<char *>(A.out) + (size_t)16 * b * (FM ? 4u : 8u);
         if (FM) {
-            if (b == first && w > 0 && f2 == 0) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) RA.yfirst[(size_t)w * M256 + k1 + 16 * XIDX(i)] = to_f2(vv[i]);
-            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile image (issued a tile ago): nothing else is outstanding
 #pragma unroll
             for (int i = 0; i < 16; i += 4) {
@@ -346,7 +378,6 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     bar();                                              // stash of the last tile visible to every wave
     if (FM) {
         const float2 lastY = ST[(tid & 15) * 16 + XIDX(tid >> 4)];
-        reinterpret_cast<float2 *>(A.ylast)[(size_t)w * M256 + tid] = lastY;
         if (last == A.nb) A.rp_out[tid] = lastY;
     }
     if (last == A.nb && tid == 0) A.vend_out[0] = c;
