@@ -28,6 +28,13 @@
 #define V2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem, 8 one FIR tap
 #endif
 
+#ifndef V2_SNOP
+// Wait states in front of the asm stores would cover a scalar base that comes straight out of a spill lane (v_readlane ->
+// VMEM hazard, fused_v2_common.h); they cost 1 % of the launch, and this kernel has no SGPR spills (the bases are SALU
+// results of the tile index): empty, and tests/test_build_invariants.py fails when a change makes hipcc spill SGPRs here.
+#define V2_SNOP ""
+#endif
+
 #include "fused_v2_common.h"
 
 namespace csdr {
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                 for (int u = 0; u < 4; u++) {                       // stores go out between the quads
                     const char *rowp = obase + (size_t)XIDX(i + u) * row16;
                     if (V2_ABLATE & 2) asm volatile("" :: "v"(mq[u]), "s"(rowp));
-                    else asm volatile("global_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
+                    else asm volatile(V2_SNOP "global_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
                 }
             }
             if (f2 == 15) {
@@ -357,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             for (int i = 0; i < 16; i++) {
                 const char *rowp = obase + (size_t)XIDX(i) * row16;
                 if (V2_ABLATE & 2) asm volatile("" :: "v"(vv[i]), "s"(rowp));
-                else asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(vv[i]), "s"(rowp) : "memory");
+                else asm volatile(V2_SNOP "global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(vv[i]), "s"(rowp) : "memory");
             }
         }
         V2STAMP(14);

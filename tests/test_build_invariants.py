@@ -1,0 +1,34 @@
+"""Build-time invariants the hand-written asm of the run kernels relies on (no GPU needed: hipcc cross-compiles).
+
+k_run256v2 issues its output stores from inline asm with a scalar base and no wait states in front (1 % of the launch).
+That is only safe while hipcc does not spill SGPRs in the kernel: a base reloaded from a spill lane (v_readlane = a VALU
+write of an SGPR) must be five wait states old before a VMEM instruction reads it, and the hazard recognizer does not look
+into inline asm ("Inline-asm hazards").  k_run1024v2 does spill SGPRs and pays for the wait states."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_run256v2_has_no_register_spills(tmp_path):
+    src = os.path.join(ROOT, "composable_sdr_amd", "csrc")
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", os.path.join(src, "kernels_fused_v2.hip"),
+                          "-o", str(tmp_path / "v2.o"), "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = re.split(r"remark: Function Name: ", out.stderr)[1:]
+    seen = 0
+    for b in blocks:
+        if "k_run256v2" not in b.splitlines()[0]:
+            continue
+        seen += 1
+        sg = int(re.search(r"SGPRs Spill: (\d+)", b).group(1))
+        vg = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
+        assert sg == 0 and vg == 0, f"k_run256v2 spills (SGPR {sg}, VGPR {vg}): its asm stores have no wait states in front (V2_SNOP)"
+    assert seen == 2                                     # <FM> and <CF32>
