@@ -65,7 +65,6 @@ struct Run1024v2Host {
     const float4 *taps_q;       // [4][4][256] float4: taps of branch 256 q + j (14) + its even-frame pre-mix phasor
     const float2 *tw;
     const float2 *uhist_in; float2 *uhist_out; const float2 *vend_in; float2 *vend_out; const float2 *rp_in; float2 *rp_out;
-    float2 *yfirst, *ylast;     // [nruns][1024] each
     char *stage;                // [nruns] output staging blocks of 128 KiB
     uint32_t nf, nruns, parity0;
     bool dc_block;

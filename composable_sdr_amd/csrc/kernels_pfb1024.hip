@@ -493,7 +493,7 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         ALLOC(p->d_vend[i], sizeof(float2));
         ALLOC(p->d_rp[i], sizeof(float2) * cfg.C);
     }
-    ALLOC(p->d_scratch, sizeof(float2) * 2 * (size_t)(2 * p->cus) * PM);      // k_run1024v2: two runs per CU
+    ALLOC(p->d_scratch, sizeof(float2) * 2 * (size_t)p->cus * PM);
     ALLOC(p->d_stage, (size_t)(2 * p->cus) * 131072u);
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
 #undef ALLOC
@@ -568,7 +568,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.uhist_in = p->d_uhist[p->cur]; H.uhist_out = p->d_uhist[p->cur ^ 1];
         H.vend_in = p->d_vend[p->cur]; H.vend_out = p->d_vend[p->cur ^ 1];
         H.rp_in = p->d_rp[p->cur]; H.rp_out = p->d_rp[p->cur ^ 1];
-        H.yfirst = p->d_scratch; H.ylast = p->d_scratch + (size_t)v2runs * PM; H.stage = p->d_stage;
+        H.stage = p->d_stage;
         H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
         if ((r = run1024_v2_launch(H, c.fm, s, timer))) return r;
