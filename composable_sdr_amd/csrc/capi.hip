@@ -120,7 +120,8 @@ struct csdr_chain {
     uint32_t G = 1;                  // chan_stride: interleaved shard g = c0 of G (generic route, pruned DFT)
     float2 *d_tw_g = nullptr, *d_fold_ph = nullptr, *d_fold = nullptr;   // (M/G)-point twiddles, fold phasors, folded frames
     bool mix_identity = false;       // DeNo --mix over all channels: M * (branch-0 FIR) instead of bank + DFT + sum
-    float2 *d_u0 = nullptr, *d_u0hist = nullptr;     // branch-0 samples of the call behind p - 1 of history; history between calls
+    float2 *d_u0 = nullptr, *d_u0hist = nullptr;     // branch-0 samples of the call behind p - 1 of history; history between calls (two copies, ping-pong)
+    int u0_cur = 0;
     float2 *d_u = nullptr, *d_hist_tmp = nullptr, *d_A = nullptr, *d_B = nullptr;
     AgcState *d_agc = nullptr;
     float2 *d_rp[2] = {nullptr, nullptr}; int rp_cur = 0;
@@ -616,7 +617,7 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
     h->theta = 0; h->tab_pos = 0; h->rp_cur = 0;
     CSDR_HIP(hipMemsetAsync(h->d_dcstate, 0, sizeof(float2), s));
     if (h->d_u) CSDR_HIP(hipMemsetAsync(h->d_u, 0, sizeof(float2) * (size_t)(h->p - 1) * h->M, s));
-    if (h->d_u0hist) CSDR_HIP(hipMemsetAsync(h->d_u0hist, 0, sizeof(float2) * (h->p - 1), s));
+    if (h->d_u0hist) { CSDR_HIP(hipMemsetAsync(h->d_u0hist, 0, sizeof(float2) * 2 * (h->p - 1), s)); h->u0_cur = 0; }
     if (h->d_agc) { int r = launch_agc_init(h->d_agc, h->C, s); if (r) return r; }
     if (h->d_rp[0]) {
         CSDR_HIP(hipMemsetAsync(h->d_rp[0], 0, sizeof(float2) * h->C, s));
@@ -757,8 +758,8 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         h->mix_identity = M > 1 && G == 1 && C == M && cfg->mix && cfg->demod == CSDR_DEMOD_NONE && cfg->agc_threshold_db == 0.0f &&
                           h->dctile && !(cfg->flags & CSDR_FLAG_NO_MIX_IDENTITY) && !am;
         if (h->mix_identity) {
-            if ((r = dev_alloc(&h->d_u0, (size_t)(h->p - 1) + h->max_nf)) || (r = dev_alloc(&h->d_u0hist, h->p - 1))) return fail(r);
-            h->path = "generic+mix-identity"; h->timed_kernel = (M % 4096u == 0) ? "k_dc_pick_tile" : "k_dc_tile";
+            if ((r = dev_alloc(&h->d_u0, (size_t)(h->p - 1) + h->max_nf)) || (r = dev_alloc(&h->d_u0hist, 2 * (h->p - 1)))) return fail(r);
+            h->path = "generic+mix-identity"; h->timed_kernel = (M % 4096u == 0) ? (getenv("CSDR_PICK_LOOKBACK") ? "k_dc_pick_tile" : "k_dc_fold") : "k_dc_tile";   // refined per call
         }
         if (G > 1) {
             const uint32_t Mg = M / G;
@@ -844,11 +845,22 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
         if (h->mix_identity) {
             // sum over ALL channels of a frame = M * X_t[0]: DC blocker + pre-mix on the whole stream, every M-th sample kept,
             // then the 2m-tap FIR of polyphase branch 0 (no bank, no DFT, no channel sum; 8 B read per input sample)
-            CSDR_HIP(hipMemcpyAsync(h->d_u0, h->d_u0hist, sizeof(float2) * (h->p - 1), hipMemcpyDeviceToDevice, s));
-            if ((r = h->timer.begin(s))) return r;
-            if ((r = dctile_process(h->dctile, d_in, h->d_u0 + (h->p - 1), nx, true, nco, h->d_nco_tab, s, M))) return r;
-            if ((r = h->timer.end(s))) return r;
-            if ((r = launch_branch0_fir(h->d_u0, h->d_taps, (float2 *)d_out, h->d_u0hist, M, h->p, nf, s))) return r;
+            float2 *hin = h->d_u0hist + (size_t)h->u0_cur * (h->p - 1), *hout = h->d_u0hist + (size_t)(h->u0_cur ^ 1) * (h->p - 1);
+            if (dctile_mix_identity_supported(h->dctile, M, nx, h->p)) {
+                // k_dc_fold (one aggregate per tile: a plain streaming read) + k_mixid_finish (DC state, pick, pre-mix, FIR)
+                h->timed_kernel = "k_dc_fold";
+                if ((r = h->timer.begin(s))) return r;
+                if ((r = dctile_mix_identity(h->dctile, d_in, nx, nco, h->d_nco_tab, h->d_taps, M, h->p, hin, hout, (float2 *)d_out, s))) return r;
+                if ((r = h->timer.end(s))) return r;
+            } else {
+                h->timed_kernel = (M % 4096u == 0) ? "k_dc_pick_tile" : "k_dc_tile";
+                CSDR_HIP(hipMemcpyAsync(h->d_u0, hin, sizeof(float2) * (h->p - 1), hipMemcpyDeviceToDevice, s));
+                if ((r = h->timer.begin(s))) return r;
+                if ((r = dctile_process(h->dctile, d_in, h->d_u0 + (h->p - 1), nx, true, nco, h->d_nco_tab, s, M))) return r;
+                if ((r = h->timer.end(s))) return r;
+                if ((r = launch_branch0_fir(h->d_u0, h->d_taps, (float2 *)d_out, hout, M, h->p, nf, s))) return r;
+            }
+            h->u0_cur ^= 1;
             h->theta += nx * h->d_theta;
             if (h->tab_len) h->tab_pos = (uint32_t)(((uint64_t)h->tab_pos + nx) % h->tab_len);
             return 0;

@@ -83,6 +83,9 @@ int  dctile_reset(DcTilePlan *plan, hipStream_t s);
 int  dctile_process(DcTilePlan *plan, const float2 *x, float2 *y, uint32_t n, bool do_mix, const NcoParams &nco,
                     const float2 *nco_tab, hipStream_t s, uint32_t pick = 0);
 // out[t] = M sum_n taps[(M-1) + n M] u0[(p-1) + t - n]; hist_out <- the last p - 1 samples of u0 (the next call's history)
+bool dctile_mix_identity_supported(const DcTilePlan *plan, uint32_t M, uint32_t n, uint32_t taps_p);
+int  dctile_mix_identity(DcTilePlan *plan, const float2 *x, uint32_t n, const NcoParams &nco, const float2 *nco_tab, const float *taps,
+                         uint32_t M, uint32_t taps_p, const float2 *hist_in, float2 *hist_out, float2 *out, hipStream_t s);
 int  launch_branch0_fir(const float2 *u0, const float *taps, float2 *out, float2 *hist_out, uint32_t M, uint32_t p, uint32_t nf, hipStream_t s);
 // sticky device-side error word (a look-back wait hit its spin limit); reads, then clears it; synchronises
 int  dctile_status(DcTilePlan *plan, unsigned *status);

@@ -5,6 +5,7 @@
 // Replaces iirfilt_crcf_execute_block + nco_crcf_mix_block_down (Liquid.chs:575-589, 846-847)
 // for whole chunks; the 3-kernel scan in kernels_generic.hip remains for the standalone Pipes.
 #include "fused_common.h"
+#include <cstring>
 
 namespace csdr {
 
@@ -303,6 +304,118 @@ __global__ __launch_bounds__(256) void k_dc_pick_tile(DcTileArgs D, float l2beta
     }
 }
 
+// The same job without any inter-workgroup hand-off (round 2): the DC state in front of a frame is a decayed sum over
+// everything before it, so k_dc_fold leaves one zero-state aggregate (and the first sample) per 4096-sample tile -- one
+// wave per tile, four 8 KiB quarters with the next one in flight, no LDS, no barrier, no ticket: a plain streaming read --
+// and k_mixid_finish forms the state in front of a frame from the ten aggregates before it (beta^(4096 * 10) = 1.3e-9 of
+// anything older: the cut the look-back kernels make) and runs the branch-0 FIR.
+__global__ __launch_bounds__(256) void k_dc_fold(const float4 *__restrict__ x, float2 *__restrict__ agg, float2 *__restrict__ first, uint32_t nb, float l2beta)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wid = (blockIdx.x * 256u + threadIdx.x) >> 6, nw = (gridDim.x * 256u) >> 6;
+    float w0[8], w1[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int n = 2 * (64 * it + lane);             // first of my two samples of piece `it` inside a 1024-sample quarter
+        w0[it] = exp2f((float)(1023 - n) * l2beta); w1[it] = exp2f((float)(1022 - n) * l2beta);
+    }
+    const float bq = exp2f(1024.0f * l2beta);           // beta^1024: one quarter further
+    float4 cur[8], nxt[8];
+    uint32_t b = wid;
+    if (b < nb) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) cur[it] = x[(size_t)b * 2048 + 64 * it + lane];
+    }
+    for (; b < nb; b += nw) {
+        float2 a = make_float2(0.f, 0.f);
+        float2 x0 = make_float2(cur[0].x, cur[0].y);    // lane 0: the tile's first sample (the picked one)
+#pragma unroll 1
+        for (int qd = 0; qd < 4; qd++) {
+            // next quarter (of this tile, or the first one of my next tile) in flight
+            const uint32_t bn = qd < 3 ? b : b + nw;
+            const int qn = qd < 3 ? qd + 1 : 0;
+            if (bn < nb) {
+#pragma unroll
+                for (int it = 0; it < 8; it++) nxt[it] = x[(size_t)bn * 2048 + 512 * qn + 64 * it + lane];
+            }
+            float2 p = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                p = cfma(make_float2(cur[it].x, cur[it].y), w0[it], p);
+                p = cfma(make_float2(cur[it].z, cur[it].w), w1[it], p);
+            }
+            a = cfma(a, bq, p);                         // per lane: the lanes are summed once per tile
+#pragma unroll
+            for (int it = 0; it < 8; it++) cur[it] = nxt[it];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a.x += __shfl_xor(a.x, d); a.y += __shfl_xor(a.y, d); }
+        if (lane == 0) { agg[b] = a; first[b] = x0; }
+    }
+}
+
+// The mix identity in two launches: k_dc_fold, then this -- the picked samples of a workgroup's 256 frames (+ p - 1 in front:
+// from the tile aggregates, or from the previous call's history) go to LDS, the branch-0 FIR runs out of it
+// (out[t] = M sum_n h[(M-1) + n M] u0[t - n]), the call's last p - 1 picked samples and the DC state are left for the next call.
+__device__ __forceinline__ float2 dc_state_before(const DcTileArgs &D, const float2 *__restrict__ agg, uint32_t b)
+{
+    float2 v = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int k = LOOKBACK; k >= 1; k--) {
+        if (b >= (uint32_t)k) { const float2 a = agg[b - k]; v = make_float2(fmaf(a.x, D.wtile[k - 1], v.x), fmaf(a.y, D.wtile[k - 1], v.y)); }
+    }
+    if (b <= LOOKBACK) { const float2 vi = D.vend_in[0]; v = make_float2(fmaf(vi.x, D.wtile[b], v.x), fmaf(vi.y, D.wtile[b], v.y)); }
+    return v;
+}
+__global__ __launch_bounds__(256) void k_mixid_finish(DcTileArgs D, const float2 *__restrict__ agg, const float2 *__restrict__ first,
+                                                     const float *__restrict__ taps, const float2 *__restrict__ hist_in, float2 *__restrict__ hist_out,
+                                                     float2 *__restrict__ out, uint32_t M, uint32_t p, uint32_t nf)
+{
+    __shared__ float2 u[256 + 32];                      // p - 1 <= 32 samples of history in front
+    const uint32_t tid = threadIdx.x, f0 = blockIdx.x * 256u, tpf = D.pick / 4096u, H = p - 1;
+    auto picked = [&](int64_t f) -> float2 {
+        if (f < 0) return hist_in[(int64_t)H + f];
+        const uint32_t b = (uint32_t)f * tpf, n0 = b * 4096u;
+        const float2 v = dc_state_before(D, agg, b), x0 = first[b];
+        float2 y = make_float2(fmaf(-D.alpha, v.x, x0.x), fmaf(-D.alpha, v.y, x0.y));
+        if (D.do_mix) {
+            float c_, s_;
+            if (D.nco.tab_len) { const float2 cs = D.nco_tab[(D.nco.tab_pos + n0) % D.nco.tab_len]; c_ = cs.x; s_ = cs.y; }
+            else {
+                const uint32_t theta = D.nco.theta0 + n0 * D.nco.d_theta;
+                sincosf((float)(6.283185307179586 * (double)(float)theta / 4294967296.0), &s_, &c_);
+            }
+            if (!D.nco.up) s_ = -s_;
+            y = make_float2(y.x * c_ - y.y * s_, y.x * s_ + y.y * c_);
+        }
+        return y;
+    };
+    u[H + tid] = (f0 + tid < nf) ? picked((int64_t)(f0 + tid)) : make_float2(0.f, 0.f);
+    if (tid < H) u[tid] = picked((int64_t)f0 - (int64_t)H + (int64_t)tid);
+    __syncthreads();
+    const uint32_t t = f0 + tid;
+    if (t < nf) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (uint32_t n = p; n-- > 0;) {                 // oldest tap first, like the bank's dot product
+            const float h = taps[(M - 1) + (size_t)n * M];
+            const float2 w = u[H + tid - n];
+            acc.x = fmaf(w.x, h, acc.x); acc.y = fmaf(w.y, h, acc.y);
+        }
+        out[t] = make_float2(acc.x * (float)M, acc.y * (float)M);
+    }
+    if (f0 + 256u >= nf) {                               // the workgroup with the call's last frame
+        if (tid < H) {
+            const int64_t f = (int64_t)nf - (int64_t)H + (int64_t)tid;      // >= f0 - H when nf >= ... ; earlier frames come from the old history
+            hist_out[tid] = (f >= (int64_t)f0 - (int64_t)H) ? u[(uint32_t)(f - ((int64_t)f0 - (int64_t)H))] : picked(f);
+        }
+        if (tid == 0) {
+            const uint32_t b = D.nb - 1;
+            const float2 v = dc_state_before(D, agg, b), a = agg[b];
+            D.vend_out[0] = make_float2(fmaf(v.x, D.wtile[1], a.x), fmaf(v.y, D.wtile[1], a.y));
+        }
+    }
+}
+
 // DeNo --mix over ALL channels of an M-channel bank (Trans.hs:119-122 after Liquid.chs:843): sum_k Y_t[k] = M X_t[0], because
 // sum_k W_M^{jk} = M delta[j]: only polyphase branch 0 of every frame survives the channel sum.  u0[13 + t] = DC-blocked,
 // pre-mixed sample t*M of the stream (13 samples of history in front); out[t] = M sum_n h[(M-1) + n M] u0[13 + t - n].
@@ -336,6 +449,8 @@ struct DcTilePlan {
     uint32_t max_nb = 0, epoch = 0;
     unsigned *d_ticket = nullptr, *d_status = nullptr;
     u64 *d_agg = nullptr;
+    float2 *d_part = nullptr;            // k_dc_fold: one aggregate and the first sample per tile
+    uint32_t cus = 256;
     float2 *d_vend[2] = {nullptr, nullptr};
     int cur = 0;
     DcTileArgs proto;
@@ -351,7 +466,7 @@ int dctile_status(DcTilePlan *p, unsigned *status)
 void dctile_destroy(DcTilePlan *p)
 {
     if (!p) return;
-    void *ptrs[] = {p->d_ticket, p->d_status, p->d_agg, p->d_vend[0], p->d_vend[1]};
+    void *ptrs[] = {p->d_ticket, p->d_status, p->d_agg, p->d_part, p->d_vend[0], p->d_vend[1]};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -364,6 +479,8 @@ int dctile_create(const DcParams &dc, uint64_t max_samples, DcTilePlan **out)
 #define ALLOC(ptr, bytes) do { hipError_t e = hipMalloc((void **)&(ptr), (bytes) ? (bytes) : 1); if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc", __FILE__, __LINE__)); } while (0)
     ALLOC(p->d_ticket, sizeof(unsigned)); ALLOC(p->d_status, sizeof(unsigned));
     ALLOC(p->d_agg, sizeof(u64) * 2 * p->max_nb);
+    ALLOC(p->d_part, sizeof(float2) * 2 * (size_t)p->max_nb);      // [nb] tile aggregates | [nb] first samples of the tiles
+    { int dev = 0, cus = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); p->cus = (uint32_t)cus; }
     ALLOC(p->d_vend[0], sizeof(float2)); ALLOC(p->d_vend[1], sizeof(float2));
 #undef ALLOC
     CSDR_HIP(hipMemset(p->d_status, 0, sizeof(unsigned)));
@@ -391,6 +508,35 @@ int dctile_reset(DcTilePlan *p, hipStream_t s)
     return 0;
 }
 
+// DeNo --mix over all M channels, M a multiple of 4096, n a multiple of M: out[n / M] = M x (branch-0 FIR of the DC-blocked,
+// pre-mixed stream); hist_in / hist_out: the p - 1 picked samples before / after the call (different buffers)
+bool dctile_mix_identity_supported(const DcTilePlan *p, uint32_t M, uint32_t n, uint32_t taps_p)
+{
+    static const bool lookback_pick = getenv("CSDR_PICK_LOOKBACK") != nullptr;   // round-2 first version (k_dc_pick_tile + k_branch0_fir) for A/B
+    return !lookback_pick && M && M % 4096u == 0 && n && n % M == 0 && p->proto.beta > 0.f && taps_p >= 1 && taps_p <= 33;
+}
+
+int dctile_mix_identity(DcTilePlan *p, const float2 *x, uint32_t n, const NcoParams &nco, const float2 *nco_tab, const float *taps,
+                        uint32_t M, uint32_t taps_p, const float2 *hist_in, float2 *hist_out, float2 *out, hipStream_t s)
+{
+    DcTileArgs D = p->proto;
+    D.x = x; D.y = nullptr; D.n = n; D.nb = n / 4096u;
+    D.pick = M; D.ypick = nullptr;
+    D.vend_in = p->d_vend[p->cur]; D.vend_out = p->d_vend[p->cur ^ 1];
+    D.nco = nco; D.nco_tab = nco_tab; D.do_mix = 1;
+    const float l2b = (float)std::log2((double)D.beta);
+    uint32_t wgs = p->cus * 4u;                                      // four workgroups of four waves per CU, a tile per wave and round
+    if (wgs > (D.nb + 3) / 4) wgs = (D.nb + 3) / 4;
+    float2 *d_first = p->d_part + (size_t)p->max_nb;
+    const uint32_t nf = n / M;
+    hipLaunchKernelGGL(k_dc_fold, dim3(wgs), dim3(256), 0, s, reinterpret_cast<const float4 *>(x), p->d_part, d_first, D.nb, l2b);
+    hipLaunchKernelGGL(k_mixid_finish, dim3((nf + 255) / 256), dim3(256), 0, s, D, (const float2 *)p->d_part, (const float2 *)d_first, taps,
+                       hist_in, hist_out, out, M, taps_p, nf);
+    CSDR_HIP(hipGetLastError());
+    p->cur ^= 1;
+    return 0;
+}
+
 int dctile_process(DcTilePlan *p, const float2 *x, float2 *y, uint32_t n, bool do_mix, const NcoParams &nco,
                    const float2 *nco_tab, hipStream_t s, uint32_t pick)
 {
@@ -405,7 +551,7 @@ int dctile_process(DcTilePlan *p, const float2 *x, float2 *y, uint32_t n, bool d
     if (pick && pick % 4096u == 0 && n % 4096u == 0 && D.beta > 0.f)
         hipLaunchKernelGGL(k_dc_pick_tile, dim3((D.nb + PICK_T - 1) / PICK_T), dim3(256), 0, s, D, (float)std::log2((double)D.beta));
     else
-    hipLaunchKernelGGL(k_dc_tile, dim3(D.nb), dim3(256), 0, s, D);
+        hipLaunchKernelGGL(k_dc_tile, dim3(D.nb), dim3(256), 0, s, D);
     CSDR_HIP(hipGetLastError());
     p->cur ^= 1;
     return 0;
