@@ -19,6 +19,8 @@ struct FusedCall {
     void *d_out;             // [C][nf] CF32 / F32, or [nf] when mixing
     uint32_t nf;
     uint32_t theta0;         // NCO phase of the first sample
+    float *d_energy = nullptr;   // FM plans, optional: [C][nf] energy words for the AGC mask pass (fused_common.h: agc_energy_word)
+    float agc_alpha = 0.f;
 };
 
 bool fused_supported(uint32_t M, uint32_t p);
@@ -26,6 +28,8 @@ int  fused_create(const FusedConfig &cfg, FusedPlan **out);
 int  fused_reset(FusedPlan *plan, hipStream_t s);
 int  fused_process(FusedPlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
 const char *fused_name(const FusedPlan *plan);
+const float2 *fused_rp_next(const FusedPlan *plan);   // [C] freqdem r' (last Y frame) the NEXT call starts from
+bool fused_whole_band_v2(const FusedPlan *plan);       // large calls take k_run256v2 (energy words are emitted by it and by k_tile256 only)
 void fused_seek(FusedPlan *plan, uint64_t frames);   // after fused_reset: global frame index of the next frame
 // sticky device-side error word (bit0/bit1: an inter-workgroup wait hit its spin limit); reads, then clears it; synchronises
 int  fused_status(FusedPlan *plan, unsigned *status);

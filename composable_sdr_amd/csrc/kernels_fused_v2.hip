@@ -49,7 +49,9 @@ struct V2Args {
     RunArgs r;
 };
 
-template <bool FM>
+// EN (FM only): also emit the energy words of the AGC mask pass.  The extra bases make hipcc spill SGPRs, so this variant's
+// asm stores carry their wait states (fused_v2_common.h); the plain variants stay spill-free and without them.
+template <bool FM, bool EN>
 __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 {
     const RunArgs &RA = VA.r;
@@ -343,10 +345,20 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 #pragma unroll
                     for (int u = 0; u < 4; u++) mq[u] = fm_sample(rp[u], rr[u], k1s);
                 }
+                if (EN) {                                           // AGC mask pass input: energy word of every output sample (same rows, same offsets)
+                    char *ebase = reinterpret_cast<char *>(A.energy) + (size_t)16 * b * 4u;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float ew = agc_energy_word(rr[u], A.agc_alpha);
+                        const char *rowe = ebase + (size_t)XIDX(i + u) * row16;
+                        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(voff), "v"(ew), "s"(rowe) : "memory");
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {                       // stores go out between the quads
                     const char *rowp = obase + (size_t)XIDX(i + u) * row16;
                     if (V2_ABLATE & 2) asm volatile("" :: "v"(mq[u]), "s"(rowp));
+                    else if (EN) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
                     else asm volatile(V2_SNOP "global_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
                 }
             }
@@ -402,16 +414,17 @@ static V2Args make_v2(const void *run_args)
 int run256_v2_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s)
 {
     const V2Args VA = make_v2(run_args);
-    if (fm) hipLaunchKernelGGL(k_run256v2<true>, dim3(nruns), dim3(256), 0, s, VA);
-    else hipLaunchKernelGGL(k_run256v2<false>, dim3(nruns), dim3(256), 0, s, VA);
+    if (fm && VA.r.t.energy) hipLaunchKernelGGL((k_run256v2<true, true>), dim3(nruns), dim3(256), 0, s, VA);
+    else if (fm) hipLaunchKernelGGL((k_run256v2<true, false>), dim3(nruns), dim3(256), 0, s, VA);
+    else hipLaunchKernelGGL((k_run256v2<false, false>), dim3(nruns), dim3(256), 0, s, VA);
     return 0;
 }
 
 int run256_v2_blocks_per_cu(bool fm)
 {
     int occ = 0;
-    if (fm) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run256v2<true>, 256, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run256v2<false>, 256, 0);
+    if (fm) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<true, false>), 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<false, false>), 256, 0);
     return occ < 1 ? 1 : occ;
 }
 

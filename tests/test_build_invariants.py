@@ -31,4 +31,4 @@ def test_run256v2_has_no_register_spills(tmp_path):
         sg = int(re.search(r"SGPRs Spill: (\d+)", b).group(1))
         vg = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         assert sg == 0 and vg == 0, f"k_run256v2 spills (SGPR {sg}, VGPR {vg}): its asm stores have no wait states in front (V2_SNOP)"
-    assert seen == 2                                     # <FM> and <CF32>
+    assert seen == 3                                     # <FM>, <FM, energy words> and <CF32>
