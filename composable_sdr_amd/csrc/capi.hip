@@ -1022,7 +1022,7 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
             if (n_out) *n_out = h->C * nf;
             return CSDR_OK;
         }
-        if (h->small) { if ((r = small_process(h->small, fcall, s, &h->timer))) return r; }
+        if (h->small) { if ((r = small_process(h->small, fcall, s, &h->timer))) return r; h->timed_kernel = small_name(h->small); }   // k_run64v2 or k_run64, by call
         else if (h->big) { if ((r = big_process(h->big, fcall, s, &h->timer))) return r; h->timed_kernel = big_name(h->big); }   // k_run1024v2 or k_run1024, by call
         else if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
         h->theta += n_in * h->d_theta;

@@ -63,6 +63,18 @@ void big_seek(BigPlan *plan, uint64_t frames);
 const char *big_name(const BigPlan *plan);
 void big_destroy(BigPlan *plan);
 
+// k_run64v2 (kernels_run64_v2.hip): whole-band M = 64 calls with CF32 output and nf % 64 == 0; same state buffers as k_run64
+struct Run64v2Host {
+    const float2 *x; float2 *out;
+    const float *taps; const float2 *tw, *wpre;
+    const float2 *uhist_in; float2 *uhist_out; const float2 *vend_in; float2 *vend_out;
+    uint32_t nf, nruns, parity0;
+    bool dc_block;
+    double beta;
+};
+uint32_t run64_v2_runs(uint32_t nf, uint32_t cus);      // 0: not a call for the kernel
+int run64_v2_launch(const Run64v2Host &h, hipStream_t s, KernelTimer *timer);
+
 // k_run1024v2 (kernels_run1024_v2.hip): whole-band M = 1024 calls with nf % 4 == 0; same state buffers as k_run1024
 struct Run1024v2Host {
     const float2 *x; void *out;

@@ -337,7 +337,8 @@ __global__ __launch_bounds__(64) void k_run64_fixup(const float2 *__restrict__ y
 // ---------------------------------------------------------------------------------------------
 struct SmallPlan {
     FusedConfig cfg;
-    uint32_t max_nb = 0, resident_wgs = 768;
+    uint32_t max_nb = 0, resident_wgs = 768, cus = 256;
+    bool v2_ok = false, v2_last = false;     // k_run64v2 usable (CF32, whole band); used by the last call
     uint64_t frames_done = 0;
     float *d_taps = nullptr;
     float2 *d_tw = nullptr, *d_wpre = nullptr;
@@ -410,6 +411,8 @@ int small_create(const FusedConfig &cfg, SmallPlan **out)
         else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run64<false>, 256, 0);
         if (occ < 1) occ = 1;
         p->resident_wgs = (uint32_t)(cus * occ);
+        p->cus = (uint32_t)cus;
+        p->v2_ok = !cfg.fm && cfg.c0 == 0 && cfg.C == (uint32_t)MS && !getenv("CSDR_RUN64_V1");
     }
     *out = p;
     return 0;
@@ -434,6 +437,24 @@ int small_process(SmallPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     const uint32_t nf = call.nf;
     if (!nf) return 0;
     int r;
+    const uint32_t v2runs = (p->v2_ok && (uint64_t)c.C * nf * 8u < (1ull << 32)) ? run64_v2_runs(nf, p->cus) : 0;
+    p->v2_last = v2runs != 0;
+    if (v2runs) {
+        Run64v2Host H{};
+        H.x = call.d_in; H.out = (float2 *)(c.mix ? p->d_premix : call.d_out);
+        H.taps = p->d_taps; H.tw = p->d_tw; H.wpre = p->d_wpre;
+        H.uhist_in = p->d_yhist[p->cur]; H.uhist_out = p->d_yhist[p->cur ^ 1];
+        H.vend_in = p->d_vend[p->cur]; H.vend_out = p->d_vend[p->cur ^ 1];
+        H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
+        H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0;
+        if ((r = run64_v2_launch(H, s, timer))) return r;
+        p->cur ^= 1;
+        p->frames_done += nf;
+        if (c.mix) {
+            if ((r = launch_mix((const float *)p->d_premix, (float *)call.d_out, c.C, 2 * nf, s))) return r;
+        }
+        return 0;
+    }
     SmallArgs SA{};
     TileArgs &A = SA.t;
     A = p->proto;
@@ -467,6 +488,6 @@ int small_process(SmallPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     return 0;
 }
 
-const char *small_name(const SmallPlan *p) { return p->cfg.fm ? "k_run64<FM>" : "k_run64<CF32>"; }
+const char *small_name(const SmallPlan *p) { return p->cfg.fm ? "k_run64<FM>" : (p->v2_last ? "k_run64v2" : "k_run64<CF32>"); }
 
 }  // namespace csdr

@@ -730,6 +730,35 @@ def test_full_size_cfg3_linearity_and_kernel_agreement(monkeypatch):
     assert int(p.argmax()) == k and float(iso) > 75 and abs(float(p[k]) / M - 1) < 0.02
 
 
+def test_run64_v2_matches_first_generation_kernel_and_oracle(monkeypatch):
+    """k_run64v2 (CF32, whole band, nf % 64 == 0: DMA'd tiles, in-place passes, wave-local DFT) against k_run64
+    (CSDR_RUN64_V1) and the oracle: an odd call first (first-generation kernel: odd NCO parity, non-trivial DC state and window),
+    then 8192 frames (8 runs with warm-up and halo), a ragged call (first generation again), and 2048 more."""
+    M = 64
+    frames = [5, 8192, 70, 2048]
+    x = synth_cf32(M * sum(frames), M, seed=64)
+    x = (x + np.complex64(0.05 - 0.02j)).astype(np.complex64)
+    kw = dict(channels=M, demod="none", max_frames=max(frames))
+    a = cs.Chain(**kw)
+    monkeypatch.setenv("CSDR_RUN64_V1", "1")
+    b = cs.Chain(**kw)
+    monkeypatch.delenv("CSDR_RUN64_V1")
+    orc = O.Chain(M, demod="none")
+    ga, gb, wo, pos, names = [], [], [], 0, []
+    for f in frames:
+        xa = x[pos * M:(pos + f) * M]; pos += f
+        ga.append(a.process(xa)); gb.append(b.process(xa)); wo.append(orc.process(xa))
+        names.append((a.kernel_time()[0], b.kernel_time()[0]))
+    print("kernels:", names)
+    assert names[0][0] == "k_run64<CF32>" and names[1][0] == "k_run64v2" and names[2][0] == "k_run64<CF32>" and names[3][0] == "k_run64v2"
+    assert all(n[1] == "k_run64<CF32>" for n in names)
+    ga, gb, wo = [np.concatenate(v, axis=1) for v in (ga, gb, wo)]
+    print(f"run64v2: vs v1 {rel_rms(ga, gb):.2e}, vs oracle {rel_rms(ga, wo):.2e}; last call vs oracle {rel_rms(ga[:, -2048:], wo[:, -2048:]):.2e}")
+    assert rel_rms(ga, gb) < 2e-6 and rel_rms(ga, wo) < 1e-5
+    assert rel_rms(ga[:, 5:5 + 64], wo[:, 5:5 + 64]) < 1e-5 and rel_rms(ga[:, -64:], wo[:, -64:]) < 1e-5
+    a.close(); b.close()
+
+
 def test_full_size_cfg2_64ch_chunk_invariance():
     """configs[1] size (64 ch, 1 048 576 frames): one chunk == 16 chunks (state carry), DeNo."""
     import torch
