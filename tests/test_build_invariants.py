@@ -32,3 +32,10 @@ def test_run256v2_has_no_register_spills(tmp_path):
         vg = int(re.search(r"VGPRs Spill: (\d+)", b).group(1))
         assert sg == 0 and vg == 0, f"k_run256v2 spills (SGPR {sg}, VGPR {vg}): its asm stores have no wait states in front (V2_SNOP)"
     assert seen == 3                                     # <FM>, <FM, energy words> and <CF32>
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", os.path.join(src, "kernels_run64_v2.hip"),
+                          "-o", str(tmp_path / "r64.o"), "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    b = [x for x in re.split(r"remark: Function Name: ", out.stderr)[1:] if "k_run64v2" in x.splitlines()[0]]
+    assert len(b) == 1
+    assert int(re.search(r"SGPRs Spill: (\d+)", b[0]).group(1)) == 0 and int(re.search(r"VGPRs Spill: (\d+)", b[0]).group(1)) == 0
