@@ -12,7 +12,7 @@
 //     of an LDS image that the tile was DMA'd into (global_load_lds: no VGPR staging, no ds_write), freqdem uses literal
 //     coefficients and SGPR-mask selects, and the FIR window changes hands by register renaming (two tiles per loop
 //     iteration) instead of moves.
-//   * barriers: 5 per tile instead of 10-12.  Pass 2 of the DFT runs with the frame index in the low four lane bits, so
+//   * barriers: 4 per tile instead of 10-12.  Pass 2 of the DFT runs with the frame index in the low four lane bits, so
 //     the previous frame of a channel is one DPP row shift away and a 16-lane row writes 64 (F32) / 128 (CF32)
 //     contiguous bytes of a channel row: no transpose of Y or of the demodulated samples through LDS at all.
 //   * two workgroups per CU (70 KiB of LDS each), up to 256 VGPRs: taps and pass-1 twiddles live in registers.
@@ -28,6 +28,9 @@
 #define V2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem, 8 one FIR tap
 #endif
 
+#ifndef V2_BAR_E
+#define V2_BAR_E 0      // 1: the (redundant) barrier between the X reads and the Z writes of pass 1, for A/B
+#endif
 #ifndef V2_SNOP
 // Wait states in front of the asm stores would cover a scalar base that comes straight out of a spill lane (v_readlane ->
 // VMEM hazard, fused_v2_common.h); they cost 1 % of the launch, and this kernel has no SGPR spills (the bases are SALU
@@ -308,7 +311,9 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 #pragma unroll
         for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + b1]));
         V2STAMP(7);
-        bar();                                          // B_e: everyone has read X
+        // no barrier here: Z[f1] goes into frame f1's own 2 KiB of the buffer, which only the 16 lanes that have just read
+        // X[f1] (same wave, program order) ever touched since B_d
+        if (V2_BAR_E) bar();
         V2STAMP(8);
 #pragma unroll
         for (int i = 0; i < 16; i++) *reinterpret_cast<float2 *>(B + zw_a + 128 * XIDX(i)) = to_f2(vv[i]);
