@@ -759,6 +759,35 @@ def test_run64_v2_matches_first_generation_kernel_and_oracle(monkeypatch):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("M,demod,env,frames,extra", [
+    (64, "none", "CSDR_RUN64_V1", [8192, 2048], {}),
+    (64, "none", "CSDR_RUN64_V1", [8192], {"mix": True}),
+    (1024, "fm", "CSDR_RUN1024_V1", [4096], {}),
+    (256, "fm", "CSDR_RUN_V1", [40000], {}),
+])
+def test_second_generation_run_kernels_without_dc_blocker(M, demod, env, frames, extra, monkeypatch):
+    """dc_block = False (alpha = 0, beta = 0 inside the kernels) and DeNo --mix through k_run64v2 / k_run1024v2 / k_run256v2
+    against the first-generation kernels: without the DC scan's approximated run-start state the CF32 results are bitwise
+    those of k_run64 (same FIR order, same DFT butterflies)."""
+    x = synth_cf32(M * sum(frames), M, seed=3)
+    kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames), dc_block=False, **extra)
+    a = cs.Chain(**kw)
+    monkeypatch.setenv(env, "1")
+    b = cs.Chain(**kw)
+    monkeypatch.delenv(env)
+    pos = 0
+    for f in frames:
+        xa = x[pos * M:(pos + f) * M]; pos += f
+        ga, gb = a.process(xa), b.process(xa)
+        assert "v2" in a.kernel_time()[0] and "v2" not in b.kernel_time()[0]
+        if demod == "fm":
+            d = np.abs(ga.astype(np.float64) - gb); d = np.minimum(d, np.abs(d - 1 / 0.3))
+            assert np.median(d) < 1e-6 and np.quantile(d, 0.999) < 5e-5
+        else:
+            assert rel_rms(ga, gb) < 1e-6
+    a.close(); b.close()
+
+
 def test_full_size_cfg2_64ch_chunk_invariance():
     """configs[1] size (64 ch, 1 048 576 frames): one chunk == 16 chunks (state carry), DeNo."""
     import torch
