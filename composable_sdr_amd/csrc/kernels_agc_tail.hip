@@ -27,7 +27,7 @@
 #include "agc_common.h"
 #include <cstdlib>
 #ifndef CSDR_AGC_ABLATE
-#define CSDR_AGC_ABLATE 0      // timing experiments only: 1 no log/exp, 2 every block reloads the same (cached) lines, 4 no stores, 16 no compute
+#define CSDR_AGC_ABLATE 0      // timing experiments only: 1 no log/exp, 2 every block reloads the same (cached) lines, 4 no stores, 16 no compute, 32 mover skips the ring writes, 64 no barrier
 #endif
 
 namespace csdr {
@@ -350,13 +350,18 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec(TailArgs A, uint32_t groups
     auto iteration = [&](uint32_t it, float4 (&ld)[8]) {       // ld holds block it (mover)
         if (mover) {
             if (it < nblk) {
+                if (CSDR_AGC_ABLATE & 32) {
 #pragma unroll
-                for (int m = 0; m < 8; m++) ring[s_in][slot8(8 * m + (lane >> 3), pc)] = ld[m];
+                    for (int m = 0; m < 8; m++) { const float t0 = ld[m].x, t1 = ld[m].w; asm volatile("" :: "v"(t0), "v"(t1)); }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 8; m++) ring[s_in][slot8(8 * m + (lane >> 3), pc)] = ld[m];
+                }
                 if (it + 2 < nblk) fetch(it + 2, ld);
             }
             if (it >= 2 && it - 2 >= kreal && it - 2 < nblk) store_block(it - 2, ring[s_out]);
         } else if (it >= 1 && it - 1 < nblk) work_block(it - 1, ring[s_wk]);
-        lds_barrier();
+        if (!(CSDR_AGC_ABLATE & 64)) lds_barrier();
         s_out = s_wk; s_wk = s_in; s_in = s_in == 2 ? 0 : s_in + 1;
     };
     for (uint32_t it = 0; it < nblk + 2; it += 2) {
