@@ -684,7 +684,8 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     h->max_nf = cfg->max_frames ? cfg->max_frames : 4096;
     h->max_nx = (uint64_t)h->max_nf * M;
     if (h->max_nx > 0xffffffffull) { set_error("chain: max_frames*channels exceeds 2^32-1 samples"); delete h; return CSDR_ERR_INVALID; }
-    h->timer.enabled = (cfg->flags & CSDR_FLAG_TIME_KERNELS) != 0;
+    h->timer.enabled = (cfg->flags & (CSDR_FLAG_TIME_KERNELS | CSDR_FLAG_TIME_REGION)) != 0;
+    h->timer.region = (cfg->flags & CSDR_FLAG_TIME_REGION) != 0;
     if (cfg->dc_block) h->dc = make_dc(cfg->dc_alpha);
     if (cfg->agc_threshold_db != 0.0f) h->agc = make_agc(cfg->agc_threshold_db);
     if (cfg->demod == CSDR_DEMOD_FM) h->fm_ref = fm_ref_of(cfg->kf);
@@ -1014,7 +1015,11 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         FusedCall fcall{};
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         if (h->agc_mask) {
-            const float2 *rp_prev = fused_rp_next(h->fused);     // the last channelizer frame of the call before this one
+            // the last channelizer frame of the call before this one.  Snapshot it: a run-sized call with a ragged tail flips the
+            // plan's ping-pong twice, so the k_tile256 tail launch writes the very buffer fused_rp_next() names now (the chain's own
+            // d_rp pair is idle on this route: the fused plan keeps the freqdem history)
+            CSDR_HIP(hipMemcpyAsync(h->d_rp[0], fused_rp_next(h->fused), sizeof(float2) * h->C, hipMemcpyDeviceToDevice, s));
+            const float2 *rp_prev = h->d_rp[0];
             fcall.d_out = d_out; fcall.d_energy = reinterpret_cast<float *>(h->d_A); fcall.agc_alpha = h->agc.alpha;
             if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
             h->theta += n_in * h->d_theta;

@@ -170,8 +170,21 @@ struct KernelTimer {
     size_t used = 0;
     double acc_ms = 0.0; uint32_t launches = 0;
     bool enabled = false;
+    // region mode (CSDR_FLAG_TIME_REGION): ONE event in front of the first timed launch and one behind the last, recorded when the
+    // total is read; total / launches = the launch cadence of back-to-back calls (kernel + the gap to the next one).  A pair of
+    // events around every launch costs the stream 10-20 us per launch on this runtime, which the per-launch mode pays and reports.
+    bool region = false, open = false;
+    hipEvent_t r0 = nullptr, r1 = nullptr; hipStream_t last = nullptr; uint32_t pending = 0;
     int begin(hipStream_t s) {
         if (!enabled) return 0;
+        if (region) {
+            if (!open) {
+                if (!r0) { CSDR_HIP(hipEventCreate(&r0)); CSDR_HIP(hipEventCreate(&r1)); }
+                CSDR_HIP(hipEventRecord(r0, s));
+                open = true; pending = 0;
+            }
+            return 0;
+        }
         if (used + 2 > ev.size()) {
             if (ev.size() >= 4096) { int r = drain(); if (r) return r; }
             else for (int i = 0; i < 2; i++) { hipEvent_t e; CSDR_HIP(hipEventCreate(&e)); ev.push_back(e); }
@@ -181,11 +194,23 @@ struct KernelTimer {
     }
     int end(hipStream_t s) {
         if (!enabled) return 0;
+        if (region) { last = s; pending++; return 0; }
         CSDR_HIP(hipEventRecord(ev[used + 1], s));
         used += 2;
         return 0;
     }
     int drain() {
+        if (region) {
+            if (open && pending) {
+                CSDR_HIP(hipEventRecord(r1, last));
+                CSDR_HIP(hipEventSynchronize(r1));
+                float ms = 0.f;
+                CSDR_HIP(hipEventElapsedTime(&ms, r0, r1));
+                acc_ms += ms; launches += pending;
+            }
+            open = false; pending = 0;
+            return 0;
+        }
         for (size_t i = 0; i + 1 < used; i += 2) {
             CSDR_HIP(hipEventSynchronize(ev[i + 1]));
             float ms = 0.f;
@@ -195,7 +220,7 @@ struct KernelTimer {
         used = 0;
         return 0;
     }
-    void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); used = 0; }
+    void destroy() { for (auto e : ev) (void)hipEventDestroy(e); ev.clear(); used = 0; if (r0) { (void)hipEventDestroy(r0); (void)hipEventDestroy(r1); r0 = r1 = nullptr; } open = false; }
 };
 
 // ---- fused kernels (kernels_fused.hip) --------------------------------------

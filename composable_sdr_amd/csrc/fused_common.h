@@ -302,6 +302,7 @@ __device__ __forceinline__ void tile_load(const float4 *__restrict__ src, int va
     }
 }
 
+__device__ __forceinline__ float2 scan_staged(float2 *R, float2 *E, float2 *T, const TileArgs &A, int tid);
 // Registers -> LDS, then the zero-state DC scan of the tile.  On return R holds
 // z[n] = x[n] - alpha*s[n-1] (s = scan inside the 16-sample run), E[q] the carry into run q from
 // earlier runs of its frame, T[f] the frame totals.  Ends with a barrier.
@@ -313,7 +314,14 @@ __device__ __forceinline__ float2 stage_and_scan(const float4 (&raw)[8], float2 
 #pragma unroll
     for (int it = 0; it < 8; it++) R4[64 * (it * 4 + wave) + lane] = raw[it];
     __syncthreads();
+    return scan_staged(R, E, T, A, tid);
+}
 
+// The same scan on a raw tile image that is already in LDS (k_run256v2 DMA's the halo tile of a run straight into it; the
+// caller has waited for the DMA and synchronised).  Ends with a barrier.
+__device__ __forceinline__ float2 scan_staged(float2 *R, float2 *E, float2 *T, const TileArgs &A, int tid)
+{
+    float4 *R4 = reinterpret_cast<float4 *>(R);
     const int q = tid, sw = (q >> 1) & 7;
     float2 s = make_float2(0.f, 0.f);
     const float na = -A.alpha, be = A.beta;
@@ -385,6 +393,7 @@ struct RunArgs {
     float l2beta;               // log2(beta)
     uint32_t prio_div;          // > 0: rotate the wave priority per tile; CU slot of a run = blockIdx / prio_div
     uint32_t trace_light;       // CSDR_TRACE=2: only per-run s_memrealtime stamps (entry / warm-up / halo / end)
+    uint32_t wu, wu_rot;        // k_run256v2: read-only warm-up tiles in front of a run's halo tile (WU = 6); runs walk them in rotated order
 };
 
 __device__ __forceinline__ float2 wg_sum(float2 v, float2 *red, int tid)

@@ -857,6 +857,8 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         RA.split = make_split(A.nb, nruns, p->cus, (v2 && !getenv("CSDR_RUN_WEIGHTS")) ? v2_weight : p->slot_weight);
         { const char *e = getenv("CSDR_PRIO_ROT"); RA.prio_div = e ? (atoi(e) ? p->cus : 0u) : (v2 ? 0u : p->cus); }
         { const char *e = getenv("CSDR_TRACE"); RA.trace_light = (e && atoi(e) == 2) ? 1u : 0u; }
+        { const char *e = getenv("CSDR_WU"); RA.wu = e ? (uint32_t)atoi(e) : (uint32_t)WU; }       // experiments: fewer tiles = wrong DC state at run starts
+        { const char *e = getenv("CSDR_WU_ROT"); RA.wu_rot = e ? (uint32_t)atoi(e) : 1u; }
         RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;
         if (timer && (r = timer->begin(s))) return r;
         static const size_t extra_lds = getenv("CSDR_EXTRA_LDS") ? (size_t)atol(getenv("CSDR_EXTRA_LDS")) : 0;   // occupancy experiments

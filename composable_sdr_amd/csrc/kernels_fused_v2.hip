@@ -62,16 +62,29 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     __shared__ __attribute__((aligned(16))) float2 L[V2_F2];
     float2 *R = L, *ST = L + V2_STASH, *Tt = ST + 256, *red = Tt + 16;
     float2 *tw_s = red + 16;
-    float2 *E = L + V2_BUF;                             // run start only: 256 run carries
+    float2 *H = L + V2_BUF;                             // run start only: the halo tile's image, then scratch of the one-frame DFT (buffer 1 is free until the first tile's B_a)
+    float2 *E = ST;                                     // run start only: 256 run carries (the stash area, before the stash is initialised)
     const int tid = threadIdx.x, j = tid;
     const unsigned w = blockIdx.x;
     unsigned first, last;
     run_range(RA.split, w, first, last);
     const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
+    const unsigned goff = dma_offset(tid);
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)R + 1024u * wave_u;
 
 #define V2LSTAMP(i) do { if (A.trace && RA.trace_light && tid == 0) A.trace[(size_t)first * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     V2LSTAMP(0);
+    // Everything the run start waits for is requested up front, so that the prologue is one burst of memory traffic and not
+    // a chain of round trips: the first tile (buffer 0) and the halo tile (buffer 1) by DMA, the table values as plain loads.
+    if (first < last) dma_tile(x4 + (size_t)first * 2048, goff, lds_wave);
+    if (w > 0) dma_tile(x4 + (size_t)(first - 1) * 2048, goff, lds_wave + (unsigned)(V2_BUF * 8));
+    float h[P];
+#pragma unroll
+    for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j) + n * M256];
+    const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
+    tw_s[tid] = A.tw[tid];
     float2 wa[NB], wb[NB];                              // FIR window halves: one holds the previous tile, the other the new one
 #pragma unroll
     for (int f = 0; f < NB; f++) { wa[f] = make_float2(0.f, 0.f); wb[f] = make_float2(0.f, 0.f); }
@@ -85,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         for (int f = 3; f < NB; f++) wa[f] = A.yhist_in[(f - 3) * M256 + j];
     } else {
         const unsigned halo = first - 1;
-        const unsigned h0 = halo > (unsigned)WU ? halo - WU : 0u;
+        const unsigned h0 = halo > RA.wu ? halo - RA.wu : 0u, nwu = halo - h0;
         float4 raw[8];
         float w0[8], w1[8];
         {
@@ -99,39 +112,46 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                 w1[it] = exp2f((float)(4094 - n) * RA.l2beta);
             }
         }
+        // zero-state aggregate of the warm-up tiles: sum over tiles of beta^(4096 (halo - 1 - t)) x (weighted sum inside tile t),
+        // order-free, so that run w may start at tile (w mod nwu) of its window: 512 runs that walk their windows in the same order
+        // hit the HBM channels in lockstep
         float2 acc = make_float2(0.f, 0.f);
-        auto fold = [&](const float4 (&r)[8]) {
+        auto fold = [&](const float4 (&r)[8], unsigned t) {
             float2 p = make_float2(0.f, 0.f);
 #pragma unroll
             for (int it = 0; it < 8; it++) {
                 p = cfma(make_float2(r[it].x, r[it].y), w0[it], p);
                 p = cfma(make_float2(r[it].z, r[it].w), w1[it], p);
             }
-            acc = cfma(acc, A.b256[16], p);
+            acc = cfma(p, exp2f((float)(4096u * (halo - 1u - t)) * RA.l2beta), acc);
         };
-        unsigned t = h0;
-        if (halo - h0 == (unsigned)WU) {
+        const unsigned rot = RA.wu_rot ? w : 0u;
+        unsigned i = 0;
+        if (nwu >= 3) {
             float4 rb[8], rc[8];
 #pragma unroll 1
-            for (int half = 0; half < 2; half++, t += 3) {
-                tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
-                tile_load(x4 + (size_t)(t + 1) * 2048, 256, rb, tid);
-                tile_load(x4 + (size_t)(t + 2) * 2048, 256, rc, tid);
-                fold(raw); fold(rb); fold(rc);
+            for (; i + 3 <= nwu; i += 3) {
+                const unsigned t0 = h0 + (i + rot) % nwu, t1 = h0 + (i + 1 + rot) % nwu, t2 = h0 + (i + 2 + rot) % nwu;
+                tile_load(x4 + (size_t)t0 * 2048, 256, raw, tid);
+                tile_load(x4 + (size_t)t1 * 2048, 256, rb, tid);
+                tile_load(x4 + (size_t)t2 * 2048, 256, rc, tid);
+                fold(raw, t0); fold(rb, t1); fold(rc, t2);
             }
         }
-        for (; t < halo; t++) {
-            tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
-            fold(raw);
+        for (; i < nwu; i++) {
+            const unsigned t0 = h0 + (i + rot) % nwu;
+            tile_load(x4 + (size_t)t0 * 2048, 256, raw, tid);
+            fold(raw, t0);
         }
         float2 ch = wg_sum(acc, red, tid);
         V2LSTAMP(1);
         if (h0 == 0) ch = cfma(A.vend_in[0], exp2f((float)(4096u * halo) * RA.l2beta), ch);
-        tile_load(x4 + (size_t)halo * 2048, 256, raw, tid);
-        stage_and_scan(raw, R, E, Tt, A, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the two DMA'd tiles (older than every warm-up load)
+        __syncthreads();
+        scan_staged(H, E, Tt, A, tid);
 #pragma unroll
-        for (int f = 3; f < NB; f++) wa[f] = R[256 * f + col_off];
-        w2 = R[256 * 2 + col_off];                      // FM: the 14th tap of the halo tile's last frame (freqdem history of the run)
+        for (int f = 3; f < NB; f++) wa[f] = H[256 * f + col_off];
+        w2 = H[256 * 2 + col_off];                      // FM: the 14th tap of the halo tile's last frame (freqdem history of the run)
         const float kj = -A.alpha * A.bj[j & 15];
         const float br = A.b16[tid & 15], bf = A.b256[tid >> 4];
         float2 vb, ve;
@@ -143,12 +163,12 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         for (int f = 3; f < NB; f++) wa[f] = cfma(E[16 * f + (j >> 4)], kj, wa[f]);
         w2 = cfma(E[16 * 2 + (j >> 4)], kj, w2);
     }
-    const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
 #pragma unroll
     for (int f = 3; f < NB; f++) wa[f] = cmul(wa[f], (f & 1) ? Wb : Wa);       // the window holds pre-mixed samples
+    __syncthreads();                                    // every thread has read its run carries out of the stash area
     // freqdem history: stash[k1][i] = last Y frame of channel k1 + 16 XIDX(i)
     ST[(tid & 15) * 16 + XIDX(tid >> 4)] = (FM && w == 0) ? A.rp_in[tid] : make_float2(0.f, 0.f);
-    __syncthreads();                                    // R, E free; stash visible
+    __syncthreads();                                    // H free; stash and twiddles visible
     if (FM && w > 0) {
         // The run's first freqdem sample needs the frame in front of it: the halo tile's last frame goes through the FIR and
         // a one-frame DFT here (same arithmetic as the tile loop: pass 1 thread b1, pass 2 thread k1), instead of a fix-up
@@ -157,26 +177,25 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         v2f acc = {0.f, 0.f};
 #pragma unroll
         for (int n = P - 1; n >= 0; n--) {
-            const float hn = A.taps[(M256 - 1 - j) + n * M256];
             const float2 s2 = (n == P - 1) ? w2 : wa[NB - 1 - n];
-            acc = __builtin_elementwise_fma((v2f){s2.x, s2.y}, (v2f){hn, hn}, acc);
+            acc = __builtin_elementwise_fma((v2f){s2.x, s2.y}, (v2f){h[n], h[n]}, acc);
         }
-        R[j] = to_f2(acc);
+        H[j] = to_f2(acc);
         __syncthreads();
         v2f vv[16];
         if (tid < 16) {
 #pragma unroll
-            for (int a = 0; a < 16; a++) vv[a] = to_v(R[16 * a + tid]);
+            for (int a = 0; a < 16; a++) vv[a] = to_v(H[16 * a + tid]);
             fft16_v(vv);
 #pragma unroll
-            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(A.tw[16 * XIDX(i) + tid]));
+            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + tid]));
 #pragma unroll
-            for (int i = 0; i < 16; i++) E[16 * XIDX(i) + tid] = to_f2(vv[i]);     // Z[k1][b1]
+            for (int i = 0; i < 16; i++) H[256 + 16 * XIDX(i) + tid] = to_f2(vv[i]);     // Z[k1][b1]
         }
         __syncthreads();
         if (tid < 16) {
 #pragma unroll
-            for (int b = 0; b < 16; b++) vv[b] = to_v(E[16 * tid + b]);
+            for (int b = 0; b < 16; b++) vv[b] = to_v(H[256 + 16 * tid + b]);
             fft16_v(vv);                                // vv[i] = Y[tid + 16 XIDX(i)]
 #pragma unroll
             for (int i = 0; i < 16; i++) ST[tid * 16 + i] = to_f2(vv[i]);
@@ -185,10 +204,6 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     }
 
     // ------------------------------------------------------------------ per-thread constants of the tile loop
-    float h[P];
-    tw_s[tid] = A.tw[tid];
-#pragma unroll
-    for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j) + n * M256];
     const v2f Wav = to_v(Wa), Wbv = to_v(Wb);
     const float na = opaque_v(-A.alpha), be = opaque_v(A.beta);
     const float kJ = -A.alpha * exp2f((float)j * RA.l2beta);                    // -alpha beta^j: frame state into column j
@@ -196,9 +211,6 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const FmK2 fk = {{opaque_v(9.999993443e-01f), opaque_v(-3.332985938e-01f), opaque_v(1.994656026e-01f), opaque_v(-1.390860826e-01f),
                       opaque_v(9.642146528e-02f), opaque_v(-5.591168255e-02f), opaque_v(2.186254039e-02f), opaque_v(-4.054457881e-03f)},
                      opaque_v(1e-37f), opaque_v(A.fm_ref), opaque_v(RA.pk.hp), opaque_v(RA.pk.pi)};
-    const unsigned goff = dma_offset(tid);
-    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)R + 1024u * wave_u;
     // LDS byte offsets inside a tile buffer that do not change from tile to tile
     const int q = tid, sw = (q >> 1) & 7;
     const unsigned raw_a = (unsigned)q * 128u + ((unsigned)sw << 4);            // slot i of my run: raw_a ^ (i << 4)
@@ -388,8 +400,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     };
 
     V2LSTAMP(2);
-    if (first < last) dma_tile(x4 + (size_t)first * 2048, goff, lds_wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the first tile was requested at the kernel's entry
     V2LSTAMP(3);
     for (unsigned b = first; b < last; b += 2) {
         tile(wa, wb, b, 0);

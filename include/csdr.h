@@ -66,6 +66,13 @@ extern "C" {
                                         * DC blocker on the whole stream and the FIR of polyphase branch 0 only.  Set this flag
                                         * to run the full bank + DFT + channel sum instead (same result to f32 rounding).      */
 
+#define CSDR_FLAG_TIME_REGION 32u   /* time the dominant kernel over a REGION instead of per launch: one hipEvent in front of the
+                                     * first timed launch after the last csdr_chain_kernel_time() and one behind the last, recorded
+                                     * when the total is read.  total / launches is then the launch cadence of back-to-back calls
+                                     * (kernel + the gap to the next launch); it includes whatever else the call puts on the stream
+                                     * between two timed launches, so it is a per-kernel figure only for one-kernel steps.  Per-launch
+                                     * event pairs (CSDR_FLAG_TIME_KERNELS alone) cost the stream 10-20 us per launch.           */
+
 const char *csdr_last_error(void);
 int  csdr_device_count(void);
 /* library / build identification: "csdr-hip gfx950 <version>" */

@@ -1348,7 +1348,7 @@ def test_agc_fm_mask_route_same_mute_decisions_as_exact_route(monkeypatch):
     gains, same squelch states), the samples next to a muted one (0 or ref*pi) identical, un-muted samples equal to the
     rounding of an algebraically identical expression."""
     M = 256
-    frames = [4096, 33, 40000, 17]
+    frames = [4096, 33, 40000, 40001, 17]     # 40001: a run-sized call with a ragged tail (run kernel + k_tile256 tail in one call)
     x = synth_cf32(M * sum(frames), M, seed=11)
     kw = dict(channels=M, demod="fm", kf=0.3, agc=10.0, max_frames=max(frames))
     monkeypatch.setenv("CSDR_AGC_FM_MASK", "1")
@@ -1454,3 +1454,102 @@ def test_full_size_cfg5_shape_4096ch_mix_linearity():
     inv = float((run(x1, parts=4) - y1).abs().max())
     print("cfg5 shape mix: linearity err", err, "chunk-invariance err", inv, "of", scale)
     assert err < 1e-4 * scale and inv < 1e-4 * scale
+
+
+# --------------------------------------------------------------------------- the oracle at the BENCHMARKED layouts
+# One whole bench-sized chunk (67 M samples: 512 runs with warm-up, halo and run-start frames; the 1.2 : 0.8 tile shares)
+# through the product path, device-resident like bench.py, against the oracle on the same samples.  The oracle runs at
+# ~20 MS/s on the GPU box: 3-10 s per call.
+
+
+def _bench_layout(M, nf, seed, **kw):
+    import torch
+    from synth import synth_cf32_torch
+    dev = torch.device("cuda", 0)
+    x = synth_cf32_torch(M * nf, M, dev, seed=seed)
+    ch = cs.Chain(channels=M, max_frames=nf, flags=kw.pop("flags", 4) | 1, **kw)
+    fm, mix = kw.get("demod", "none") == "fm", kw.get("mix", False)
+    n_out = (nf if mix else M * nf) * (1 if fm else 2)
+    out = torch.empty(n_out, dtype=torch.float32, device=dev)
+    ch.process_device(x.data_ptr(), M * nf, out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    kname, path = ch.kernel_time()[0], ch.path
+    ch.close()
+    got = out.cpu().numpy()
+    got = got if fm else got.view(np.complex64)
+    got = got.reshape(-1) if mix else got.reshape(M, nf)
+    xh = x.cpu().numpy().view(np.complex64).reshape(-1)
+    del x, out
+    torch.cuda.empty_cache()
+    return got, xh, kname, path
+
+
+def _fm_against_oracle(got, xh, M, kf, label):
+    """The tolerances of test_chain_fm_matches_oracle on a whole bench-sized chunk."""
+    ref = 1.0 / (2 * np.pi * kf)
+    want = O.Chain(M, demod="fm", kf=kf).process(xh)
+    r = np.abs(O.Chain(M).process(xh))
+    assert got.shape == want.shape == r.shape
+    rmax = float(r.max())
+    worst_w, worst_s, med = 0.0, 0.0, []
+    for k0 in range(0, M, 32):                           # by blocks of rows: the f64 temporaries of a whole chunk would be 2 GiB
+        sl = slice(k0, k0 + 32)
+        d = np.abs(wrap_pm(got[sl].astype(np.float64) - want[sl], 1.0 / kf))
+        rr = r[sl]
+        rmin = np.minimum(rr, np.concatenate([np.zeros((rr.shape[0], 1), rr.dtype), rr[:, :-1]], axis=1))
+        worst_w = max(worst_w, float((d * rmin).max()) / rmax)
+        strong = rmin > 0.25 * rmax
+        if strong.any():
+            worst_s = max(worst_s, float(d[strong].max()))
+        med.append(float(np.median(d)))
+    print(f"{label}: whole chunk vs oracle: median {np.median(med):.3e}, weighted max {worst_w:.3e} (tol {2 * ref * 1e-4:.3e}), strong-sample max {worst_s:.3e}")
+    assert worst_w < 2 * ref * 1e-4
+    assert max(med) < 2e-5
+    assert worst_s < 2e-5
+
+
+def test_bench_layout_cfg3_256ch_fm_whole_chunk_matches_oracle():
+    """k_run256v2<FM> at 256 x 262 144 (BASELINE configs[2] shape as bench.py runs it) against O.Chain, every sample."""
+    M, nf, kf = 256, 262144, 0.3
+    got, xh, kname, path = _bench_layout(M, nf, 31, demod="fm", kf=kf)
+    assert kname == "k_run256v2<FM>", (kname, path)
+    _fm_against_oracle(got, xh, M, kf, f"cfg3 {kname}")
+
+
+def test_bench_layout_cfg2_64ch_deno_whole_chunk_matches_oracle():
+    """k_run64v2 at 64 x 1 048 576 (BASELINE configs[1]) against O.Chain, every sample."""
+    M, nf = 64, 1048576
+    got, xh, kname, path = _bench_layout(M, nf, 32)
+    assert kname == "k_run64v2", (kname, path)
+    want = O.Chain(M).process(xh)
+    r, e = rel_rms(got, want), max_abs_err(got, want)
+    print(f"cfg2 {kname}: whole chunk vs oracle: rel-rms {r:.3e}, max-abs {e:.3e} of {np.abs(want).max():.2f}")
+    assert r < 1e-5 and e < 1e-4 * np.abs(want).max()
+
+
+def test_bench_layout_cfg4_shape_1024ch_fm_whole_chunk_matches_oracle():
+    """k_run1024v2<FM> at 1024 x 65 536 (BASELINE configs[3] shape on one GPU) against O.Chain, every sample."""
+    M, nf, kf = 1024, 65536, 0.3
+    got, xh, kname, path = _bench_layout(M, nf, 33, demod="fm", kf=kf)
+    assert kname == "k_run1024v2<FM>", (kname, path)
+    _fm_against_oracle(got, xh, M, kf, f"cfg4 shape {kname}")
+
+
+def test_bench_layout_cfg5_shape_4096ch_mix_identity_whole_chunk_matches_oracle_and_full_bank():
+    """The DeNo --mix identity (k_dc_fold + k_mixid_finish) at 4096 x 16 384 (BASELINE configs[4] shape on one GPU) against
+    the oracle's full bank + DFT + left fold, every sample, and against the product's own full computation
+    (CSDR_FLAG_NO_MIX_IDENTITY) at that size."""
+    from composable_sdr_amd import _lib
+    M, nf = 4096, 16384
+    got, xh, kname, path = _bench_layout(M, nf, 34, demod="none", mix=True)
+    assert "mix-identity" in path and kname == "k_dc_fold", (kname, path)
+    full, _, kname2, path2 = _bench_layout(M, nf, 34, demod="none", mix=True, flags=_lib.FLAG_QUIET | _lib.FLAG_NO_MIX_IDENTITY)
+    assert "mix-identity" not in path2
+    want = O.Chain(M, demod="none", mix=True).process(xh)
+    assert got.shape == full.shape == want.shape == (nf,)
+    ymax = float(np.abs(O.Chain(M).process(xh[: M * 256])).max())      # size of the M terms the full sums add up
+    tol = max(4e-7 * ymax * M, 1e-5 * float(np.abs(want).max()))
+    print(f"cfg5 shape [{path}]: identity vs full bank [{path2}] max {np.abs(got - full).max():.3e}, vs oracle max {np.abs(got - want).max():.3e}, "
+          f"full bank vs oracle {np.abs(full - want).max():.3e} (tolerance {tol:.3e}, |out| max {np.abs(want).max():.2f})")
+    assert np.abs(got - full).max() < tol
+    assert np.abs(got - want).max() < tol

@@ -15,14 +15,16 @@ from synth import synth_cf32_torch
 M, nf = 256, int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 dev = torch.device("cuda", 0)
 x = synth_cf32_torch(M * nf, M, dev)
+# bench.py alternates two input buffers (together beyond the 256 MiB Infinity Cache); TRACE_ALT=0 re-reads one buffer (MALL-assisted)
+xs = [x, synth_cf32_torch(M * nf, M, dev, seed=20260101 + 7919)] if os.environ.get("TRACE_ALT", "1") != "0" else [x, x]
 out = torch.empty(M * nf * 2, dtype=torch.float32, device=dev)
 ch = cs.Chain(channels=M, demod=os.environ.get("TRACE_DEMOD", "fm"), max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
-for _ in range(3):
-    ch.process_device(x.data_ptr(), M * nf, out.data_ptr(), 0)
+for i in range(3):
+    ch.process_device(xs[i & 1].data_ptr(), M * nf, out.data_ptr(), 0)
 torch.cuda.synchronize()
 ch.kernel_time()
-for _ in range(5):
-    ch.process_device(x.data_ptr(), M * nf, out.data_ptr(), 0)
+for i in range(6):
+    ch.process_device(xs[(i + 1) & 1].data_ptr(), M * nf, out.data_ptr(), 0)
 torch.cuda.synchronize()
 nb = nf // 16
 buf = np.zeros((nb, 16), dtype=np.uint64)
