@@ -73,6 +73,9 @@ SIGNATURES = {
     "csdr_chain_create": (_i32, [C.POINTER(ChainCfg), _pp]),
     "csdr_chain_process": (_i32, [_vp, _vp, _u32, _vp, _pu32]),
     "csdr_chain_process_device": (_i32, [_vp, _vp, _u32, _vp, _pu32, _vp]),
+    "csdr_chain_submit_device": (_i32, [_vp, _vp, _u32, _vp, _pu32, _vp]),
+    "csdr_chain_wait_device": (_i32, [_vp, _vp]),
+    "csdr_chain_debug_independent_launches": (_u32, [_vp]),
     "csdr_chain_submit": (_i32, [_vp, _vp, _u32, _vp]),
     "csdr_chain_collect": (_i32, [_vp, _pu32]),
     "csdr_chain_status": (_i32, [_vp]),

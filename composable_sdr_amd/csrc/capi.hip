@@ -149,6 +149,13 @@ struct csdr_chain {
     float2 *d_amz = nullptr; float *d_amf = nullptr; float *d_amq[2] = {nullptr, nullptr}; int amq_cur = 0;
     KernelTimer timer;
     std::string timed_kernel;
+    // pipelined device entry point (csdr_chain_submit_device): two handle-owned streams used alternately, so that consecutive
+    // chunks' launches may overlap (the next launch's cold run starts fill the CUs the previous one has already left)
+    hipStream_t s_pd[2] = {nullptr, nullptr};
+    hipEvent_t e_pd_done[2] = {nullptr, nullptr}, e_pd_tail[3] = {nullptr, nullptr, nullptr}, e_serial = nullptr;
+    bool pd_used[2] = {false, false}, pd_tail_rec = false, serial_pending = false, in_submit = false;
+    uint32_t pd_count = 0, pd_indep_calls = 0;
+    bool call_indep = false; hipEvent_t call_ev_tail = nullptr;     // handed to the fused plan by the call in progress
 };
 
 extern "C" {
@@ -956,7 +963,24 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
 
 static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream);
 
+static int chain_process_device_any(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream);
+
 int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
+{
+    if (h && h->s_pd[0] && !h->in_submit) {
+        // the handle has pipelined chunks (csdr_chain_submit_device): this call follows them, and a later submit follows this call
+        DevGuard guard(h->device);
+        for (int i = 0; i < 2; i++) if (h->pd_used[i]) CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, h->e_pd_done[i], 0));
+        int r = chain_process_device_any(h, d_in, n_in, d_out, n_out, stream);
+        if (r) return r;
+        CSDR_HIP(hipEventRecord(h->e_serial, (hipStream_t)stream));
+        h->serial_pending = true;
+        return CSDR_OK;
+    }
+    return chain_process_device_any(h, d_in, n_in, d_out, n_out, stream);
+}
+
+static int chain_process_device_any(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
 {
     if (h && h->wbfm) {
         if (n_out) *n_out = 0;
@@ -1014,6 +1038,7 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         float2 *Z = (agc_on && (fm || mixo || h->agc_tail)) ? h->d_A : (float2 *)d_out;
         FusedCall fcall{};
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
+        fcall.indep = h->call_indep; fcall.ev_tail = h->call_ev_tail;
         if (h->agc_mask) {
             // the last channelizer frame of the call before this one.  Snapshot it: a run-sized call with a ragged tail flips the
             // plan's ping-pong twice, so the k_tile256 tail launch writes the very buffer fused_rp_next() names now (the chain's own
@@ -1071,6 +1096,63 @@ int csdr_chain_status(csdr_chain *h)
     if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
     DevGuard guard(h->device);
     return chain_device_status(h);
+}
+
+int csdr_chain_submit_device(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *ready_event)
+{
+    if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
+    if (n_out) *n_out = 0;
+    if (n_in == 0) return CSDR_OK;
+    if (!d_in || !d_out) { set_error("chain: null buffer"); return CSDR_ERR_INVALID; }
+    if (n_in % h->M) { set_error("chain: n_in=%u is not a multiple of channels=%u (the reference misbehaves here; Liquid.chs:832-862)", n_in, h->M); return CSDR_ERR_SIZE; }
+    if (n_in > h->max_nx) { set_error("chain: n_in=%u exceeds max_frames*channels=%llu", n_in, (unsigned long long)h->max_nx); return CSDR_ERR_SIZE; }
+    DevGuard guard(h->device);
+    if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
+    if (!h->s_pd[0]) {
+        CSDR_HIP(hipDeviceSynchronize());               // whatever the handle has queued on caller streams so far
+        for (int i = 0; i < 2; i++) {
+            CSDR_HIP(hipStreamCreateWithFlags(&h->s_pd[i], hipStreamNonBlocking));
+            CSDR_HIP(hipEventCreateWithFlags(&h->e_pd_done[i], hipEventDisableTiming));
+        }
+        for (int i = 0; i < 3; i++) CSDR_HIP(hipEventCreateWithFlags(&h->e_pd_tail[i], hipEventDisableTiming));
+        CSDR_HIP(hipEventCreateWithFlags(&h->e_serial, hipEventDisableTiming));
+        if (h->fused) fused_keep_tail(h->fused);
+    }
+    const uint32_t nf = n_in / h->M, k = h->pd_count;
+    const int si = (int)(k & 1);
+    hipStream_t s = h->s_pd[si];
+    // An independent launch (fused M = 256 chain without AGC / AM / WBFM tails, run-kernel-sized whole-tile chunk, previous
+    // chunk's tail on file) reads nothing an earlier launch writes: it only waits for the input and for the copy of the
+    // previous chunk's tail.  Every other call is ordered behind everything the handle has in flight.
+    const bool overlap = h->use_fused && h->fused && !h->d_agc && !h->am && !h->wbfm && !h->agc_mask && fused_can_overlap(h->fused, nf);
+    if (ready_event) CSDR_HIP(hipStreamWaitEvent(s, (hipEvent_t)ready_event, 0));
+    if (h->serial_pending) { CSDR_HIP(hipStreamWaitEvent(s, h->e_serial, 0)); h->serial_pending = false; }
+    if (overlap) {
+        if (h->pd_tail_rec) CSDR_HIP(hipStreamWaitEvent(s, h->e_pd_tail[(k + 2) % 3], 0));       // recorded by call k - 1
+    } else if (h->pd_used[si ^ 1]) CSDR_HIP(hipStreamWaitEvent(s, h->e_pd_done[si ^ 1], 0));
+    h->call_indep = overlap; h->call_ev_tail = h->e_pd_tail[k % 3]; h->in_submit = true;
+    const int r = csdr_chain_process_device(h, d_in, n_in, d_out, n_out, s);
+    h->call_indep = false; h->call_ev_tail = nullptr; h->in_submit = false;
+    if (r) return r;
+    h->pd_tail_rec = h->fused && fused_tail_recorded(h->fused);
+    if (overlap) h->pd_indep_calls++;
+    CSDR_HIP(hipEventRecord(h->e_pd_done[si], s));
+    h->pd_used[si] = true; h->pd_count = k + 1;
+    return CSDR_OK;
+}
+
+uint32_t csdr_chain_debug_independent_launches(const csdr_chain *h) { return h ? h->pd_indep_calls : 0u; }
+
+int csdr_chain_wait_device(csdr_chain *h, void *stream)
+{
+    if (!h) { set_error("chain: null handle"); return CSDR_ERR_INVALID; }
+    DevGuard guard(h->device);
+    for (int i = 0; i < 2; i++) {
+        if (!h->pd_used[i]) continue;
+        if (stream) CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, h->e_pd_done[i], 0));
+        else CSDR_HIP(hipEventSynchronize(h->e_pd_done[i]));
+    }
+    return CSDR_OK;
 }
 
 void *csdr_host_alloc(size_t bytes)
@@ -1201,6 +1283,7 @@ int csdr_chain_reset(csdr_chain *h)
     DevGuard guard(h->device);
     CSDR_HIP(hipDeviceSynchronize());                  // chunks still in flight are abandoned
     h->q_head = 0; h->q_count = 0;
+    h->pd_used[0] = h->pd_used[1] = false; h->pd_tail_rec = false; h->serial_pending = false; h->pd_count = 0;
     int r = chain_init_state(h, nullptr);
     if (r) return r;
     CSDR_HIP(hipDeviceSynchronize());
@@ -1256,6 +1339,10 @@ const char *csdr_chain_path(const csdr_chain *h) { return h ? h->path.c_str() : 
 const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *launches)
 {
     if (!h) return "";
+    if (h->s_pd[0] && h->timer.region && h->timer.open && h->timer.last) {
+        DevGuard guard(h->device);
+        for (int i = 0; i < 2; i++) if (h->pd_used[i]) (void)hipStreamWaitEvent(h->timer.last, h->e_pd_done[i], 0);
+    }
     (void)h->timer.drain();
     if (total_ms) *total_ms = h->timer.acc_ms;
     if (launches) *launches = h->timer.launches;
@@ -1287,7 +1374,8 @@ int csdr_chain_destroy(csdr_chain *h)
         if (sl.h_out) (void)hipHostFree(sl.h_out);
         for (hipEvent_t e : {sl.e_in, sl.e_k, sl.e_out}) if (e) (void)hipEventDestroy(e);
     }
-    for (hipStream_t st : {h->s_in, h->s_k, h->s_out}) if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : {h->s_in, h->s_k, h->s_out, h->s_pd[0], h->s_pd[1]}) if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : {h->e_pd_done[0], h->e_pd_done[1], h->e_pd_tail[0], h->e_pd_tail[1], h->e_pd_tail[2], h->e_serial}) if (e) (void)hipEventDestroy(e);
     delete h;
     return CSDR_OK;
 }

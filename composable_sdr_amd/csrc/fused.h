@@ -21,7 +21,14 @@ struct FusedCall {
     uint32_t theta0;         // NCO phase of the first sample
     float *d_energy = nullptr;   // FM plans, optional: [C][nf] energy words for the AGC mask pass (fused_common.h: agc_energy_word)
     float agc_alpha = 0.f;
+    // pipelined entry point (csdr_chain_submit_device): run the launch without reading anything an earlier launch wrote, if the
+    // plan can (fused_can_overlap); ev_tail is recorded on s once the chunk's last tiles are saved for the next call's run 0
+    bool indep = false;
+    hipEvent_t ev_tail = nullptr;
 };
+void fused_keep_tail(FusedPlan *plan);                  // from now on every run-kernel call saves its last WU + 1 raw tiles
+bool fused_can_overlap(const FusedPlan *plan, uint32_t nf);
+bool fused_tail_recorded(const FusedPlan *plan);       // the last call saved its tail (and recorded FusedCall::ev_tail)   // the next call of nf frames can run with FusedCall::indep
 
 bool fused_supported(uint32_t M, uint32_t p);
 int  fused_create(const FusedConfig &cfg, FusedPlan **out);

@@ -393,6 +393,9 @@ struct RunArgs {
     float l2beta;               // log2(beta)
     uint32_t prio_div;          // > 0: rotate the wave priority per tile; CU slot of a run = blockIdx / prio_div
     uint32_t trace_light;       // CSDR_TRACE=2: only per-run s_memrealtime stamps (entry / warm-up / halo / end)
+    const float4 *prev_tail;    // k_run256v2, indep: the previous chunk's last WU + 1 raw tiles (run 0's warm-up window and halo)
+    uint32_t indep;             // k_run256v2: run 0 starts cold from prev_tail instead of the carried state: the launch reads nothing an earlier launch wrote
+    uint32_t pair_align;        // k_run256v2<FM>: run boundaries rounded down to even tiles (whole 128-byte output lines per tile pair)
     uint32_t wu, wu_rot;        // k_run256v2: read-only warm-up tiles in front of a run's halo tile (WU = 6); runs walk them in rotated order
 };
 

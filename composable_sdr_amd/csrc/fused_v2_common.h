@@ -8,6 +8,9 @@ namespace csdr {
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+#ifndef V2_DMA_AUX
+#define V2_DMA_AUX ""       // cache-policy bits of the tile DMA (" nt", " sc1", ...) for A/B builds
+#endif
 
 __device__ __forceinline__ void bar()              // LDS-only barrier: outstanding global stores / LDS-DMA are not waited for
 {
@@ -31,12 +34,15 @@ __device__ __forceinline__ unsigned dma_offset(int tid)
 }
 __device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, unsigned goff, unsigned lds_wave)
 {
+    // the eight destination addresses are recomputed per call (one s_add each): as loop invariants they are sixteen SGPRs that
+    // hipcc parks in spill lanes and reloads with v_readlane right here
+    asm volatile("" : "+s"(lds_wave));
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const unsigned dst = lds_wave + 4096u * (unsigned)it;
         const float4 *src = tile_base + 256 * it;
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3" V2_DMA_AUX "\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(goff), "s"(dst), "s"(src) : "memory");
     }
 }

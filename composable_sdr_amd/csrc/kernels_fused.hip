@@ -703,6 +703,14 @@ static RunSplit make_split(uint32_t nb, uint32_t nruns, uint32_t cus, const floa
     return sp;
 }
 
+// The chunk's last WU + 1 raw tiles -> the plan's tail slot (a kernel on the launch's own stream rather than a D2D memcpy: no
+// copy engine, no blit-path synchronisation in front of the run kernel)
+__global__ __launch_bounds__(256) void k_save_tail(const float4 *__restrict__ src, float4 *__restrict__ dst)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    dst[i] = src[i];
+}
+
 struct FusedPlan {
     FusedConfig cfg;
     std::string name;
@@ -723,6 +731,11 @@ struct FusedPlan {
     uint32_t resident_wgs = 512;     // workgroups of k_run256 the device holds at once
     uint32_t resident_wgs_v2 = 512;  // workgroups of k_run256v2 the device holds at once
     bool use_v2 = true;              // CSDR_RUN_V1=1: first-generation run kernel (A/B)
+    // independent launches (csdr_chain_submit_device): the last WU + 1 raw tiles of the previous chunk, three slots (the launch
+    // two calls back may still be reading its slot when this call's copy is queued on the other stream)
+    float4 *d_tail[3] = {nullptr, nullptr, nullptr};
+    int tail_w = 0;                  // slot that holds the tail of the most recent chunk
+    bool tail_valid = false, keep_tail = false;
     TileArgs proto;
 };
 
@@ -744,6 +757,8 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
         ALLOC(p->d_vend[i], sizeof(float2));
         ALLOC(p->d_rp[i], sizeof(float2) * cfg.C);
     }
+    for (int i = 0; i < 3; i++) { ALLOC(p->d_tail[i], sizeof(float4) * 2048 * (WU + 1)); CSDR_HIP(hipMemset(p->d_tail[i], 0, sizeof(float4) * 2048 * (WU + 1))); }
+    p->tail_valid = true;            // a fresh stream: zero history IS the exact history
     ALLOC(p->d_ticket, sizeof(unsigned));
     ALLOC(p->d_status, sizeof(unsigned));
     ALLOC(p->d_yflag, sizeof(unsigned) * p->max_nb);
@@ -815,7 +830,23 @@ int fused_reset(FusedPlan *p, hipStream_t s)
         CSDR_HIP(hipMemsetAsync(p->d_vend[i], 0, sizeof(float2), s));
         CSDR_HIP(hipMemsetAsync(p->d_rp[i], 0, sizeof(float2) * p->cfg.C, s));
     }
+    CSDR_HIP(hipMemsetAsync(p->d_tail[0], 0, sizeof(float4) * 2048 * (WU + 1), s));
+    p->tail_w = 0; p->tail_valid = true;
     return 0;
+}
+
+void fused_keep_tail(FusedPlan *p) { p->keep_tail = true; }
+bool fused_tail_recorded(const FusedPlan *p) { return p->keep_tail && p->tail_valid; }
+
+static bool fused_v2_call(const FusedPlan *p, uint32_t nf)
+{
+    const FusedConfig &c = p->cfg;
+    return p->use_v2 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32) && nf / NB >= p->run_min_tiles;
+}
+
+bool fused_can_overlap(const FusedPlan *p, uint32_t nf)
+{
+    return p->keep_tail && p->tail_valid && fused_v2_call(p, nf) && nf % NB == 0 && !p->cfg.mix;
 }
 
 int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *timer)
@@ -853,13 +884,31 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         // k_run256v2: the older of a CU's two workgroups wins the issue arbitration and runs ~1.4x faster than the younger
         // one, so it gets the larger share of the tiles (measured: both end together at about 1.2 : 0.8); rotating the
         // priority per tile instead was no better
-        static const float v2_weight[8] = {1.2f, 0.8f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-        RA.split = make_split(A.nb, nruns, p->cus, (v2 && !getenv("CSDR_RUN_WEIGHTS")) ? v2_weight : p->slot_weight);
+        static const float v2_weight_cf[8] = {1.2f, 0.8f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        static const float v2_weight_fm[8] = {1.24f, 0.76f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};      // with whole-line stores the younger workgroup loses more (r03 trace: 4.8 vs 7.6 us per tile)
+        const float *v2_weight = c.fm ? v2_weight_fm : v2_weight_cf;
+        static const float equal_weight[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        static const bool pd_equal = getenv("CSDR_PD_EQUAL") != nullptr;
+        RA.split = make_split(A.nb, nruns, p->cus, (call.indep && pd_equal) ? equal_weight : ((v2 && !getenv("CSDR_RUN_WEIGHTS")) ? v2_weight : p->slot_weight));
         { const char *e = getenv("CSDR_PRIO_ROT"); RA.prio_div = e ? (atoi(e) ? p->cus : 0u) : (v2 ? 0u : p->cus); }
         { const char *e = getenv("CSDR_TRACE"); RA.trace_light = (e && atoi(e) == 2) ? 1u : 0u; }
         { const char *e = getenv("CSDR_WU"); RA.wu = e ? (uint32_t)atoi(e) : (uint32_t)WU; }       // experiments: fewer tiles = wrong DC state at run starts
-        { const char *e = getenv("CSDR_WU_ROT"); RA.wu_rot = e ? (uint32_t)atoi(e) : 1u; }
+        { const char *e = getenv("CSDR_WU_ROT"); RA.wu_rot = e ? (uint32_t)atoi(e) : 0u; }      // measured: no effect on the run-start burst
+        RA.pair_align = (v2 && c.fm) ? 1u : 0u;
         RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;
+        const bool whole = nf == nb_full * NB;
+        RA.indep = (call.indep && v2 && whole && !c.mix && p->keep_tail && p->tail_valid) ? 1u : 0u;
+        RA.prev_tail = p->d_tail[p->tail_w];
+        if (call.indep && !RA.indep) { set_error("fused: internal: independent launch requested from a call that cannot run as one"); return -1; }
+        if (p->keep_tail && v2 && whole) {
+            // this chunk's last WU + 1 tiles, for run 0 of the next call (queued in front of the launch: the copy only reads the input)
+            const int nxt = (p->tail_w + 1) % 3;
+            static const bool nocopy = getenv("CSDR_PD_NOCOPY") != nullptr;      // scheduling experiments only (wrong run-0 starts)
+            if (!nocopy) hipLaunchKernelGGL(k_save_tail, dim3(2048 * (WU + 1) / 256), dim3(256), 0, s,
+                                            reinterpret_cast<const float4 *>(call.d_in + (size_t)(nb_full - (WU + 1)) * 4096), p->d_tail[nxt]);
+            if (call.ev_tail) CSDR_HIP(hipEventRecord(call.ev_tail, s));
+            p->tail_w = nxt; p->tail_valid = true;
+        } else p->tail_valid = false;
         if (timer && (r = timer->begin(s))) return r;
         static const size_t extra_lds = getenv("CSDR_EXTRA_LDS") ? (size_t)atol(getenv("CSDR_EXTRA_LDS")) : 0;   // occupancy experiments
         if (v2) { if ((r = run256_v2_launch(&RA, c.fm, nruns, s))) return r; }
@@ -886,6 +935,8 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         }
     } else {
         p->name = c.fm ? "k_tile256<FM>" : "k_tile256<CF32>";
+        p->tail_valid = false;
+        if (call.indep) { set_error("fused: internal: independent launch requested from a tile-kernel call"); return -1; }
         if (++p->epoch == 0) p->epoch = 1;
         A.epoch = p->epoch; A.nf = nf; A.nb = (nf + NB - 1) / NB;
         CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
@@ -926,7 +977,7 @@ int fused_status(FusedPlan *p, unsigned *status)
 void fused_destroy(FusedPlan *p)
 {
     if (!p) return;
-    void *ptrs[] = {p->d_taps, p->d_tw, p->d_wpre, p->d_yhist[0], p->d_yhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0],
+    void *ptrs[] = {p->d_tail[0], p->d_tail[1], p->d_tail[2], p->d_taps, p->d_tw, p->d_wpre, p->d_yhist[0], p->d_yhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0],
                     p->d_rp[1], p->d_ticket, p->d_yflag, p->d_status, p->d_agg, p->d_ylast, p->d_premix, p->d_trace, p->d_yfirst};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;

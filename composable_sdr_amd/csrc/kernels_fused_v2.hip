@@ -25,9 +25,12 @@
 #define V2_FM_PACKED 1    // freqdem on packed pairs (fm_quad) instead of one sample at a time (fm_sample)
 #endif
 #ifndef V2_ABLATE
-#define V2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem, 8 one FIR tap
+#define V2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem, 8 one FIR tap, 16 no butterflies in the two DFT passes, 32 no DC scan arithmetic
 #endif
 
+#ifndef V2_PAIR
+#define V2_PAIR 1       // FM: whole 128-byte row lines per tile pair (0: every tile stores its own 64-byte halves, for A/B)
+#endif
 #ifndef V2_BAR_E
 #define V2_BAR_E 0      // 1: the (redundant) barrier between the X reads and the Z writes of pass 1, for A/B
 #endif
@@ -68,6 +71,10 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const unsigned w = blockIdx.x;
     unsigned first, last;
     run_range(RA.split, w, first, last);
+    if (RA.pair_align) {                                // runs start on even tiles: a tile pair fills whole 128-byte lines of the F32 rows
+        first &= ~1u;
+        if (last != A.nb) last &= ~1u;
+    }
     const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
     const unsigned goff = dma_offset(tid);
@@ -78,8 +85,15 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     V2LSTAMP(0);
     // Everything the run start waits for is requested up front, so that the prologue is one burst of memory traffic and not
     // a chain of round trips: the first tile (buffer 0) and the halo tile (buffer 1) by DMA, the table values as plain loads.
+    // cold run start: DC state from a read-only warm-up window, FIR window and freqdem history from the halo tile.  Run 0
+    // instead carries the exact state of the previous call -- unless the call is INDEPENDENT of the previous launch
+    // (RA.indep, the pipelined entry point csdr_chain_submit_device): then run 0 is a cold start like any other, its
+    // window being the previous chunk's last WU + 1 tiles, kept in RA.prev_tail (tiles -1 .. -(WU + 1) of this chunk).
+    const bool cold = w > 0 || RA.indep;
+    const int halo = (int)first - 1;
+    auto tile_ptr = [&](int t) -> const float4 * { return t >= 0 ? x4 + (size_t)t * 2048 : RA.prev_tail + (size_t)(WU + 1 + t) * 2048; };
     if (first < last) dma_tile(x4 + (size_t)first * 2048, goff, lds_wave);
-    if (w > 0) dma_tile(x4 + (size_t)(first - 1) * 2048, goff, lds_wave + (unsigned)(V2_BUF * 8));
+    if (cold) dma_tile(tile_ptr(halo), goff, lds_wave + (unsigned)(V2_BUF * 8));
     float h[P];
 #pragma unroll
     for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j) + n * M256];
@@ -92,13 +106,13 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     float2 w2 = make_float2(0.f, 0.f);
 
     // ------------------------------------------------------------------ run start (as k_run256)
-    if (w == 0) {
+    if (!cold) {
         c = A.vend_in[0];
 #pragma unroll
         for (int f = 3; f < NB; f++) wa[f] = A.yhist_in[(f - 3) * M256 + j];
     } else {
-        const unsigned halo = first - 1;
-        const unsigned h0 = halo > RA.wu ? halo - RA.wu : 0u, nwu = halo - h0;
+        const int h0 = RA.indep ? halo - (int)RA.wu : (halo > (int)RA.wu ? halo - (int)RA.wu : 0);
+        const unsigned nwu = (unsigned)(halo - h0);
         float4 raw[8];
         float w0[8], w1[8];
         {
@@ -116,14 +130,14 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         // order-free, so that run w may start at tile (w mod nwu) of its window: 512 runs that walk their windows in the same order
         // hit the HBM channels in lockstep
         float2 acc = make_float2(0.f, 0.f);
-        auto fold = [&](const float4 (&r)[8], unsigned t) {
+        auto fold = [&](const float4 (&r)[8], int t) {
             float2 p = make_float2(0.f, 0.f);
 #pragma unroll
             for (int it = 0; it < 8; it++) {
                 p = cfma(make_float2(r[it].x, r[it].y), w0[it], p);
                 p = cfma(make_float2(r[it].z, r[it].w), w1[it], p);
             }
-            acc = cfma(p, exp2f((float)(4096u * (halo - 1u - t)) * RA.l2beta), acc);
+            acc = cfma(p, exp2f((float)(4096 * (halo - 1 - t)) * RA.l2beta), acc);
         };
         const unsigned rot = RA.wu_rot ? w : 0u;
         unsigned i = 0;
@@ -131,21 +145,21 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             float4 rb[8], rc[8];
 #pragma unroll 1
             for (; i + 3 <= nwu; i += 3) {
-                const unsigned t0 = h0 + (i + rot) % nwu, t1 = h0 + (i + 1 + rot) % nwu, t2 = h0 + (i + 2 + rot) % nwu;
-                tile_load(x4 + (size_t)t0 * 2048, 256, raw, tid);
-                tile_load(x4 + (size_t)t1 * 2048, 256, rb, tid);
-                tile_load(x4 + (size_t)t2 * 2048, 256, rc, tid);
+                const int t0 = h0 + (int)((i + rot) % nwu), t1 = h0 + (int)((i + 1 + rot) % nwu), t2 = h0 + (int)((i + 2 + rot) % nwu);
+                tile_load(tile_ptr(t0), 256, raw, tid);
+                tile_load(tile_ptr(t1), 256, rb, tid);
+                tile_load(tile_ptr(t2), 256, rc, tid);
                 fold(raw, t0); fold(rb, t1); fold(rc, t2);
             }
         }
         for (; i < nwu; i++) {
-            const unsigned t0 = h0 + (i + rot) % nwu;
-            tile_load(x4 + (size_t)t0 * 2048, 256, raw, tid);
+            const int t0 = h0 + (int)((i + rot) % nwu);
+            tile_load(tile_ptr(t0), 256, raw, tid);
             fold(raw, t0);
         }
         float2 ch = wg_sum(acc, red, tid);
         V2LSTAMP(1);
-        if (h0 == 0) ch = cfma(A.vend_in[0], exp2f((float)(4096u * halo) * RA.l2beta), ch);
+        if (h0 == 0 && !RA.indep) ch = cfma(A.vend_in[0], exp2f((float)(4096 * halo) * RA.l2beta), ch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the two DMA'd tiles (older than every warm-up load)
         __syncthreads();
         scan_staged(H, E, Tt, A, tid);
@@ -167,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     for (int f = 3; f < NB; f++) wa[f] = cmul(wa[f], (f & 1) ? Wb : Wa);       // the window holds pre-mixed samples
     __syncthreads();                                    // every thread has read its run carries out of the stash area
     // freqdem history: stash[k1][i] = last Y frame of channel k1 + 16 XIDX(i)
-    ST[(tid & 15) * 16 + XIDX(tid >> 4)] = (FM && w == 0) ? A.rp_in[tid] : make_float2(0.f, 0.f);
+    ST[(tid & 15) * 16 + XIDX(tid >> 4)] = (FM && !cold) ? A.rp_in[tid] : make_float2(0.f, 0.f);
     __syncthreads();                                    // H free; stash and twiddles visible
-    if (FM && w > 0) {
+    if (FM && cold) {
         // The run's first freqdem sample needs the frame in front of it: the halo tile's last frame goes through the FIR and
         // a one-frame DFT here (same arithmetic as the tile loop: pass 1 thread b1, pass 2 thread k1), instead of a fix-up
         // kernel after the launch patching one float into every row.
@@ -223,6 +237,10 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const size_t row16 = (size_t)16 * A.out_stride * (FM ? 4u : 8u);
 #define V2STAMP(i) do { if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b_ * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
+    // FM: the even tile of a pair keeps its 16 results per thread and the odd tile stores both, so that the two 64-byte halves of
+    // a row's 128-byte line reach the L2 back to back and leave it as ONE write (halves that arrive a tile apart are evicted
+    // separately under the streaming reads: F32 output then costs as much HBM write energy as CF32 output of twice the size)
+    float hold[16];
     auto tile = [&](float2 (&old)[NB], float2 (&nw)[NB], unsigned b_, const int par) {
         unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)b_);            // keep the tile index (store / DMA bases) in SGPRs
         asm volatile("" : "+s"(b));
@@ -246,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             xr[i] = *reinterpret_cast<const v4f *>(B + (raw_a ^ (unsigned)(i << 4)));
+            if (V2_ABLATE & 32) { s.x += xr[i].x; continue; }
             s = make_float2(fmaf(s.x, be, xr[i].x), fmaf(s.y, be, xr[i].y));
             s = make_float2(fmaf(s.x, be, xr[i].z), fmaf(s.y, be, xr[i].w));
         }
@@ -261,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             v4f y;
+            if (V2_ABLATE & 32) { *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = xr[i]; continue; }
             y.x = fmaf(s.x, na, xr[i].x); y.y = fmaf(s.y, na, xr[i].y);
             s = make_float2(fmaf(s.x, be, xr[i].x), fmaf(s.y, be, xr[i].y));
             y.z = fmaf(s.x, na, xr[i].z); y.w = fmaf(s.y, na, xr[i].w);
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         v2f vv[16];
 #pragma unroll
         for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B + (x_a ^ (unsigned)((a >> 1) << 4)) + 128 * a));
-        fft16_v(vv);
+        if (!(V2_ABLATE & 16)) fft16_v(vv);
 #pragma unroll
         for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + b1]));
         V2STAMP(7);
@@ -338,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             const v4f v = *reinterpret_cast<const v4f *>(B + (z_a ^ (unsigned)(i << 4)));
             vv[2 * i] = (v2f){v.x, v.y}; vv[2 * i + 1] = (v2f){v.z, v.w};
         }
-        fft16_v(vv);                                    // vv[i] = Y[k1 + 16 XIDX(i)] of frame f2
+        if (!(V2_ABLATE & 16)) fft16_v(vv);             // vv[i] = Y[k1 + 16 XIDX(i)] of frame f2
         V2STAMP(11);
         // ---- tail
         char *obase = reinterpret_cast<char *>(A.out) + (size_t)16 * b * (FM ? 4u : 8u);
@@ -354,7 +374,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                     rp[u + 1] = make_float2(dpp_keep<0x111>(sp.z, vv[i + u + 1].x), dpp_keep<0x111>(sp.w, vv[i + u + 1].y));
                     rr[u] = to_f2(vv[i + u]); rr[u + 1] = to_f2(vv[i + u + 1]);
                 }
-                float mq[4];
+                float mq_[4];
+                float (&mq)[4] = (V2_PAIR && par == 0) ? *reinterpret_cast<float (*)[4]>(&hold[i]) : mq_;
                 if (V2_ABLATE & 4) { mq[0] = rp[0].x + rr[0].y; mq[1] = rp[1].y + rr[1].x; mq[2] = rp[2].x + rr[2].y; mq[3] = rp[3].y + rr[3].x; }
                 else if (V2_FM_PACKED) fm_quad(rp, rr, fk, mq);
                 else {
@@ -371,12 +392,18 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                         asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(voff), "v"(ew), "s"(rowe) : "memory");
                     }
                 }
+                if (V2_PAIR && par == 0 && b + 1 < last) continue;   // (uniform) the odd tile of the pair stores these
 #pragma unroll
                 for (int u = 0; u < 4; u++) {                       // stores go out between the quads
                     const char *rowp = obase + (size_t)XIDX(i + u) * row16;
                     if (V2_ABLATE & 2) asm volatile("" :: "v"(mq[u]), "s"(rowp));
-                    else if (EN) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
-                    else asm volatile(V2_SNOP "global_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
+                    else if (EN) {
+                        if (V2_PAIR && par == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:-64" :: "v"(voff), "v"(hold[i + u]), "s"(rowp) : "memory");
+                        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
+                    } else {
+                        if (V2_PAIR && par == 1) asm volatile(V2_SNOP "global_store_dword %0, %1, %2 offset:-64" :: "v"(voff), "v"(hold[i + u]), "s"(rowp) : "memory");
+                        asm volatile(V2_SNOP "global_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
+                    }
                 }
             }
             if (f2 == 15) {

@@ -322,6 +322,21 @@ class Chain:
                                               C.byref(n_out), C.c_void_p(stream)))
         return n_out.value
 
+    # ---- pipelined device entry point (csdr_chain_submit_device / csdr_chain_wait_device)
+    def submit_device(self, d_in_ptr, n_in, d_out_ptr, ready_event=0):
+        """Queue one HBM-resident chunk on the handle's own streams; consecutive chunks' launches may overlap (include/csdr.h).
+        `d_in_ptr` must stay untouched and `d_out_ptr` unread until wait_device()."""
+        n_out = C.c_uint32()
+        check(lib().csdr_chain_submit_device(self.h, C.c_void_p(d_in_ptr), n_in, C.c_void_p(d_out_ptr), C.byref(n_out), C.c_void_p(ready_event)))
+        return n_out.value
+
+    def independent_launches(self):
+        return lib().csdr_chain_debug_independent_launches(self.h)
+
+    def wait_device(self, stream=None):
+        """Host (stream=None) or `stream` waits for every chunk queued with submit_device()."""
+        check(lib().csdr_chain_wait_device(self.h, C.c_void_p(stream) if stream is not None else None))
+
     # ---- asynchronous host-buffer entry point (csdr_chain_submit / csdr_chain_collect)
     def submit(self, x, out=None):
         """Queue one chunk; `x` / `out` should come from host_array() (page-locked) for full PCIe speed.  Returns `out`,

@@ -240,6 +240,22 @@ int  csdr_chain_process_device(csdr_chain *h, const void *d_in_cf32, uint32_t n_
  * in the `out` given to its submit.  Buffers from csdr_host_alloc (page-locked) are copied from / to directly; any
  * other buffer is staged through page-locked memory owned by the handle (one extra host memcpy each way).  The
  * buffers of a chunk must stay valid until its collect.  csdr_chain_process = submit + collect. */
+/* Pipelined DEVICE entry point, for callers that keep several chunks in flight in HBM (a capture ring, the bench): like
+ * csdr_chain_process_device, but the work goes onto two handle-owned streams used alternately, and the call does not order
+ * itself behind the previous chunk where the path allows it.  For the fused 256-channel chain without AGC / AM / WBFM
+ * tails and chunks of whole 16-frame tiles at the run-kernel size, consecutive launches are INDEPENDENT: run 0 of a
+ * chunk starts cold like every other run of the launch (DC state from a read-only warm-up over the previous chunk's last
+ * tiles, which the handle keeps a copy of; FIR window and freqdem history from its last tile), so the next launch's
+ * workgroups fill the compute units the previous launch has already left, and its cold start (tens of microseconds of
+ * memory traffic with idle ALUs) runs under the previous launch's tile loops.  Same results as csdr_chain_process_device
+ * to the run-start tolerance every run of a launch already has (DC state truncated at beta^24576).  Other configurations
+ * are accepted and run serialized.
+ *   ready_event: hipEvent_t after which d_in is complete, or NULL if it already is when the call is made.
+ *   d_in must stay untouched and d_out unread until csdr_chain_wait_device (stream = NULL: the host waits for every
+ *   submitted chunk; else `stream` is made to wait).  csdr_chain_process_device orders itself behind submitted chunks. */
+int  csdr_chain_submit_device(csdr_chain *h, const void *d_in_cf32, uint32_t n_in, void *d_out, uint32_t *n_out, void *ready_event);
+int  csdr_chain_wait_device(csdr_chain *h, void *stream);
+uint32_t csdr_chain_debug_independent_launches(const csdr_chain *h);   /* submit_device calls since create that ran as independent launches */
 #define CSDR_CHAIN_INFLIGHT 3
 void *csdr_host_alloc(size_t bytes);            /* page-locked host memory (hipHostMalloc); NULL on failure */
 void  csdr_host_free(void *p);
