@@ -70,28 +70,36 @@ def cpu_baseline(M, demod, kf, agc, x_host, seconds, mix=False):
     res = {"value": round(done / dt / 1e6, 3), "unit": "MS/s", "cores": 1, "kind": "port",
            "sample": f"{done // chunk} chunks of 4096 frames x {M} ch ({done / 1e6:.1f} MS) of the same synthetic stream, "
                      f"oracle/csdr_oracle.c single thread, {dt:.1f} s"}
-    # the same restatement on all host cores -- one independent chain per core, each on its own
-    # stretch of the stream (the reference itself is single-threaded; this is the fair-hardware figure)
-    import threading
+    # the same restatement on all host cores -- one PROCESS per core (children of this one; each builds its own
+    # chain and runs reference-sized chunks of the same signal family for `budget` seconds of its own clock, after a common start
+    # time), the fair-hardware figure; the reference itself is single-threaded
+    import subprocess
     ncores = os.cpu_count() or 1
     if ncores > 1 and nchunks >= 1:
-        chains = [O.Chain(M, dc_block=True, agc_db=agc, demod=demod, kf=kf, mix=mix) for _ in range(ncores)]
-        counts = [0] * ncores
         budget = max(2.0, seconds / 3)
-        t1 = time.perf_counter()
-
-        def work(k):
-            i = k % nchunks
-            while time.perf_counter() - t1 < budget:
-                chains[k].process(x_host[i * chunk:(i + 1) * chunk])    # ctypes releases the GIL
-                counts[k] += chunk
-                i = (i + 1) % nchunks
-        th = [threading.Thread(target=work, args=(k,)) for k in range(ncores)]
-        for t in th: t.start()
-        for t in th: t.join()
-        dt2 = time.perf_counter() - t1
-        res["all_cores"] = {"value": round(sum(counts) / dt2 / 1e6, 3), "unit": "MS/s", "cores": ncores,
-                            "sample": f"{ncores} independent chains, one thread each, {sum(counts) / 1e6:.1f} MS in {dt2:.1f} s"}
+        worker = (
+            "import sys,time,os;sys.path.insert(0,%r);sys.path.insert(0,%r);import numpy as np,oracle_lib as O;from synth import synth_cf32;"
+            "M=%d;x=synth_cf32(4096*M,M,seed=1000+int(sys.argv[1]));c=O.Chain(M,dc_block=True,agc_db=%r,demod=%r,kf=%r,mix=%r);"
+            "t_go=float(sys.argv[2]);n=0\n"
+            "while time.time()<t_go: time.sleep(0.01)\n"
+            "t0=time.perf_counter()\n"
+            "while time.perf_counter()-t0<%r:\n c.process(x);n+=x.size\n"
+            "print(n,time.perf_counter()-t0)" % (ROOT, os.path.join(ROOT, "tests"), M, agc, demod, kf, mix, budget))
+        t_go = time.time() + 4.0 + 0.02 * ncores                     # every child has imported numpy and built its chain by then
+        procs = [subprocess.Popen([sys.executable, "-c", worker, str(k), repr(t_go)], stdout=subprocess.PIPE, text=True,
+                                  env=dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")) for k in range(ncores)]
+        tot, tmax, ok = 0, 0.0, 0
+        for pr in procs:
+            o, _ = pr.communicate()
+            try:
+                n, t = o.split()
+                tot += int(n); tmax = max(tmax, float(t)); ok += 1
+            except Exception:
+                pass
+        if ok:
+            res["all_cores"] = {"value": round(tot / tmax / 1e6, 3), "unit": "MS/s", "cores": ok,
+                                "sample": f"{ok} processes (one per host core, os.cpu_count() = {ncores}), one independent chain each on its own reference-sized "
+                                          f"chunk, started together, {tot / 1e6:.1f} MS in {tmax:.1f} s"}
     return res
 
 
@@ -137,7 +145,9 @@ def main():
     # channel shards: every rank sees the SAME stream (in production: broadcast over xGMI) and owns channels rank, rank + N, ...
     xs = [synth_cf32_torch(nx, M, dev, seed=20260101 + 7919 * (2 * (0 if chan else rank) + i)) for i in range(2)]
     out = torch.empty(M * nf * out_elem // 4, dtype=torch.float32, device=dev)
-    flags = _lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS
+    # one hipEvent pair around the K timed launches of the dominant kernel, on their stream (a pair per launch costs the stream
+    # a few us each); the multi-kernel channel-shard route keeps the pair per launch, which brackets the one kernel it names
+    flags = _lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS | (0 if (a.shard == "channel" and int(os.environ.get("WORLD_SIZE", "1")) > 1) else _lib.FLAG_TIME_REGION)
     if chan:
         from composable_sdr_amd.pipes import ChainConfig
         from composable_sdr_amd.sharded import ShardedChain
@@ -176,6 +186,41 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # N > 1, time stripes (the default): north_star's own partition -- interleaved channel ownership, every rank on the SAME
+    # stream -- measured beside it in the same run and reported under "channel_shard" (strong scaling: the samples are counted once)
+    chan2 = None
+    if world > 1 and not chan and M % world == 0:
+        from composable_sdr_amd.pipes import ChainConfig
+        from composable_sdr_amd.sharded import ShardedChain
+        xc = [synth_cf32_torch(nx, M, dev, seed=20260101 + 7919 * i) for i in range(2)]
+        sc2 = ShardedChain(ChainConfig(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local,
+                                       flags=_lib.FLAG_QUIET), mode="channel", interleave=True)
+        xcv = [x.view(-1) for x in xc]
+
+        def step2(i):
+            if a.mix:
+                sc2.process_device_mix(xcv[i & 1], out[: nf * out_elem // 4], stream)
+            else:
+                sc2.chain.process_device(xc[i & 1].data_ptr(), nx, out.data_ptr(), stream)
+        reps2 = max(3, a.steps // 2)
+        for i in range(2):
+            step2(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(reps2):
+            step2(i)
+        barrier()
+        d2 = time.perf_counter() - t1
+        t = torch.tensor([d2], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d2 = float(t.item())
+        chan2 = {"value": round(nx * reps2 / d2 / 1e6, 1), "unit": "MS/s", "ms_per_step": round(d2 / reps2 * 1e3, 4), "steps": reps2, "scaling": "strong",
+                 "path": sc2.chain.path,
+                 "sharding": f"channel-interleaved: rank g owns channels g + {world} m (every rank reads the whole stream; DC blocker, pre-mix and FIR are not divided)",
+                 "collective": (f"RCCL all-reduce(SUM) of {nf} {'F32' if a.demod == 'fm' else 'CF32'} per step" if a.mix else "none"),
+                 "rccl_ranks": dist.get_world_size()}
+        sc2.chain.close()
+
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
@@ -199,11 +244,13 @@ def main():
     def traffic_of(kernel):
         return tj.get(f"{kernel}|M={M}|nf={nf}", {}).get("hbm_bytes_per_launch")
     traffic = traffic_of(kname)
+    cfg_name = {(64, "none", False): "cfg2", (256, "fm", False): "cfg3", (1024, "fm", False): "cfg4 shape (one GPU)" if world == 1 else "cfg4",
+                (4096, "none", True): "cfg5 shape (one GPU)" if world == 1 else "cfg5"}.get((M, a.demod, bool(a.mix)), "custom")
     res = {
-        "metric": "MS/s CF32 throughput, 256-ch PFB+FM pipeline", "value": round(value, 1), "unit": "MS/s",
+        "metric": f"MS/s CF32 throughput, {M}-ch PFB{'+FM' if a.demod == 'fm' else ''}{'+AGC' if a.agc else ''}{' --mix' if a.mix else ''} pipeline", "value": round(value, 1), "unit": "MS/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong" if chan else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"cfg3: {M}-ch firpfbch(m=7,As=80)+dcBlocker+freqdem(kf={a.kf}) on synthetic CF32, "
+        "config": {"workload": f"{cfg_name}: {M}-ch firpfbch(m=7,As=80)+dcBlocker{f'+freqdem(kf={a.kf})' if a.demod == 'fm' else ' (DeNo)'}{' --mix' if a.mix else ''} on synthetic CF32, "
                                f"AGC {'off (-a 0)' if a.agc == 0 else a.agc}, {nf} frames/step "
                                f"({nx * 8 / 2**20:.0f} MiB in, {M * nf * out_elem / 2**20:.0f} MiB out), HBM-resident",
                    "channels": M, "frames_per_step": nf, "demod": a.demod, "kf": a.kf, "agc_db": a.agc, "mix": bool(a.mix),
@@ -221,6 +268,8 @@ def main():
                      "alg_bytes_per_sample": alg_bytes_per_sample, "samples_per_launch": nx},
     }
 
+    if chan2:
+        res["channel_shard"] = chan2
     if world == 1 and not a.no_agc_variant and a.agc == 0.0 and M == 256 and not a.mix:
         # cfg3 with the AGC on (squelch threshold -a 10 between the tone and the noise channels): the PFB kernel
         # writes channel-major CF32, the time-parallel verified AGC tail (bit-identical to the sequential

@@ -128,6 +128,14 @@ class ShardedChain:
         the chunk (interleaved CF32 as float32), the same on every rank; returns the number of output elements."""
         n = self.chain.process_device(x_dev.data_ptr(), x_dev.numel() // 2, out_dev.data_ptr(), stream)
         if self.dist is not None and self.world > 1:
+            if out_dev.is_cuda:
+                import torch
+                cur = torch.cuda.current_stream(out_dev.device)
+                if int(stream or 0) != int(cur.cuda_stream):
+                    # the collective runs on torch's current stream: order it behind the chain's launches on `stream`
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.ExternalStream(int(stream or 0), device=out_dev.device))
+                    cur.wait_event(ev)
             self.dist.all_reduce(out_dev, op=self.dist.ReduceOp.SUM, group=self.group)
         return n
 

@@ -561,6 +561,10 @@ def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
         assert ("all-reduce" in r["config"]["collective"]) == mix
     else:
         assert r["scaling"] == "weak" and "time stripes" in r["config"]["sharding"] and r["config"]["collective"] == "none"
+        # the default partition's line also carries north_star's partition, measured in the same run
+        cs2 = r["channel_shard"]
+        assert cs2["value"] > 0 and cs2["scaling"] == "strong" and "channel-interleaved" in cs2["sharding"] and cs2["rccl_ranks"] == 2
+        assert ("all-reduce" in cs2["collective"]) == mix
 
 
 def test_seek_frames_sets_premix_phase():
