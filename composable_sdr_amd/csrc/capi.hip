@@ -727,12 +727,13 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     // Path selection: the fused kernels cover M = 256 (DC blocker + pre-mix + PFB [+ freqdem]).
     // With the AGC on, the fused kernel stops at the channel-major CF32 samples and the
     // exactly-sequential per-channel AGC tail (one lane per channel) + freqdem + mix follow.
-    const bool want_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && G == 1;   // interleaved shards: any-M route, pruned DFT
+    // interleaved shards: the fused M = 256 chain takes strides 2, 4, 8 (k_run256v2<.., G>); every other shape the any-M route with a pruned DFT
+    const bool want_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && (G == 1 || (fused_supported(M, h->p) && (G == 2 || G == 4 || G == 8) && !getenv("CSDR_SHARD_GENERIC")));
     h->use_fused = want_fused && (fused_supported(M, h->p) || small_supported(M, h->p) || (big_supported(M, h->p) && !getenv("CSDR_NO_RUN1024")));
     if (h->use_fused) {
         const bool agc_on = cfg->agc_threshold_db != 0.0f;
         FusedConfig fc{};
-        fc.M = M; fc.p = h->p; fc.C = C; fc.c0 = c0; fc.max_nf = h->max_nf;
+        fc.M = M; fc.p = h->p; fc.C = C; fc.c0 = c0; fc.max_nf = h->max_nf; fc.G = G;
         fc.dc_block = cfg->dc_block != 0; fc.dc = h->dc;
         // FM + AGC on the whole-band M = 256 plan, CSDR_AGC_FM_MASK=1: the gain drops out of arg(conj(y') y), so the run kernel
         // demodulates the channelizer output itself and leaves an energy word per sample; the AGC is a mask pass over those
@@ -753,7 +754,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             h->timed_kernel = big_name(h->big);
         } else {
             if ((r = fused_create(fc, &h->fused))) return fail(r);
-            h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (agc_on ? "+agc" : "");
+            h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (G > 1 ? "+interleaved-shard" : "") + (agc_on ? "+agc" : "");
             h->timed_kernel = fused_name(h->fused);
             if (mask_route && fused_whole_band_v2(h->fused)) {
                 if ((r = agc_mask_create(C, h->max_nf, &h->agc_mask))) return fail(r);

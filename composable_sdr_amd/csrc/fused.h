@@ -7,6 +7,7 @@ namespace csdr {
 
 struct FusedConfig {
     uint32_t M, p, C, c0, max_nf;
+    uint32_t G = 1;          // > 1: interleaved shard c0 of G (channels c0, c0 + G, ...; C = M / G rows out): k_run256v2<.., G>, G = 2, 4, 8
     bool dc_block; DcParams dc;
     bool fm; float fm_ref;
     bool mix;
@@ -45,7 +46,7 @@ int  fused_trace(FusedPlan *plan, unsigned long long *out, uint32_t ntiles);
 void fused_destroy(FusedPlan *plan);
 // second-generation run kernel of the M = 256 chain (kernels_fused_v2.hip): whole-band calls of >= run_min_tiles tiles.
 // run_args points at the RunArgs the first-generation k_run256 would have been launched with.
-int  run256_v2_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s);
+int  run256_v2_launch(const void *run_args, bool fm, unsigned G, unsigned nruns, hipStream_t s);
 int  run256_v2_blocks_per_cu(bool fm);
 
 

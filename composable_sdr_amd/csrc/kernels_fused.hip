@@ -711,6 +711,15 @@ __global__ __launch_bounds__(256) void k_save_tail(const float4 *__restrict__ sr
     dst[i] = src[i];
 }
 
+// ragged end of an interleaved shard's call: rows c0 + G m of the whole-band tile result [256][rem] -> the shard's plane [C][nf] at frame t0
+// (w = floats per sample: 1 F32, 2 CF32)
+__global__ __launch_bounds__(64) void k_shard_gather(const float *__restrict__ src, float *__restrict__ dst, uint32_t c0, uint32_t G, uint32_t rem,
+                                                     uint32_t nf, uint32_t t0, uint32_t w)
+{
+    const uint32_t m = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < rem * w; i += 64) dst[((size_t)m * nf + t0) * w + i] = src[(size_t)(c0 + G * m) * rem * w + i];
+}
+
 struct FusedPlan {
     FusedConfig cfg;
     std::string name;
@@ -733,6 +742,7 @@ struct FusedPlan {
     bool use_v2 = true;              // CSDR_RUN_V1=1: first-generation run kernel (A/B)
     // independent launches (csdr_chain_submit_device): the last WU + 1 raw tiles of the previous chunk, three slots (the launch
     // two calls back may still be reading its slot when this call's copy is queued on the other stream)
+    float *d_shard_tail = nullptr;   // interleaved shard: whole-band result of a call's ragged end, [256][< 16] CF32 at most
     float4 *d_tail[3] = {nullptr, nullptr, nullptr};
     int tail_w = 0;                  // slot that holds the tail of the most recent chunk
     bool tail_valid = false, keep_tail = false;
@@ -755,8 +765,9 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     for (int i = 0; i < 2; i++) {
         ALLOC(p->d_yhist[i], sizeof(float2) * 13 * cfg.M);
         ALLOC(p->d_vend[i], sizeof(float2));
-        ALLOC(p->d_rp[i], sizeof(float2) * cfg.C);
+        ALLOC(p->d_rp[i], sizeof(float2) * (cfg.G > 1 ? cfg.M : cfg.C));     // interleaved shard: full-band indices (fused_v2: rp_in / rp_out)
     }
+    if (cfg.G > 1) ALLOC(p->d_shard_tail, sizeof(float2) * cfg.M * NB);
     for (int i = 0; i < 3; i++) { ALLOC(p->d_tail[i], sizeof(float4) * 2048 * (WU + 1)); CSDR_HIP(hipMemset(p->d_tail[i], 0, sizeof(float4) * 2048 * (WU + 1))); }
     p->tail_valid = true;            // a fresh stream: zero history IS the exact history
     ALLOC(p->d_ticket, sizeof(unsigned));
@@ -828,7 +839,7 @@ int fused_reset(FusedPlan *p, hipStream_t s)
     for (int i = 0; i < 2; i++) {
         CSDR_HIP(hipMemsetAsync(p->d_yhist[i], 0, sizeof(float2) * 13 * p->cfg.M, s));
         CSDR_HIP(hipMemsetAsync(p->d_vend[i], 0, sizeof(float2), s));
-        CSDR_HIP(hipMemsetAsync(p->d_rp[i], 0, sizeof(float2) * p->cfg.C, s));
+        CSDR_HIP(hipMemsetAsync(p->d_rp[i], 0, sizeof(float2) * (p->cfg.G > 1 ? p->cfg.M : p->cfg.C), s));
     }
     CSDR_HIP(hipMemsetAsync(p->d_tail[0], 0, sizeof(float4) * 2048 * (WU + 1), s));
     p->tail_w = 0; p->tail_valid = true;
@@ -841,7 +852,7 @@ bool fused_tail_recorded(const FusedPlan *p) { return p->keep_tail && p->tail_va
 static bool fused_v2_call(const FusedPlan *p, uint32_t nf)
 {
     const FusedConfig &c = p->cfg;
-    return p->use_v2 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32) && nf / NB >= p->run_min_tiles;
+    return p->use_v2 && c.G == 1 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32) && nf / NB >= p->run_min_tiles;
 }
 
 bool fused_can_overlap(const FusedPlan *p, uint32_t nf)
@@ -865,13 +876,16 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     A.energy = (c.fm && !c.mix) ? call.d_energy : nullptr; A.agc_alpha = call.agc_alpha;
     A.parity0 = (uint32_t)(p->frames_done & 1);
     const uint32_t nb_full = nf / NB;
-    if (nb_full >= p->run_min_tiles) {
+    const bool shard = c.G > 1;      // interleaved shard: every whole tile goes through k_run256v2<.., G> (the tile kernel only knows whole bands)
+    if (shard && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) >= (1ull << 32)) { set_error("fused: interleaved shard output of %u frames exceeds 4 GiB", nf); return -1; }
+    if (nb_full >= p->run_min_tiles || shard) {
         // large chunk: dependency-free runs of S full tiles; a ragged tail (< 16 frames) follows as
         // a second launch of the tile kernel on the state the run kernel leaves behind
         // whole-band calls whose output fits 32-bit byte offsets take the second-generation kernel
-        const bool v2 = p->use_v2 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32);
+        const bool v2 = shard || (p->use_v2 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32));
         if (A.energy && !v2) { set_error("fused: energy words requested from a call that takes k_run256 (shard or output >= 4 GiB)"); return -1; }   // CSDR_ERR_INVALID
         p->name = v2 ? (c.fm ? "k_run256v2<FM>" : "k_run256v2<CF32>") : (c.fm ? "k_run256<FM>" : "k_run256<CF32>");
+        if (shard) p->name += "/G" + std::to_string(c.G);
         RunArgs RA{};
         A.nf = nb_full * NB; A.nb = nb_full;
         RA.t = A; RA.yfirst = p->d_yfirst; RA.pk = phase_consts(c.fm_ref);
@@ -911,7 +925,8 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         } else p->tail_valid = false;
         if (timer && (r = timer->begin(s))) return r;
         static const size_t extra_lds = getenv("CSDR_EXTRA_LDS") ? (size_t)atol(getenv("CSDR_EXTRA_LDS")) : 0;   // occupancy experiments
-        if (v2) { if ((r = run256_v2_launch(&RA, c.fm, nruns, s))) return r; }
+        if (nb_full == 0) { /* shard, fewer than 16 frames: the tile kernel below does the whole call */ }
+        else if (v2) { if ((r = run256_v2_launch(&RA, c.fm, c.G, nruns, s))) return r; }
         else if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), extra_lds, s, RA);
         else hipLaunchKernelGGL(k_run256<false>, dim3(nruns), dim3(256), extra_lds, s, RA);
         if (timer && (r = timer->end(s))) return r;
@@ -920,18 +935,22 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
                                (float *)A.out, nf, RA.split, c.c0, c.C, c.fm_ref);
         const uint32_t rem = nf - nb_full * NB;
         if (rem) {
-            p->cur ^= 1;                                         // the tail starts from the run kernel's state
+            if (nb_full) p->cur ^= 1;                            // the tail starts from the run kernel's state
             TileArgs T = p->proto;
             T.x = call.d_in + (size_t)nb_full * NB * c.M; T.out = A.out; T.energy = A.energy; T.agc_alpha = A.agc_alpha;
+            if (shard) { T.c0 = 0; T.C = c.M; T.out = p->d_shard_tail; }   // whole band into [256][rem], the owned rows are gathered below
             T.yhist_in = p->d_yhist[p->cur]; T.yhist_out = p->d_yhist[p->cur ^ 1];
             T.vend_in = p->d_vend[p->cur];   T.vend_out = p->d_vend[p->cur ^ 1];
             T.rp_in = p->d_rp[p->cur];       T.rp_out = p->d_rp[p->cur ^ 1];
             if (++p->epoch == 0) p->epoch = 1;
             T.epoch = p->epoch; T.nf = rem; T.nb = 1; T.out_stride = nf; T.out_t0 = nb_full * NB;
+            if (shard) { T.out_stride = rem; T.out_t0 = 0; }
             T.parity0 = (uint32_t)((p->frames_done + nb_full * NB) & 1);
             CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
             if (c.fm) hipLaunchKernelGGL(k_tile256<true>, dim3(1), dim3(256), 0, s, T);
             else hipLaunchKernelGGL(k_tile256<false>, dim3(1), dim3(256), 0, s, T);
+            if (shard) hipLaunchKernelGGL(k_shard_gather, dim3(c.C), dim3(64), 0, s, (const float *)p->d_shard_tail, (float *)A.out, c.c0, c.G, rem,
+                                          nf, nb_full * NB, c.fm ? 1u : 2u);
         }
     } else {
         p->name = c.fm ? "k_tile256<FM>" : "k_tile256<CF32>";
@@ -977,7 +996,7 @@ int fused_status(FusedPlan *p, unsigned *status)
 void fused_destroy(FusedPlan *p)
 {
     if (!p) return;
-    void *ptrs[] = {p->d_tail[0], p->d_tail[1], p->d_tail[2], p->d_taps, p->d_tw, p->d_wpre, p->d_yhist[0], p->d_yhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0],
+    void *ptrs[] = {p->d_shard_tail, p->d_tail[0], p->d_tail[1], p->d_tail[2], p->d_taps, p->d_tw, p->d_wpre, p->d_yhist[0], p->d_yhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0],
                     p->d_rp[1], p->d_ticket, p->d_yflag, p->d_status, p->d_agg, p->d_ylast, p->d_premix, p->d_trace, p->d_yfirst};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;

@@ -42,6 +42,7 @@
 #endif
 
 #include "fused_v2_common.h"
+#include <type_traits>
 
 namespace csdr {
 namespace {
@@ -57,9 +58,18 @@ struct V2Args {
 
 // EN (FM only): also emit the energy words of the AGC mask pass.  The extra bases make hipcc spill SGPRs, so this variant's
 // asm stores carry their wait states (fused_v2_common.h); the plain variants stay spill-free and without them.
-template <bool FM, bool EN>
+// G > 1: INTERLEAVED CHANNEL SHARD g = A.c0 of G (rank g of G owns the channels g, g + G, ...; G | 16).  With
+// k = k1 + 16 k2 ownership only depends on k1, and W16^(a k1) = W16^(a g) W16^(a k1'), k1 = g + k1': the factor W16^(a g) is a
+// constant of polyphase branch j = 16 a + b1 and rides on its pre-mix phasor for free, after which the shard needs the pass-1
+// outputs k1' = 0, G, 2G, ... only (the radix-16 butterflies prune themselves: G is a template parameter), 16 / G rows of Z per
+// frame, and 256 / G radix-16 butterflies + 4096 / G freqdem samples + stores per tile in pass 2.  Those are spread over ALL
+// 256 threads: thread (q, f2), q = s NK1 + j1, takes row k1' = G j1 and the slice s of the 16 output slots, and the slice is
+// wave-uniform (G = 8: up to one lane bit), so that every wave runs a pass-2 butterfly pruned to its own quad of slots.
+template <bool FM, bool EN, int G>
 __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 {
+    static_assert(G == 1 || (!EN && (G == 2 || G == 4 || G == 8)), "interleaved shards: G = 2, 4, 8, no energy words");
+    constexpr int NK1 = 16 / G;                         // owned pass-1 rows per frame = output slots per slice
     const RunArgs &RA = VA.r;
     const TileArgs &A = RA.t;
     __shared__ __attribute__((aligned(16))) float2 L[V2_F2];
@@ -97,7 +107,15 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     float h[P];
 #pragma unroll
     for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j) + n * M256];
-    const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
+    float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
+    if (G > 1) {                                        // W16^(a g), a = j >> 4: one of the sixteen 16th roots of unity, exact constants
+        const int n = ((j >> 4) * (int)A.c0) & 15;
+        const float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+        const int m4 = n & 3, qd = n >> 2;              // W16^n = (-j)^qd (cos - j sin)(2 pi m4 / 16)
+        const float2 e = m4 == 0 ? make_float2(1.f, 0.f) : (m4 == 1 ? make_float2(C1, -S1) : (m4 == 2 ? make_float2(R2, -R2) : make_float2(S1, -C1)));
+        const float2 rot = qd == 0 ? e : (qd == 1 ? make_float2(e.y, -e.x) : (qd == 2 ? make_float2(-e.x, -e.y) : make_float2(-e.y, e.x)));
+        Wa = cmul(Wa, rot); Wb = cmul(Wb, rot);
+    }
     tw_s[tid] = A.tw[tid];
     float2 wa[NB], wb[NB];                              // FIR window halves: one holds the previous tile, the other the new one
 #pragma unroll
@@ -181,7 +199,12 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     for (int f = 3; f < NB; f++) wa[f] = cmul(wa[f], (f & 1) ? Wb : Wa);       // the window holds pre-mixed samples
     __syncthreads();                                    // every thread has read its run carries out of the stash area
     // freqdem history: stash[k1][i] = last Y frame of channel k1 + 16 XIDX(i)
-    ST[(tid & 15) * 16 + XIDX(tid >> 4)] = (FM && !cold) ? A.rp_in[tid] : make_float2(0.f, 0.f);
+    // (interleaved shard: rp_in / rp_out keep FULL-BAND indices, channel k = tid, so that the whole-band tile kernel can finish a
+    // ragged call; channel k = (g + G j1) + 16 k2 lives in slot i = XIDX(k2) of thread row q = (i / NK1) NK1 + j1)
+    const int st_i = XIDX(tid >> 4), st_j1 = ((tid & 15) - (int)(G > 1 ? A.c0 : 0u)) / G;
+    const bool st_own = G == 1 || ((((tid & 15) - (int)A.c0) & (G - 1)) == 0 && (tid & 15) >= (int)A.c0);
+    const int st_idx = G == 1 ? (tid & 15) * 16 + st_i : (st_own ? ((st_i / NK1) * NK1 + st_j1) * 16 + st_i : 0);
+    if (st_own) ST[st_idx] = (FM && !cold) ? A.rp_in[tid] : make_float2(0.f, 0.f);
     __syncthreads();                                    // H free; stash and twiddles visible
     if (FM && cold) {
         // The run's first freqdem sample needs the frame in front of it: the halo tile's last frame goes through the FIR and
@@ -202,15 +225,15 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             for (int a = 0; a < 16; a++) vv[a] = to_v(H[16 * a + tid]);
             fft16_v(vv);
 #pragma unroll
-            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + tid]));
+            for (int i = (G > 1 ? 0 : 1); i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * ((XIDX(i) + (G > 1 ? (int)A.c0 : 0)) & 15) + tid]));
 #pragma unroll
-            for (int i = 0; i < 16; i++) H[256 + 16 * XIDX(i) + tid] = to_f2(vv[i]);     // Z[k1][b1]
+            for (int i = 0; i < 16; i++) H[256 + 16 * XIDX(i) + tid] = to_f2(vv[i]);     // Z[k1'][b1], k1 = g + k1'
         }
         __syncthreads();
-        if (tid < 16) {
+        if (tid < 16) {                                 // thread row q = tid: pass-1 row k1' = G (q mod NK1); every slot is written, the row's own slice is read later
 #pragma unroll
-            for (int b = 0; b < 16; b++) vv[b] = to_v(H[256 + 16 * tid + b]);
-            fft16_v(vv);                                // vv[i] = Y[tid + 16 XIDX(i)]
+            for (int b = 0; b < 16; b++) vv[b] = to_v(H[256 + 16 * (G * (tid % NK1)) + b]);
+            fft16_v(vv);                                // vv[i] = Y[k1 + 16 XIDX(i)]
 #pragma unroll
             for (int i = 0; i < 16; i++) ST[tid * 16 + i] = to_f2(vv[i]);
         }
@@ -233,8 +256,11 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const unsigned x_a = (unsigned)f1 * 2048u + (unsigned)b1 * 8u;              // X[f1][16 a + b1]: (x_a ^ ((a >> 1) << 4)) + 128 a
     const unsigned zw_a = (unsigned)(f1 * 256 + ((((b1 >> 1) ^ (f1 & 7)) << 1) | (b1 & 1))) * 8u;   // Z[f1][k1][b1]: + 128 k1
     const unsigned z_a = (unsigned)(f2 * 256 + k1 * 16) * 8u + ((unsigned)(f2 & 7) << 4);           // pair i of Z[f2][k1][.]: z_a ^ (i << 4)
-    const uint32_t voff = ((uint32_t)k1 * A.out_stride + A.out_t0 + (uint32_t)f2) * (FM ? 4u : 8u);  // + 16 k2 rows, + 16 b frames
-    const size_t row16 = (size_t)16 * A.out_stride * (FM ? 4u : 8u);
+    // interleaved shard: thread row q = k1 = s NK1 + j1; output row of channel (g + G j1) + 16 k2 in the shard's [M / G][nf] plane: j1 + NK1 k2
+    const int j1 = k1 % NK1, hb = (G == 8) ? ((k1 >> 1) & 1) : 0;              // G = 8: lane bit of the slice (slots S0 + 2 hb, S0 + 2 hb + 1)
+    const unsigned z_a_g = (unsigned)(f2 * 256 + G * j1 * 16) * 8u + ((unsigned)(f2 & 7) << 4);
+    const uint32_t voff = ((uint32_t)(G == 1 ? k1 : j1 + 16 * hb) * A.out_stride + A.out_t0 + (uint32_t)f2) * (FM ? 4u : 8u);  // + NK1 k2 rows, + 16 b frames
+    const size_t row16 = (size_t)NK1 * A.out_stride * (FM ? 4u : 8u);
 #define V2STAMP(i) do { if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b_ * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
     // FM: the even tile of a pair keeps its 16 results per thread and the odd tile stores both, so that the two 64-byte halves of
@@ -340,18 +366,103 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 #pragma unroll
         for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B + (x_a ^ (unsigned)((a >> 1) << 4)) + 128 * a));
         if (!(V2_ABLATE & 16)) fft16_v(vv);
+        if (G == 1) {
 #pragma unroll
-        for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + b1]));
+            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + b1]));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++)                // rows k1' = 0, G, 2G, ... only; twiddle of the true k1 = g + k1'
+                if (XIDX(i) % G == 0) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * ((XIDX(i) + (int)A.c0) & 15) + b1]));
+        }
         V2STAMP(7);
         // no barrier here: Z[f1] goes into frame f1's own 2 KiB of the buffer, which only the 16 lanes that have just read
         // X[f1] (same wave, program order) ever touched since B_d
         if (V2_BAR_E) bar();
         V2STAMP(8);
 #pragma unroll
-        for (int i = 0; i < 16; i++) *reinterpret_cast<float2 *>(B + zw_a + 128 * XIDX(i)) = to_f2(vv[i]);
+        for (int i = 0; i < 16; i++)
+            if (XIDX(i) % G == 0) *reinterpret_cast<float2 *>(B + zw_a + 128 * XIDX(i)) = to_f2(vv[i]);
         V2STAMP(9);
         bar();                                          // B_f: Z complete
         V2STAMP(10);
+        if constexpr (G > 1) {
+            // ---- interleaved shard: pass 2 + tail of wave `Wv` (compile time): slots S0 .. S0 + NSL - 1 of row k1' = G j1
+            auto shard_tail = [&](auto WC) {
+                constexpr int Wv = decltype(WC)::value;
+                constexpr int S0 = (G == 2) ? 8 * (Wv >> 1) : 4 * Wv;
+                constexpr int NSL = (G == 2) ? 8 : 4;           // slots computed per thread (G = 8: the lane keeps two of the four)
+                constexpr int NS = (G == 8) ? 2 : NSL;          // slots demodulated and stored per thread
+                v2f vz[16];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const v4f v = *reinterpret_cast<const v4f *>(B + (z_a_g ^ (unsigned)(i << 4)));
+                    vz[2 * i] = (v2f){v.x, v.y}; vz[2 * i + 1] = (v2f){v.z, v.w};
+                }
+                fft16_v(vz);                                    // only slots S0 .. S0 + NSL - 1 are used: the rest of the butterfly is dead code
+                v2f y[NS];
+#pragma unroll
+                for (int u = 0; u < NS; u++) {
+                    if (G == 8) { y[u].x = hb ? vz[S0 + 2 + u].x : vz[S0 + u].x; y[u].y = hb ? vz[S0 + 2 + u].y : vz[S0 + u].y; }
+                    else y[u] = vz[S0 + u];
+                }
+                // slot u of mine is register slot S0 (+ 2 hb) + u: k2 = XIDX(slot); the lane part of the row (j1, hb) is in voff
+                float2 *stp = ST + k1 * 16 + S0 + (G == 8 ? 2 * hb : 0);
+                char *obase = reinterpret_cast<char *>(A.out) + (size_t)16 * b * (FM ? 4u : 8u);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile image (issued a tile ago)
+                if (FM) {
+                    float2 rp[NS], rr[NS];
+#pragma unroll
+                    for (int u = 0; u < NS; u += 2) {
+                        const v4f sp = *reinterpret_cast<const v4f *>(stp + u);      // previous tile's last frame (lane f2 = 0 uses it)
+                        rp[u] = make_float2(dpp_keep<0x111>(sp.x, y[u].x), dpp_keep<0x111>(sp.y, y[u].y));
+                        rp[u + 1] = make_float2(dpp_keep<0x111>(sp.z, y[u + 1].x), dpp_keep<0x111>(sp.w, y[u + 1].y));
+                        rr[u] = to_f2(y[u]); rr[u + 1] = to_f2(y[u + 1]);
+                    }
+                    float mq_[NS];
+                    float (&mq)[NS] = (V2_PAIR && par == 0) ? *reinterpret_cast<float (*)[NS]>(&hold[0]) : mq_;
+                    if (NS >= 4) {
+#pragma unroll
+                        for (int u = 0; u < NS; u += 4) {
+                            const float2 (&rp4)[4] = *reinterpret_cast<const float2 (*)[4]>(&rp[u]);
+                            const float2 (&rr4)[4] = *reinterpret_cast<const float2 (*)[4]>(&rr[u]);
+                            fm_quad(rp4, rr4, fk, *reinterpret_cast<float (*)[4]>(&mq[u]));
+                        }
+                    } else {
+                        const FmK k1s = {fk.tiny, fk.ref, fk.hp, fk.pi};
+#pragma unroll
+                        for (int u = 0; u < NS; u++) mq[u] = fm_sample(rp[u], rr[u], k1s);
+                    }
+                    if (!(V2_PAIR && par == 0 && b + 1 < last)) {
+#pragma unroll
+                        for (int u = 0; u < NS; u++) {
+                            // uniform part of the row: k2 of slot S0 + u without the lane's hb term (G = 8: XIDX(S0 + 2 hb + u) = Wv + 8 hb + 4 u)
+                            const char *rowp = obase + (size_t)XIDX(S0 + u) * row16;
+                            if (V2_PAIR && par == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:-64" :: "v"(voff), "v"(hold[u]), "s"(rowp) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
+                        }
+                    }
+                    if (f2 == 15) {
+#pragma unroll
+                        for (int u = 0; u < NS; u += 2) *reinterpret_cast<v4f *>(stp + u) = (v4f){y[u].x, y[u].y, y[u + 1].x, y[u + 1].y};
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < NS; u++) {
+                        const char *rowp = obase + (size_t)XIDX(S0 + u) * row16;
+                        asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 1" :: "v"(voff), "v"(y[u]), "s"(rowp) : "memory");
+                    }
+                }
+            };
+            if (G == 2) { if (wave_u < 2u) shard_tail(std::integral_constant<int, 0>{}); else shard_tail(std::integral_constant<int, 2>{}); }
+            else switch (wave_u) {
+                case 0: shard_tail(std::integral_constant<int, 0>{}); break;
+                case 1: shard_tail(std::integral_constant<int, 1>{}); break;
+                case 2: shard_tail(std::integral_constant<int, 2>{}); break;
+                default: shard_tail(std::integral_constant<int, 3>{}); break;
+            }
+            V2STAMP(14);
+            return;
+        }
         // ---- DFT pass 2: thread (k1, f2) reads its 16 consecutive Z values as eight 16-byte pairs
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -439,8 +550,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     V2LSTAMP(4);
     bar();                                              // stash of the last tile visible to every wave
     if (FM) {
-        const float2 lastY = ST[(tid & 15) * 16 + XIDX(tid >> 4)];
-        if (last == A.nb) A.rp_out[tid] = lastY;
+        const float2 lastY = ST[st_idx];
+        if (last == A.nb && st_own) A.rp_out[tid] = lastY;
     }
     if (last == A.nb && tid == 0) A.vend_out[0] = c;
 }
@@ -454,20 +565,28 @@ static V2Args make_v2(const void *run_args)
     return VA;
 }
 
-int run256_v2_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s)
+int run256_v2_launch(const void *run_args, bool fm, unsigned G, unsigned nruns, hipStream_t s)
 {
     const V2Args VA = make_v2(run_args);
-    if (fm && VA.r.t.energy) hipLaunchKernelGGL((k_run256v2<true, true>), dim3(nruns), dim3(256), 0, s, VA);
-    else if (fm) hipLaunchKernelGGL((k_run256v2<true, false>), dim3(nruns), dim3(256), 0, s, VA);
-    else hipLaunchKernelGGL((k_run256v2<false, false>), dim3(nruns), dim3(256), 0, s, VA);
+#define V2_LAUNCH(F, E, GG) hipLaunchKernelGGL((k_run256v2<F, E, GG>), dim3(nruns), dim3(256), 0, s, VA)
+    if (G == 1) {
+        if (fm && VA.r.t.energy) V2_LAUNCH(true, true, 1);
+        else if (fm) V2_LAUNCH(true, false, 1);
+        else V2_LAUNCH(false, false, 1);
+    } else if (VA.r.t.energy) { set_error("k_run256v2: no energy words from an interleaved shard"); return -1; }
+    else if (G == 2) { if (fm) V2_LAUNCH(true, false, 2); else V2_LAUNCH(false, false, 2); }
+    else if (G == 4) { if (fm) V2_LAUNCH(true, false, 4); else V2_LAUNCH(false, false, 4); }
+    else if (G == 8) { if (fm) V2_LAUNCH(true, false, 8); else V2_LAUNCH(false, false, 8); }
+    else { set_error("k_run256v2: interleaved shards of stride %u are not built (2, 4, 8)", G); return -1; }
+#undef V2_LAUNCH
     return 0;
 }
 
 int run256_v2_blocks_per_cu(bool fm)
 {
     int occ = 0;
-    if (fm) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<true, false>), 256, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<false, false>), 256, 0);
+    if (fm) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<true, false, 1>), 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<false, false, 1>), 256, 0);
     return occ < 1 ? 1 : occ;
 }
 

@@ -228,7 +228,8 @@ def test_chain_channel_shard_equals_slice_of_full():
     assert np.array_equal(part, full[8:20])
 
 
-@pytest.mark.parametrize("M,G,demod,agc,mix", [(256, 8, "fm", 0.0, False), (256, 2, "none", 0.0, False), (64, 4, "fm", 11.0, False),
+@pytest.mark.parametrize("M,G,demod,agc,mix", [(256, 8, "fm", 0.0, False), (256, 2, "none", 0.0, False), (256, 4, "fm", 0.0, False), (256, 2, "fm", 0.0, True),
+                                               (256, 8, "none", 0.0, False), (256, 4, "none", 0.0, True), (256, 8, "fm", 10.0, False), (64, 4, "fm", 11.0, False),
                                                (20, 4, "none", 0.0, False), (20, 2, "fm", 0.0, True), (4096, 8, "none", 0.0, True),
                                                (1024, 8, "fm", 0.0, False)])
 def test_chain_interleaved_shard_pruned_dft_equals_rows_of_full(M, G, demod, agc, mix):
@@ -245,7 +246,8 @@ def test_chain_interleaved_shard_pruned_dft_equals_rows_of_full(M, G, demod, agc
     acc = None
     for g in sorted({0, 1, G - 1}) if not mix else range(G):
         ch = cs.Chain(channels=M, demod=demod, kf=0.3, agc=agc, mix=mix, chan_first=g, chan_stride=G, max_frames=max(frames))
-        assert "pruned-dft" in ch.path
+        # M = 256 with stride 2, 4, 8: the fused run kernel's shard variant; every other shape the any-M route
+        assert ("interleaved-shard" in ch.path and "fused" in ch.path) if (M == 256 and G in (2, 4, 8)) else "pruned-dft" in ch.path
         got, pos = [], 0
         for f in frames:
             got.append(ch.process(x[pos * M:(pos + f) * M])); pos += f
@@ -557,7 +559,7 @@ def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["rccl_ranks"] == 2 and r["value"] > 0
     if shard == "channel":
-        assert r["scaling"] == "strong" and "channel-interleaved" in r["config"]["sharding"] and "pruned-dft" in r["config"]["path"]
+        assert r["scaling"] == "strong" and "channel-interleaved" in r["config"]["sharding"] and "interleaved-shard" in r["config"]["path"]
         assert ("all-reduce" in r["config"]["collective"]) == mix
     else:
         assert r["scaling"] == "weak" and "time stripes" in r["config"]["sharding"] and r["config"]["collective"] == "none"
@@ -1615,3 +1617,39 @@ def test_submit_device_independent_launches_match_serial_calls(demod):
         # |DC| = 0.094: the oracle's own f32 DC-blocker noise sets the floor (1.3e-5); the pipelined path must sit where the serial one does
         assert rel_rms(ga, want) < 1.05 * rel_rms(gb, want) + 1e-7 and rel_rms(ga, want) < 3e-5
         assert max_abs_err(ga, want) < 1e-4 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("G,demod", [(2, "fm"), (4, "none"), (8, "fm"), (8, "none")])
+def test_fused_interleaved_shard_run_sized_calls_match_whole_band(G, demod):
+    """k_run256v2<.., G> at run-kernel sizes (many runs with cold starts, paired F32 stores, ragged and tiny calls in between,
+    state carried from call to call): every shard g must reproduce the rows g, g + G, ... of the whole-band fused chain on the
+    same calls (same kernels upstream of pass 1, so FM agrees to the rounding of a differently pruned butterfly)."""
+    M, kf = 256, 0.3
+    frames = [40000, 5, 33, 40016, 16, 40001, 36864]
+    x = synth_cf32(M * sum(frames), M, seed=500 + G)
+    x = (x + np.complex64(0.03 + 0.02j)).astype(np.complex64)
+    full = cs.Chain(channels=M, demod=demod, kf=kf, max_frames=max(frames))
+    wf, pos = [], 0
+    for f in frames:
+        wf.append(full.process(x[pos * M:(pos + f) * M])); pos += f
+    wf = np.concatenate(wf, axis=1)
+    full.close()
+    for g in sorted({0, 1, G - 1}):
+        ch = cs.Chain(channels=M, demod=demod, kf=kf, chan_first=g, chan_stride=G, max_frames=max(frames))
+        assert "interleaved-shard" in ch.path
+        got, pos = [], 0
+        for f in frames:
+            got.append(ch.process(x[pos * M:(pos + f) * M])); pos += f
+        got = np.concatenate(got, axis=1)
+        ch.close()
+        want = wf[g::G]
+        assert got.shape == want.shape
+        if demod == "fm":
+            d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
+            tone = (np.arange(g, M, G) % 4) == 1
+            print(f"fused shard G={G} g={g} FM: median {np.median(d):.2e}, tone-channel max {d[tone].max() if tone.any() else 0:.2e}")
+            assert np.median(d) < 2e-6 and (not tone.any() or d[tone].max() < 1e-5)
+        else:
+            e = np.sqrt(np.mean(np.abs(got.astype(np.complex128) - want) ** 2)) / np.sqrt(np.mean(np.abs(wf) ** 2))
+            print(f"fused shard G={G} g={g} CF32: rel-rms (of the whole band) {e:.2e}")
+            assert e < 2e-6, e
