@@ -627,6 +627,7 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
     if (h->d_u) CSDR_HIP(hipMemsetAsync(h->d_u, 0, sizeof(float2) * (size_t)(h->p - 1) * h->M, s));
     if (h->d_u0hist) { CSDR_HIP(hipMemsetAsync(h->d_u0hist, 0, sizeof(float2) * 2 * (h->p - 1), s)); h->u0_cur = 0; }
     if (h->d_agc) { int r = launch_agc_init(h->d_agc, h->C, s); if (r) return r; }
+    if (h->agc_tail) agc_tail_reset(h->agc_tail);
     if (h->d_rp[0]) {
         CSDR_HIP(hipMemsetAsync(h->d_rp[0], 0, sizeof(float2) * h->C, s));
         CSDR_HIP(hipMemsetAsync(h->d_rp[1], 0, sizeof(float2) * h->C, s));

@@ -155,6 +155,7 @@ void agc_tail_destroy(AgcTailPlan *p);
 int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32_t nf, AgcState *st, const AgcParams &prm,
                      float fm_ref, const float2 *rp_in, float2 *rp_out, hipStream_t s);
 int agc_tail_stats(AgcTailPlan *p, unsigned *checked, unsigned *redone);
+void agc_tail_reset(AgcTailPlan *p);     // the AGC state was re-initialised: the next call pilots (kernels_agc_tail.hip)
 
 // ---- AGC + squelch behind an FM chain as a mask pass over 4-byte energy words (kernels_agc_mask.hip) ----
 struct AgcMaskPlan;

@@ -94,6 +94,7 @@ struct TailArgs {
     const float2 *Z;        // [C][nf] channelizer output
     void *out;              // [C][nf] CF32 or F32
     const AgcState *st_in;  // [C] state before the call
+    const AgcState *st_spec;// [C] state the speculative warm-ups start from: st_in, except on a stream's first call (k_agc_pilot)
     const float2 *rp_in;    // [C] freqdem r' before the call (FM)
     AgcSeg *seg_start, *seg_end;   // [C][nseg]
     uint32_t C, nf, L, W, nseg;
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec(TailArgs A, uint32_t groups
     const uint32_t endv = mine ? min(A.nf, sg * A.L + A.L) : 0u;
     AgcSeg q;
     {
-        const AgcState s0 = A.st_in[c];
+        // segments that begin <= W samples into the call run from sample 0 and from the TRUE state; the others warm up from st_spec
+        const AgcState s0 = ((uint64_t)sg * A.L > A.W) ? A.st_spec[c] : A.st_in[c];
         q.g = s0.g; q.y2 = s0.y2; q.mode = (int32_t)s_encode(s0.mode, s0.timer); q.timer = 0;
         const float2 r0 = FM ? A.rp_in[c] : make_float2(0.f, 0.f);
         q.rx = r0.x; q.ry = r0.y; q.pad0 = q.pad1 = 0;
@@ -405,6 +407,33 @@ __device__ __forceinline__ void repair_segment(const TailArgs &A, uint32_t c, ui
     for (; t < t1; t++) one(row[t], t);
 }
 
+// A stream's first call starts from the reference's create-time state (g = 1000, Liquid.chs:707-717), which 1024 samples of
+// warm-up do not forget: every speculative segment would fail its boundary check and the exact repair would recompute the whole
+// call in rounds (80 ms at the bench size).  The pilot runs the recurrence over the first `n` samples of every channel once, one
+// lane per channel, output discarded: the state it reaches is SETTLED, and that is all a warm-up needs to start from (the
+// verification in k_agc_fix keeps the result exact whatever the speculation started from).
+__global__ __launch_bounds__(64) void k_agc_pilot(TailArgs A, uint32_t n, AgcState *st_spec)
+{
+    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    if (c >= A.C) return;
+    const AgcState s0 = A.st_in[c];
+    AgcSeg cur; cur.g = s0.g; cur.y2 = s0.y2; cur.mode = (int32_t)s_encode(s0.mode, s0.timer); cur.timer = 0; cur.rx = cur.ry = 0.f; cur.pad0 = cur.pad1 = 0;
+    const size_t rowo = (size_t)c * A.nf;
+    const float2 *row = A.Z + rowo;
+    uint32_t t = 0;
+    if ((rowo & 1) && t < n) { (void)agc_tail_step(row[t], cur, A.p); t++; }
+    for (; t + 16 <= n; t += 16) {
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const float4 *>(row + t + 2 * i);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { (void)agc_tail_step(make_float2(v[i].x, v[i].y), cur, A.p); (void)agc_tail_step(make_float2(v[i].z, v[i].w), cur, A.p); }
+    }
+    for (; t < n; t++) (void)agc_tail_step(row[t], cur, A.p);
+    AgcState o; o.g = cur.g; o.y2 = cur.y2; s_decode((uint32_t)cur.mode, A.p.timeout, o.mode, o.timer);
+    st_spec[c] = o;
+}
+
 template <bool FM>
 __global__ __launch_bounds__(256) void k_agc_fix(TailArgs A, AgcState *st_out, float2 *rp_out, unsigned *stats)
 {
@@ -446,7 +475,9 @@ __global__ __launch_bounds__(256) void k_agc_fix(TailArgs A, AgcState *st_out, f
 struct AgcTailPlan {
     uint32_t C = 0, max_nf = 0, L = 0, Lmin = 384, W = 1024, max_seg = 0;   // L > 0: fixed by CSDR_AGC_L
     AgcSeg *d_start = nullptr, *d_end = nullptr;
-    AgcState *d_st_tmp = nullptr;
+    AgcState *d_st_tmp = nullptr;    // [C] settled state of the pilot (first call of a stream)
+    bool fresh = true;               // the AGC state is the create-time one: the next call runs the pilot
+    uint32_t pilot_n = 4096;
     unsigned *d_stats = nullptr;
     uint32_t wg_slots = 1024;            // workgroups the device holds at once
 };
@@ -487,6 +518,8 @@ void agc_tail_destroy(AgcTailPlan *p)
     delete p;
 }
 
+void agc_tail_reset(AgcTailPlan *p) { if (p) p->fresh = true; }
+
 int agc_tail_stats(AgcTailPlan *p, unsigned *checked, unsigned *redone)
 {
     unsigned h[2] = {0, 0};
@@ -520,6 +553,13 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     TailArgs A{};
     A.Z = Z; A.out = out; A.st_in = st; A.rp_in = rp_in; A.seg_start = p->d_start; A.seg_end = p->d_end;
     A.C = p->C; A.nf = nf; A.L = L; A.W = p->W; A.nseg = nseg; A.p = prm; A.ref = fm_ref;
+    A.st_spec = st;
+    if (p->fresh && nseg > 1) {
+        const uint32_t n = nf < p->pilot_n ? nf : p->pilot_n;
+        hipLaunchKernelGGL(k_agc_pilot, dim3((p->C + 63u) / 64u), dim3(64), 0, s, A, n, p->d_st_tmp);
+        A.st_spec = p->d_st_tmp;
+    }
+    if (nf >= p->pilot_n) p->fresh = false;      // (a stream that starts with short calls keeps piloting: each is cheap)
     // PAIRS: nf even, so every row starts on a 16-byte boundary and ends on one (t is always even): a piece is one
     // 16-byte load that never reaches past the buffer
     const bool pairs = (nf & 1u) == 0 && (uint64_t)p->C * nf >= 2;

@@ -920,6 +920,8 @@ def test_agc_tail_steady_state_needs_no_recompute():
     c1, r1 = a.agc_stats()
     print(f"agc tail steady state: first call {r0}/{c0} recomputed, next two {r1 - r0}/{c1 - c0}")
     assert c1 > c0 and (r1 - r0) <= (c1 - c0) // 100
+    # the first call of a stream pilots the create-time transient (k_agc_pilot): its speculation verifies like any other call's
+    assert r0 <= c0 // 50, (r0, c0)
     a.close()
 
 
@@ -1490,11 +1492,12 @@ def _bench_layout(M, nf, seed, **kw):
     return got, xh, kname, path
 
 
-def _fm_against_oracle(got, xh, M, kf, label):
-    """The tolerances of test_chain_fm_matches_oracle on a whole bench-sized chunk."""
+def _fm_against_oracle(got, xh, M, kf, label, r):
+    """The tolerances of test_chain_fm_matches_oracle on a whole bench-sized chunk.  r: |channel samples| (only weights the
+    phase errors: taken from the product's own DeNo run of the same chunk, which the cfg2 / DeNo tests pin to the oracle, to
+    save a second 67 M-sample oracle pass)."""
     ref = 1.0 / (2 * np.pi * kf)
     want = O.Chain(M, demod="fm", kf=kf).process(xh)
-    r = np.abs(O.Chain(M).process(xh))
     assert got.shape == want.shape == r.shape
     rmax = float(r.max())
     worst_w, worst_s, med = 0.0, 0.0, []
@@ -1519,7 +1522,8 @@ def test_bench_layout_cfg3_256ch_fm_whole_chunk_matches_oracle():
     M, nf, kf = 256, 262144, 0.3
     got, xh, kname, path = _bench_layout(M, nf, 31, demod="fm", kf=kf)
     assert kname == "k_run256v2<FM>", (kname, path)
-    _fm_against_oracle(got, xh, M, kf, f"cfg3 {kname}")
+    r = np.abs(_bench_layout(M, nf, 31)[0])
+    _fm_against_oracle(got, xh, M, kf, f"cfg3 {kname}", r)
 
 
 def test_bench_layout_cfg2_64ch_deno_whole_chunk_matches_oracle():
@@ -1538,7 +1542,8 @@ def test_bench_layout_cfg4_shape_1024ch_fm_whole_chunk_matches_oracle():
     M, nf, kf = 1024, 65536, 0.3
     got, xh, kname, path = _bench_layout(M, nf, 33, demod="fm", kf=kf)
     assert kname == "k_run1024v2<FM>", (kname, path)
-    _fm_against_oracle(got, xh, M, kf, f"cfg4 shape {kname}")
+    r = np.abs(_bench_layout(M, nf, 33)[0])
+    _fm_against_oracle(got, xh, M, kf, f"cfg4 shape {kname}", r)
 
 
 def test_bench_layout_cfg5_shape_4096ch_mix_identity_whole_chunk_matches_oracle_and_full_bank():
@@ -1596,27 +1601,27 @@ def test_submit_device_independent_launches_match_serial_calls(demod):
     n_indep = a.independent_launches()
     print("independent launches:", n_indep, "of", len(frames))
     assert n_indep == 5                                   # chunks 0 (fresh stream: zero history), 1, 4, 7, 8; 2 is small, 3 the serial call, 5 ragged, 6 follows the ragged one
-    orc = O.Chain(M, demod=demod, kf=kf)
-    want = orc.process(x)
     ga = np.concatenate([o.cpu().numpy().reshape(M, -1) for o in outs_a], axis=1)
     gb = np.concatenate([o.cpu().numpy().reshape(M, -1) for o in outs_b], axis=1)
     a.close(); b.close()
+    n_or = sum(frames[:3])                                 # the oracle on the first three calls (two independent launches and a small one)
+    want = O.Chain(M, demod=demod, kf=kf).process(x[: M * n_or])
     if demod == "fm":
         d = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / kf))
-        do = np.abs(wrap_pm(ga.astype(np.float64) - want, 1.0 / kf))
+        do = np.abs(wrap_pm(ga[:, :n_or].astype(np.float64) - want, 1.0 / kf))
         print(f"pipelined vs serial FM: tone channels max {d[1::4].max():.3e}, median {np.median(d):.3e}; vs oracle tone p99.9 {np.quantile(do[1::4], 0.999):.3e}")
         assert d[1::4].max() < 5e-6 and np.median(d) < 5e-6
         # the fixture's |DC| = 0.094 puts the oracle's own f32 DC-blocker noise (ulp(|v|) / 2 at |v| = 190) into the weak
         # channels' phases: the all-channel median is bounded by what the serial path shows against the same oracle
-        ds = np.abs(wrap_pm(gb.astype(np.float64) - want, 1.0 / kf))
+        ds = np.abs(wrap_pm(gb[:, :n_or].astype(np.float64) - want, 1.0 / kf))
         assert np.quantile(do[1::4], 0.999) < 2e-5 and np.median(do) < 1.05 * np.median(ds) + 1e-7
     else:
         ga, gb = ga.view(np.complex64), gb.view(np.complex64)
-        print(f"pipelined vs serial CF32: rel-rms {rel_rms(ga, gb):.3e}; vs oracle {rel_rms(ga, want):.3e}")
+        print(f"pipelined vs serial CF32: rel-rms {rel_rms(ga, gb):.3e}; vs oracle {rel_rms(ga[:, :n_or], want):.3e}")
         assert rel_rms(ga, gb) < 1e-6
         # |DC| = 0.094: the oracle's own f32 DC-blocker noise sets the floor (1.3e-5); the pipelined path must sit where the serial one does
-        assert rel_rms(ga, want) < 1.05 * rel_rms(gb, want) + 1e-7 and rel_rms(ga, want) < 3e-5
-        assert max_abs_err(ga, want) < 1e-4 * np.abs(want).max()
+        assert rel_rms(ga[:, :n_or], want) < 1.05 * rel_rms(gb[:, :n_or], want) + 1e-7 and rel_rms(ga[:, :n_or], want) < 3e-5
+        assert max_abs_err(ga[:, :n_or], want) < 1e-4 * np.abs(want).max()
 
 
 @pytest.mark.parametrize("G,demod", [(2, "fm"), (4, "none"), (8, "fm"), (8, "none")])
