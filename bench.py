@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agc-variant", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--preheat-ms", type=float, default=60.0,
+                    help="untimed load in front of the W warm-up steps (the same step, repeated for this long): the board's clock / power "
+                         "state needs tens of ms of load to settle, a 25-launch run (6 ms) sits entirely inside that transient "
+                         "(tools/short_run_time.py: 300 us per step cold, 232 us settled); 0 = off")
     return ap.parse_args()
 
 
@@ -145,9 +149,9 @@ def main():
     # channel shards: every rank sees the SAME stream (in production: broadcast over xGMI) and owns channels rank, rank + N, ...
     xs = [synth_cf32_torch(nx, M, dev, seed=20260101 + 7919 * (2 * (0 if chan else rank) + i)) for i in range(2)]
     out = torch.empty(M * nf * out_elem // 4, dtype=torch.float32, device=dev)
-    # one hipEvent pair around the K timed launches of the dominant kernel, on their stream (a pair per launch costs the stream
-    # a few us each); the multi-kernel channel-shard route keeps the pair per launch, which brackets the one kernel it names
-    flags = _lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS | (0 if (a.shard == "channel" and int(os.environ.get("WORLD_SIZE", "1")) > 1) else _lib.FLAG_TIME_REGION)
+    # a hipEvent pair around every launch of the dominant kernel, on its stream (CSDR_FLAG_TIME_REGION would time the K launches
+    # as one region instead: that figure contains the start-up latency of the first launch after the barrier, 7 us per launch at K = 20)
+    flags = _lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS
     if chan:
         from composable_sdr_amd.pipes import ChainConfig
         from composable_sdr_amd.sharded import ShardedChain
@@ -171,10 +175,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    preheat_steps = 0
+    if a.preheat_ms > 0:                        # not part of W or K: load until the clocks have settled (reported as config.preheat_steps)
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < a.preheat_ms * 1e-3:
+            for i in range(10):
+                step(i)
+            torch.cuda.synchronize()
+            preheat_steps += 10
     for i in range(a.warmup):
         step(i)
     barrier()
-    chain.kernel_time()                         # drop warm-up launches
+    chain.kernel_time()                         # drop pre-heat and warm-up launches
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
@@ -254,7 +266,7 @@ def main():
                                f"AGC {'off (-a 0)' if a.agc == 0 else a.agc}, {nf} frames/step "
                                f"({nx * 8 / 2**20:.0f} MiB in, {M * nf * out_elem / 2**20:.0f} MiB out), HBM-resident",
                    "channels": M, "frames_per_step": nf, "demod": a.demod, "kf": a.kf, "agc_db": a.agc, "mix": bool(a.mix),
-                   "path": chain.path,
+                   "path": chain.path, "preheat_steps": preheat_steps,
                    "sharding": ("none" if world == 1 else
                                 (f"channel-interleaved: rank g owns channels g + {world} m, pruned DFT (fold + {M // world}-point)" if chan
                                  else "time stripes, 1 per rank")),
@@ -275,7 +287,7 @@ def main():
         # writes channel-major CF32, the time-parallel verified AGC tail (bit-identical to the sequential
         # recurrence) adds squelch + freqdem
         ch2 = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=10.0, max_frames=nf, device=local, flags=_lib.FLAG_QUIET)
-        for i in range(3):
+        for i in range(3 + (40 if a.preheat_ms > 0 else 0)):
             ch2.process_device(xs[i & 1].data_ptr(), nx, out.data_ptr(), stream)
         torch.cuda.synchronize()
         c0, r0 = ch2.agc_stats()
