@@ -729,7 +729,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     // With the AGC on, the fused kernel stops at the channel-major CF32 samples and the
     // exactly-sequential per-channel AGC tail (one lane per channel) + freqdem + mix follow.
     // interleaved shards: the fused M = 256 chain takes strides 2, 4, 8 (k_run256v2<.., G>); every other shape the any-M route with a pruned DFT
-    const bool want_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && (G == 1 || (fused_supported(M, h->p) && (G == 2 || G == 4 || G == 8) && !getenv("CSDR_SHARD_GENERIC")));
+    const bool want_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && (G == 1 || ((fused_supported(M, h->p) || big_supported(M, h->p)) && (G == 2 || G == 4 || G == 8) && !getenv("CSDR_SHARD_GENERIC")));
     h->use_fused = want_fused && (fused_supported(M, h->p) || small_supported(M, h->p) || (big_supported(M, h->p) && !getenv("CSDR_NO_RUN1024")));
     if (h->use_fused) {
         const bool agc_on = cfg->agc_threshold_db != 0.0f;
@@ -751,7 +751,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             h->timed_kernel = small_name(h->small);
         } else if (big_supported(M, h->p)) {
             if ((r = big_create(fc, &h->big))) return fail(r);
-            h->path = std::string("fused-") + big_name(h->big) + (agc_on ? "+agc" : "");
+            h->path = std::string("fused-") + big_name(h->big) + (G > 1 ? "+interleaved-shard" : "") + (agc_on ? "+agc" : "");
             h->timed_kernel = big_name(h->big);
         } else {
             if ((r = fused_create(fc, &h->fused))) return fail(r);

@@ -77,6 +77,7 @@ struct Run64v2Host {
     const float *taps; const float2 *tw, *wpre;
     const float2 *uhist_in; float2 *uhist_out; const float2 *vend_in; float2 *vend_out;
     uint32_t nf, nruns, parity0;
+    uint32_t G = 1, g = 0;      // interleaved shard g of G (tables rotated by the plan)
     bool dc_block;
     double beta;
 };
@@ -91,6 +92,7 @@ struct Run1024v2Host {
     const float2 *uhist_in; float2 *uhist_out; const float2 *vend_in; float2 *vend_out; const float2 *rp_in; float2 *rp_out;
     char *stage;                // [nruns] output staging blocks of 128 KiB
     uint32_t nf, nruns, parity0;
+    uint32_t G = 1, g = 0;      // interleaved shard g of G (tables rotated by the plan)
     bool dc_block;
     double beta;
     float fm_ref;

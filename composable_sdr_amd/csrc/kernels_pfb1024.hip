@@ -445,6 +445,14 @@ int launch_pfb1024(const float2 *u_new, const float *taps, const float2 *tw, voi
 // k_run1024: the same kernel with the DC blocker and the NCO pre-mix fused in (DC = true) -- the whole chain of
 // assembleFold for -c 1024 in one launch per chunk, same call interface as the M = 256 / 64 run kernels (fused.h)
 // ---------------------------------------------------------------------------------------------
+// interleaved shard: row m = j + (16/G) k2 + (256/G) k3 of the shard's plane <- row G j + 16 k2 + 256 k3 of the whole primed band (w floats per sample)
+__global__ __launch_bounds__(256) void k_shard_gather1024(const float *__restrict__ src, float *__restrict__ dst, uint32_t G, uint32_t nf, uint32_t w)
+{
+    const uint32_t m = blockIdx.x, n1 = 16u / G, j = m % n1, k2 = (m / n1) & 15u, k3 = m / (16u * n1);
+    const size_t so = (size_t)(G * j + 16u * k2 + 256u * k3) * nf * w, dn = (size_t)m * nf * w;
+    for (size_t i = threadIdx.x; i < (size_t)nf * w; i += 256) dst[dn + i] = src[so + i];
+}
+
 struct BigPlan {
     FusedConfig cfg;
     uint32_t cus = 256;
@@ -456,6 +464,7 @@ struct BigPlan {
     float2 *d_uhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
     float2 *d_scratch = nullptr;     // yfirst | ylast
     char *d_stage = nullptr;         // k_run1024v2: 128 KiB of output staging per run
+    void *d_full = nullptr;          // interleaved shard, calls k_run1024v2 does not take: whole-band result [1024][max_nf] (allocated on first use)
     void *d_premix = nullptr;
     int cur = 0;
 };
@@ -466,7 +475,7 @@ void big_destroy(BigPlan *p)
 {
     if (!p) return;
     void *ptrs[] = {p->d_taps, p->d_taps_t, p->d_taps_q, p->d_tw, p->d_wpre, p->d_uhist[0], p->d_uhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0], p->d_rp[1],
-                    p->d_scratch, p->d_premix, p->d_stage};
+                    p->d_scratch, p->d_premix, p->d_stage, p->d_full};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -491,7 +500,7 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
     for (int i = 0; i < 2; i++) {
         ALLOC(p->d_uhist[i], sizeof(float2) * 13 * PM);
         ALLOC(p->d_vend[i], sizeof(float2));
-        ALLOC(p->d_rp[i], sizeof(float2) * cfg.C);
+        ALLOC(p->d_rp[i], sizeof(float2) * (cfg.G > 1 ? (uint32_t)PM : cfg.C));     // interleaved shard: indexed by the primed channel k'
     }
     ALLOC(p->d_scratch, sizeof(float2) * 2 * (size_t)p->cus * PM);
     ALLOC(p->d_stage, (size_t)(2 * p->cus) * 131072u);
@@ -512,6 +521,15 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         float c, sn;
         nco_phasor(i * cfg.d_theta, &c, &sn);
         wpre[i] = make_float2(c, -sn);
+        if (cfg.G > 1) {
+            // interleaved shard g = c0 of G: a shift of the whole spectrum by g channels, W1024^(r g) on branch r, rides on the branch's
+            // pre-mix phasor for free (the FIR is linear): every kernel of the plan then sees the PRIMED spectrum Y'[k'] = Y[k' + g],
+            // of which the shard owns the rows k' = 0 mod G
+            const int n = (int)(((i & (uint32_t)(PM - 1)) * cfg.c0) & (uint32_t)(PM - 1));
+            const double a = -2.0 * 3.14159265358979323846 * (double)n / (double)PM;
+            const double wr = std::cos(a), wi = std::sin(a), xr = wpre[i].x, xi = wpre[i].y;
+            wpre[i] = make_float2((float)(xr * wr - xi * wi), (float)(xr * wi + xi * wr));
+        }
     }
     CSDR_HIP(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice));
     CSDR_HIP(hipMemcpy(p->d_wpre, wpre.data(), sizeof(float2) * wpre.size(), hipMemcpyHostToDevice));
@@ -531,6 +549,7 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         // CF32 output (DeNo, AGC / AM tails) stays with k_run1024: staged through HBM twice, k_run1024v2<CF32> moves 2.3 GB per
         // 67 M samples and takes 405-415 us against 384 us (FM: 366 against 454); CSDR_RUN1024_V2_ALL=1 selects it anyway
         p->v2_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && !getenv("CSDR_RUN1024_V1") && (cfg.fm || getenv("CSDR_RUN1024_V2_ALL"));
+        if (cfg.G > 1) p->v2_ok = cfg.fm && !getenv("CSDR_RUN1024_V1");       // k_run1024v2<FM, G>; CF32 shards: whole band + row gather (below)
     }
     *out = p;
     return 0;
@@ -542,7 +561,7 @@ int big_reset(BigPlan *p, hipStream_t s)
     for (int i = 0; i < 2; i++) {
         CSDR_HIP(hipMemsetAsync(p->d_uhist[i], 0, sizeof(float2) * 13 * PM, s));
         CSDR_HIP(hipMemsetAsync(p->d_vend[i], 0, sizeof(float2), s));
-        CSDR_HIP(hipMemsetAsync(p->d_rp[i], 0, sizeof(float2) * p->cfg.C, s));
+        CSDR_HIP(hipMemsetAsync(p->d_rp[i], 0, sizeof(float2) * (p->cfg.G > 1 ? (uint32_t)PM : p->cfg.C), s));
     }
     return 0;
 }
@@ -570,6 +589,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.rp_in = p->d_rp[p->cur]; H.rp_out = p->d_rp[p->cur ^ 1];
         H.stage = p->d_stage;
         H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
+        H.G = c.G; H.g = c.G > 1 ? c.c0 : 0u;
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
         if ((r = run1024_v2_launch(H, c.fm, s, timer))) return r;
         p->cur ^= 1;
@@ -582,10 +602,17 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     Pfb1024Args A{};
     A.u = call.d_in; A.taps = p->d_taps; A.taps_t = p->d_taps_t; A.tw = p->d_tw; A.wpre = p->d_wpre;
     A.out = c.mix ? p->d_premix : call.d_out;
+    const bool shard = c.G > 1;
+    if (shard) {
+        // an interleaved shard's call that k_run1024v2<FM, G> does not take (CF32 output, ragged or short call): the whole primed
+        // band through k_run1024 into scratch, then the owned rows k1' = 0 mod G are gathered into the shard's plane
+        if (!p->d_full) { hipError_t e = hipMalloc(&p->d_full, (size_t)PM * c.max_nf * (c.fm ? 4 : 8)); if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__); }
+        A.out = p->d_full;
+    }
     A.rp_in = p->d_rp[p->cur]; A.rp_out = p->d_rp[p->cur ^ 1];
     A.vend_in = p->d_vend[p->cur]; A.vend_out = p->d_vend[p->cur ^ 1];
     A.uhist_in = p->d_uhist[p->cur]; A.uhist_out = p->d_uhist[p->cur ^ 1];
-    A.nf = nf; A.nb = (nf + PT - 1) / PT; A.c0 = c.c0; A.C = c.C; A.ref = c.fm_ref;
+    A.nf = nf; A.nb = (nf + PT - 1) / PT; A.c0 = shard ? 0u : c.c0; A.C = shard ? (uint32_t)PM : c.C; A.ref = c.fm_ref;
     A.parity0 = (uint32_t)(p->frames_done & 1);
     const double beta = c.dc_block ? (double)c.dc.beta : 0.0;
     A.alpha = c.dc_block ? (float)(1.0 - beta) : 0.0f;
@@ -603,6 +630,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     else hipLaunchKernelGGL((k_pfb1024<false, true>), dim3(nruns), dim3(1024), 0, s, A);
     if (timer && (r = timer->end(s))) return r;
     if (c.fm && nruns > 1) hipLaunchKernelGGL(k_pfb1024_fixup, dim3(nruns - 1), dim3(1024), 0, s, A);
+    if (shard) hipLaunchKernelGGL(k_shard_gather1024, dim3(c.C), dim3(256), 0, s, (const float *)p->d_full, (float *)(c.mix ? p->d_premix : call.d_out), c.G, nf, c.fm ? 1u : 2u);
     CSDR_HIP(hipGetLastError());
     p->cur ^= 1;
     p->frames_done += nf;

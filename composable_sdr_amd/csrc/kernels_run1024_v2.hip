@@ -68,6 +68,7 @@ struct Run1024v2Args {
     const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r'
     char *stage;                // [nruns] staging blocks of 128 KiB
     uint32_t nf, nb, nruns, n0, parity0, out_stride;   // n0: tiles of the first half of the runs (0: even split)
+    uint32_t g;                 // G > 1: shard index (informational: the tables carry the shift by g channels, see the kernel)
     float alpha, beta, l2beta, fm_ref, tiny;
     float b16[16];              // beta^(16 r)
     float b256[17];             // beta^(256 g)
@@ -90,9 +91,19 @@ __host__ __device__ __forceinline__ void run_bounds(uint32_t nb, uint32_t nruns,
     last = base + (unsigned)((unsigned long long)(i + 1) * tiles / half);
 }
 
-template <bool FM>
+// G > 1: INTERLEAVED CHANNEL SHARD g of G (G = 2, 4, 8; FM output).  The host folds a shift of the spectrum by g channels,
+// W1024^(r g) on branch r, into the pre-mix phasors of the tap table (free: the FIR is linear), so that this kernel -- and the
+// whole-band kernels of the same plan -- see Y'[k'] = Y[k' + g] and the shard owns k' = k1' + 16 k2 + 256 k3 with k1' = 0 mod G:
+// it wants the pass-1 rows k1' = 0, G, 2G, ... only (the butterfly prunes itself: G is a template parameter), pass 2 runs
+// in the lanes of those rows, pass 3 + freqdem in the threads kk = k1' + 16 k2 with k1' = 0 mod G, and every state array of the
+// plan (freqdem history, window) is indexed by the PRIMED channel k' = k1' + 16 k2 + 256 k3, as the whole-band kernels see it
+// behind the same tables.  Output: the shard's own [1024 / G][nf] plane, row k1'/G + (16/G) k2 + (256/G) k3, 16-byte pieces stored
+// directly: 512 workgroups x 1024/G rows keep 64/G MiB of lines open, which the L2s hold for G = 8 and mostly for G = 4 (the
+// staging block of the whole-band path exists because 64 MiB are not held).
+template <bool FM, int G>
 __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
 {
+    static_assert(G == 1 || (FM && (G == 2 || G == 4 || G == 8)), "interleaved shards: F32 output, G = 2, 4, 8");
     __shared__ __attribute__((aligned(16))) float2 L[B2_F2];
     float2 *tw1 = L + B2_TW1, *ST = L + B2_ST, *Tt = L + B2_TT, *red = ST;
     const int tid = threadIdx.x, j = tid;
@@ -329,11 +340,19 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
 #pragma unroll
         for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B + fb + 512 * a + (x_a ^ (unsigned)((a & 3) << 5))));
         fft16_v(vv);
+        if (G == 1) {
 #pragma unroll
-        for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (XIDX(i) - 1) + b1]));
+            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (XIDX(i) - 1) + b1]));
+        } else {
 #pragma unroll
-        for (int i = 0; i < 16; i++) *reinterpret_cast<float2 *>(B + fb + 512 * XIDX(i) + (z1w ^ (unsigned)(((2 * XIDX(i)) & 6) << 4))) = to_f2(vv[i]);
-        // ---- DFT pass 2: same wave, lane (k1, d): radix 16 over c (b = 4 c + d)
+            for (int i = 1; i < 16; i++)                // rows k1' = 0 mod G only (the spectrum arrives shifted by g: see the tables)
+                if (XIDX(i) % G == 0) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (XIDX(i) - 1) + b1]));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (XIDX(i) % G == 0) *reinterpret_cast<float2 *>(B + fb + 512 * XIDX(i) + (z1w ^ (unsigned)(((2 * XIDX(i)) & 6) << 4))) = to_f2(vv[i]);
+        // ---- DFT pass 2: same wave, lane (k1, d): radix 16 over c (b = 4 c + d); a shard's lanes of the rows it did not write sit it out
+        if (G == 1 || ((l2 >> 2) % G) == 0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const v4f v = *reinterpret_cast<const v4f *>(B + (z1r ^ (unsigned)(i << 4)));
@@ -347,8 +366,10 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
 #pragma unroll
         for (int i = 0; i < 16; i++) *reinterpret_cast<float2 *>(B + z2w_t + 512 * XIDX(i)) = to_f2(vv[i]);
         }
+        }
         bar();                                          // B_h: Z2 of all four frames complete
         // ---- DFT pass 3 + tail: thread kk = k1 + 16 k2, all four frames; Y[f][k3] = channel kk + 256 k3
+        if (G > 1 && ((tid & 15) % G) != 0) return;      // shard: threads of the rows it does not own are done (no barrier follows on this path)
         v2f y[4][4];
 #pragma unroll
         for (int f = 0; f < 4; f++) {
@@ -395,6 +416,12 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
                 const char *sp = sbase + k3 * (256 * 16);
                 const char *rowp = reinterpret_cast<const char *>(A.out) + (size_t)4 * b * esz + (size_t)k3 * 256 * A.out_stride * esz;
                 if (B2_ABLATE & 2) asm volatile("" :: "v"(mv), "s"(sp));
+                else if (G > 1) {
+                    // row of (k1', k2, k3) in the shard's plane: k1'/G + (16/G) k2 + (256/G) k3; the k3 and frame terms are uniform
+                    const unsigned mrow = ((unsigned)(tid & 15) / (unsigned)G + (16u / (unsigned)G) * ((unsigned)tid >> 4)) * A.out_stride * esz;
+                    const char *rowg = reinterpret_cast<const char *>(A.out) + (size_t)4 * b * esz + (size_t)k3 * (256 / G) * A.out_stride * esz;
+                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"(mrow), "v"(mv), "s"(rowg) : "memory");
+                }
                 else if (B2_DIRECT) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(mv), "s"(rowp) : "memory");
                 else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"(joff_t), "v"(mv), "s"(sp) : "memory");
             }
@@ -416,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             }
         }
         // ---- a block is complete (or the run ends): every row's 128 bytes leave in one piece
-        if ((ts == TB - 1u || b + 1 == last) && !(B2_ABLATE & (2 | 1024)) && !B2_DIRECT) {
+        if (G == 1 && (ts == TB - 1u || b + 1 == last) && !(B2_ABLATE & (2 | 1024)) && !B2_DIRECT) {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // the workgroup's staging stores are in L2 (one CU: same L1)
             typedef unsigned v4u __attribute__((ext_vector_type(4)));
             const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(A.stage) + (size_t)w * 131072u, 0, 131072, 0x00020000);
@@ -508,8 +535,14 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
     A.pk.hp *= h.fm_ref; A.pk.pi *= h.fm_ref; A.pk.ref = h.fm_ref;
     int r;
     if (timer && (r = timer->begin(s))) return r;
-    if (fm) hipLaunchKernelGGL(k_run1024v2<true>, dim3(h.nruns), dim3(256), 0, s, A);
-    else hipLaunchKernelGGL(k_run1024v2<false>, dim3(h.nruns), dim3(256), 0, s, A);
+    A.g = h.g;
+    if (h.G > 1 && !fm) { set_error("k_run1024v2: interleaved shards have F32 output only"); return -1; }
+    if (h.G == 2) hipLaunchKernelGGL((k_run1024v2<true, 2>), dim3(h.nruns), dim3(256), 0, s, A);
+    else if (h.G == 4) hipLaunchKernelGGL((k_run1024v2<true, 4>), dim3(h.nruns), dim3(256), 0, s, A);
+    else if (h.G == 8) hipLaunchKernelGGL((k_run1024v2<true, 8>), dim3(h.nruns), dim3(256), 0, s, A);
+    else if (h.G > 1) { set_error("k_run1024v2: interleaved shards of stride %u are not built (2, 4, 8)", h.G); return -1; }
+    else if (fm) hipLaunchKernelGGL((k_run1024v2<true, 1>), dim3(h.nruns), dim3(256), 0, s, A);
+    else hipLaunchKernelGGL((k_run1024v2<false, 1>), dim3(h.nruns), dim3(256), 0, s, A);
     if (timer && (r = timer->end(s))) return r;
     CSDR_HIP(hipGetLastError());
     return 0;

@@ -231,7 +231,7 @@ def test_chain_channel_shard_equals_slice_of_full():
 @pytest.mark.parametrize("M,G,demod,agc,mix", [(256, 8, "fm", 0.0, False), (256, 2, "none", 0.0, False), (256, 4, "fm", 0.0, False), (256, 2, "fm", 0.0, True),
                                                (256, 8, "none", 0.0, False), (256, 4, "none", 0.0, True), (256, 8, "fm", 10.0, False), (64, 4, "fm", 11.0, False),
                                                (20, 4, "none", 0.0, False), (20, 2, "fm", 0.0, True), (4096, 8, "none", 0.0, True),
-                                               (1024, 8, "fm", 0.0, False)])
+                                               (1024, 8, "fm", 0.0, False), (1024, 4, "none", 0.0, False), (1024, 2, "fm", 0.0, True)])
 def test_chain_interleaved_shard_pruned_dft_equals_rows_of_full(M, G, demod, agc, mix):
     """chan_stride = G: shard g produces the channels g, g + G, ... through one length-G fold + one M/G-point DFT per frame
     (SURVEY 8e(A)); every shard must equal those rows of the oracle's full output, and the mixed shards must add up to the
@@ -247,7 +247,7 @@ def test_chain_interleaved_shard_pruned_dft_equals_rows_of_full(M, G, demod, agc
     for g in sorted({0, 1, G - 1}) if not mix else range(G):
         ch = cs.Chain(channels=M, demod=demod, kf=0.3, agc=agc, mix=mix, chan_first=g, chan_stride=G, max_frames=max(frames))
         # M = 256 with stride 2, 4, 8: the fused run kernel's shard variant; every other shape the any-M route
-        assert ("interleaved-shard" in ch.path and "fused" in ch.path) if (M == 256 and G in (2, 4, 8)) else "pruned-dft" in ch.path
+        assert ("interleaved-shard" in ch.path and "fused" in ch.path) if (M in (256, 1024) and G in (2, 4, 8)) else "pruned-dft" in ch.path
         got, pos = [], 0
         for f in frames:
             got.append(ch.process(x[pos * M:(pos + f) * M])); pos += f
@@ -1577,10 +1577,10 @@ def test_submit_device_independent_launches_match_serial_calls(demod):
     M, kf = 256, 0.3
     frames = [40000, 40000, 33, 40000, 40016, 40001, 40000, 40000, 48000]
     serial_call = {3}                                     # this chunk goes through process_device on a caller stream in between
-    x = synth_cf32(M * sum(frames), M, seed=77)
-    x = (x + np.complex64(0.08 - 0.05j)).astype(np.complex64)
+    from synth import synth_cf32_torch
     dev = torch.device("cuda", 0)
-    xd = torch.from_numpy(x.view(np.float32)).to(dev)
+    xd = synth_cf32_torch(M * sum(frames), M, dev, seed=77, dc=(0.09, -0.04)).view(-1)     # (on the GPU: numpy takes over a minute for 84 M samples)
+    x = xd.cpu().numpy().view(np.complex64).reshape(-1)
     width = 1 if demod == "fm" else 2
     kw = dict(channels=M, demod=demod, kf=kf, max_frames=max(frames))
     a, b = cs.Chain(**kw), cs.Chain(**kw)
@@ -1624,15 +1624,18 @@ def test_submit_device_independent_launches_match_serial_calls(demod):
         assert max_abs_err(ga[:, :n_or], want) < 1e-4 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("G,demod", [(2, "fm"), (4, "none"), (8, "fm"), (8, "none")])
-def test_fused_interleaved_shard_run_sized_calls_match_whole_band(G, demod):
+@pytest.mark.parametrize("M,G,demod", [(256, 2, "fm"), (256, 4, "none"), (256, 8, "fm"), (256, 8, "none"), (1024, 8, "fm"), (1024, 2, "fm"), (1024, 4, "none")])
+def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod):
     """k_run256v2<.., G> at run-kernel sizes (many runs with cold starts, paired F32 stores, ragged and tiny calls in between,
     state carried from call to call): every shard g must reproduce the rows g, g + G, ... of the whole-band fused chain on the
     same calls (same kernels upstream of pass 1, so FM agrees to the rounding of a differently pruned butterfly)."""
-    M, kf = 256, 0.3
-    frames = [40000, 5, 33, 40016, 16, 40001, 36864]
-    x = synth_cf32(M * sum(frames), M, seed=500 + G)
-    x = (x + np.complex64(0.03 + 0.02j)).astype(np.complex64)
+    kf = 0.3
+    # M = 1024: k_run1024v2<FM, G> on the run-sized calls of whole 4-frame tiles, the whole-band kernel + row gather on the others (and for CF32)
+    import torch
+    from synth import synth_cf32_torch
+    frames = [40000, 5, 33, 40016, 16, 40001, 36864] if M == 256 else [12288, 5, 33, 12292, 16, 12289, 8192]
+    # (generated on the GPU: numpy takes minutes for 46 M samples of 256 carriers)
+    x = synth_cf32_torch(M * sum(frames), M, torch.device("cuda", 0), seed=500 + G, dc=(0.04, 0.03)).cpu().numpy().view(np.complex64).reshape(-1)
     full = cs.Chain(channels=M, demod=demod, kf=kf, max_frames=max(frames))
     wf, pos = [], 0
     for f in frames:
