@@ -9,11 +9,11 @@ import composable_sdr_amd as cs
 from composable_sdr_amd import _lib
 from synth import synth_cf32_torch
 
-M, nf, steps = 256, 262144, int(os.environ.get("STEP_STEPS", "100"))
+M = int(os.environ.get("STEP_M", "256")); nf = 262144 * 256 // M; steps = int(os.environ.get("STEP_STEPS", "100"))
 dev = torch.device("cuda", 0)
 xs = [synth_cf32_torch(M * nf, M, dev, seed=20260101 + 7919 * i) for i in range(2)]
 out = torch.empty(M * nf * 2, dtype=torch.float32, device=dev)
-for agc in (0.0, 10.0):
+for agc in ((0.0, 10.0) if M == 256 else (0.0,)):
     for G in (1, 2, 4, 8):
         kw = dict(channels=M, demod="fm", kf=0.3, agc=agc, max_frames=nf, flags=_lib.FLAG_QUIET)
         if G > 1: kw.update(chan_first=0, chan_stride=G)
