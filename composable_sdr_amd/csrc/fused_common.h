@@ -396,6 +396,7 @@ struct RunArgs {
     const float4 *prev_tail;    // k_run256v2, indep: the previous chunk's last WU + 1 raw tiles (run 0's warm-up window and halo)
     uint32_t indep;             // k_run256v2: run 0 starts cold from prev_tail instead of the carried state: the launch reads nothing an earlier launch wrote
     uint32_t pair_align;        // k_run256v2<FM>: run boundaries rounded down to even tiles (whole 128-byte output lines per tile pair)
+    uint32_t wu_batch6;         // k_run256v2: the six warm-up tiles in one batch of loads (0: two batches of three)
     uint32_t wu, wu_rot;        // k_run256v2: read-only warm-up tiles in front of a run's halo tile (WU = 6); runs walk them in rotated order
 };
 

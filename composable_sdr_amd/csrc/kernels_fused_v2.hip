@@ -132,34 +132,46 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         const int h0 = RA.indep ? halo - (int)RA.wu : (halo > (int)RA.wu ? halo - (int)RA.wu : 0);
         const unsigned nwu = (unsigned)(halo - h0);
         float4 raw[8];
-        float w0[8], w1[8];
+        // weight of my piece `it` of a tile: beta^(4095 - n), n = n0 + 512 it (the swizzle term of the slot does not depend on it): two
+        // registers and a uniform ratio instead of sixteen (the six-tile batch below needs the room)
+        float wt0, wt1;
         {
             const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
-                const int i = (slot & 7) ^ ((q >> 1) & 7);
-                const int n = 16 * q + 2 * i;
-                w0[it] = exp2f((float)(4095 - n) * RA.l2beta);
-                w1[it] = exp2f((float)(4094 - n) * RA.l2beta);
-            }
+            const int slot = 64 * wave + lane, q = slot >> 3;
+            const int i = (slot & 7) ^ ((q >> 1) & 7);
+            const int n = 16 * q + 2 * i;
+            wt0 = exp2f((float)(4095 - n) * RA.l2beta);
+            wt1 = exp2f((float)(4094 - n) * RA.l2beta);
         }
+        const float wstep = RA.l2beta < -100.0f ? 0.0f : exp2f(-512.0f * RA.l2beta);   // beta^-512 (dc_block off, l2beta = -1000: no state to warm up, and no inf * 0)
         // zero-state aggregate of the warm-up tiles: sum over tiles of beta^(4096 (halo - 1 - t)) x (weighted sum inside tile t),
         // order-free, so that run w may start at tile (w mod nwu) of its window: 512 runs that walk their windows in the same order
         // hit the HBM channels in lockstep
         float2 acc = make_float2(0.f, 0.f);
         auto fold = [&](const float4 (&r)[8], int t) {
             float2 p = make_float2(0.f, 0.f);
+            float a0 = wt0, a1 = wt1;
 #pragma unroll
             for (int it = 0; it < 8; it++) {
-                p = cfma(make_float2(r[it].x, r[it].y), w0[it], p);
-                p = cfma(make_float2(r[it].z, r[it].w), w1[it], p);
+                p = cfma(make_float2(r[it].x, r[it].y), a0, p);
+                p = cfma(make_float2(r[it].z, r[it].w), a1, p);
+                a0 *= wstep; a1 *= wstep;
             }
             acc = cfma(p, exp2f((float)(4096 * (halo - 1 - t)) * RA.l2beta), acc);
         };
         const unsigned rot = RA.wu_rot ? w : 0u;
         unsigned i = 0;
-        if (nwu >= 3) {
+        if (nwu == 6 && RA.wu_batch6) {
+            // the usual window: all six tiles requested before the first is folded (192 of the prologue's registers: nothing else is
+            // live yet) -- one memory latency instead of two behind the DMA'd halo and first tile
+            float4 rb[8], rc[8], rd[8], re[8], rf[8];
+            const int t0 = h0 + (int)(rot % 6u), t1 = h0 + (int)((1 + rot) % 6u), t2 = h0 + (int)((2 + rot) % 6u);
+            const int t3 = h0 + (int)((3 + rot) % 6u), t4 = h0 + (int)((4 + rot) % 6u), t5 = h0 + (int)((5 + rot) % 6u);
+            tile_load(tile_ptr(t0), 256, raw, tid); tile_load(tile_ptr(t1), 256, rb, tid); tile_load(tile_ptr(t2), 256, rc, tid);
+            tile_load(tile_ptr(t3), 256, rd, tid); tile_load(tile_ptr(t4), 256, re, tid); tile_load(tile_ptr(t5), 256, rf, tid);
+            fold(raw, t0); fold(rb, t1); fold(rc, t2); fold(rd, t3); fold(re, t4); fold(rf, t5);
+            i = 6;
+        } else if (nwu >= 3) {
             float4 rb[8], rc[8];
 #pragma unroll 1
             for (; i + 3 <= nwu; i += 3) {
