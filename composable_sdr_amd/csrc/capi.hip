@@ -156,6 +156,9 @@ struct csdr_chain {
     bool pd_used[2] = {false, false}, pd_tail_rec = false, serial_pending = false, in_submit = false;
     uint32_t pd_count = 0, pd_indep_calls = 0;
     bool call_indep = false; hipEvent_t call_ev_tail = nullptr;     // handed to the fused plan by the call in progress
+    // entry points share the handle's state: a call on a caller's stream is remembered so that the host-buffer entry point
+    // (own stream s_k) can order itself behind it, and the other way round
+    hipStream_t last_user_stream = nullptr; bool user_stream_dirty = false;
 };
 
 extern "C" {
@@ -977,7 +980,12 @@ int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, vo
         if (r) return r;
         CSDR_HIP(hipEventRecord(h->e_serial, (hipStream_t)stream));
         h->serial_pending = true;
+        if ((hipStream_t)stream != h->s_k) { h->last_user_stream = (hipStream_t)stream; h->user_stream_dirty = true; }
         return CSDR_OK;
+    }
+    if (h && !h->in_submit && (hipStream_t)stream != h->s_k) {
+        if (h->s_k && h->q_count) { DevGuard guard(h->device); CSDR_HIP(hipStreamSynchronize(h->s_k)); }   // host-buffer chunks still in flight come first
+        h->last_user_stream = (hipStream_t)stream; h->user_stream_dirty = true;
     }
     return chain_process_device_any(h, d_in, n_in, d_out, n_out, stream);
 }
@@ -1197,12 +1205,19 @@ int csdr_chain_submit(csdr_chain *h, const float *in, uint32_t n_in, void *out)
     if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
     int r;
     if ((r = chain_host_init(h))) return r;
+    if (h->user_stream_dirty) {                         // csdr_chain_process_device calls on caller streams precede this chunk
+        CSDR_HIP(hipStreamSynchronize(h->last_user_stream));
+        h->user_stream_dirty = false;
+    }
     csdr_chain::HostSlot &sl = h->slot[(h->q_head + h->q_count) % CSDR_CHAIN_INFLIGHT];
     sl.user_out = out; sl.n_out = 0; sl.out_bytes = 0; sl.staged_out = false;
     if (n_in) {
         const size_t in_bytes = sizeof(float2) * (size_t)n_in, out_max = (size_t)h->C * h->max_nf * 8;
         if (!sl.d_in && ((r = dev_alloc(&sl.d_in, h->max_nx)))) return r;
         if (!sl.d_out) { CSDR_HIP(hipMalloc(&sl.d_out, out_max)); }
+        // every resource of the slot exists before the chain's state moves on: a failure below this point cannot skip a chunk's state
+        const bool stage_out = !is_pinned(out);
+        if (stage_out && !sl.h_out) { CSDR_HIP(hipHostMalloc(&sl.h_out, out_max, hipHostMallocDefault)); }
         const void *src = in;
         if (!is_pinned(in)) {                               // pageable caller memory: one host copy into the slot's page-locked buffer
             if (!sl.h_in) { CSDR_HIP(hipHostMalloc(&sl.h_in, sizeof(float2) * h->max_nx, hipHostMallocDefault)); }
@@ -1219,10 +1234,7 @@ int csdr_chain_submit(csdr_chain *h, const float *in, uint32_t n_in, void *out)
         CSDR_HIP(hipEventRecord(sl.e_k, h->s_k));
         sl.n_out = no; sl.out_bytes = (size_t)no * csdr_chain_out_elem_size(h);
         void *dst = out;
-        if (!is_pinned(out)) {
-            if (!sl.h_out) { CSDR_HIP(hipHostMalloc(&sl.h_out, out_max, hipHostMallocDefault)); }
-            dst = sl.h_out; sl.staged_out = true;
-        }
+        if (stage_out) { dst = sl.h_out; sl.staged_out = true; }
         CSDR_HIP(hipStreamWaitEvent(h->s_out, sl.e_k, 0));
         CSDR_HIP(hipMemcpyAsync(dst, sl.d_out, sl.out_bytes, hipMemcpyDeviceToHost, h->s_out));
         CSDR_HIP(hipEventRecord(sl.e_out, h->s_out));
@@ -1238,11 +1250,11 @@ int csdr_chain_collect(csdr_chain *h, uint32_t *n_out)
     if (!h->q_count) { set_error("chain: nothing submitted"); return CSDR_ERR_INVALID; }
     DevGuard guard(h->device);
     csdr_chain::HostSlot &sl = h->slot[h->q_head];
-    h->q_head = (h->q_head + 1) % CSDR_CHAIN_INFLIGHT; h->q_count--;
     if (sl.out_bytes) {
-        CSDR_HIP(hipEventSynchronize(sl.e_out));
+        CSDR_HIP(hipEventSynchronize(sl.e_out));        // (a failed wait leaves the chunk queued)
         if (sl.staged_out) memcpy(sl.user_out, sl.h_out, sl.out_bytes);
     }
+    h->q_head = (h->q_head + 1) % CSDR_CHAIN_INFLIGHT; h->q_count--;
     if (n_out) *n_out = sl.n_out;
     return CSDR_OK;
 }
@@ -1265,6 +1277,7 @@ int csdr_chain_process(csdr_chain *h, const float *in, uint32_t n_in, void *out,
         DevGuard guard(h->device);
         if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
         if ((r = chain_host_init(h))) return r;
+        if (h->user_stream_dirty) { CSDR_HIP(hipStreamSynchronize(h->last_user_stream)); h->user_stream_dirty = false; }
         csdr_chain::HostSlot &sl = h->slot[0];
         if (!sl.d_in && ((r = dev_alloc(&sl.d_in, h->max_nx)))) return r;
         if (!sl.d_out) { CSDR_HIP(hipMalloc(&sl.d_out, (size_t)h->C * h->max_nf * 8)); }

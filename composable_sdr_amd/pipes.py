@@ -374,12 +374,15 @@ class Chain:
 
     def reset(self):
         check(lib().csdr_chain_reset(self.h))
+        self._pending = []                              # the native side abandons chunks still in flight
 
     def seek_frames(self, frames):
         """reset, then continue as if `frames` frames of the stream had already gone by"""
         check(lib().csdr_chain_seek_frames(self.h, int(frames)))
+        self._pending = []
 
     def close(self):
+        self._pending = []
         self._h.close()
 
 
@@ -393,7 +396,13 @@ class host_array:
         if not self.p:
             raise CsdrError(_lib.ERR_NOMEM, "csdr_host_alloc failed")
         buf = (C.c_char * n).from_address(self.p)
+        buf._csdr_owner = _PinnedBlock(self.p)          # the block lives as long as any numpy view of it (views keep `buf` as their base)
         self.a = np.frombuffer(buf, dtype=self.dtype).reshape(shape)
+
+
+class _PinnedBlock:
+    def __init__(self, p):
+        self.p = p
 
     def __del__(self):
         try:
