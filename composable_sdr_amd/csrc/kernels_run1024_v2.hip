@@ -132,32 +132,35 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
         const unsigned h0 = tile_begin - B2_WU;
         float2 acc = make_float2(0.f, 0.f);
         {
-            float4 raw[8], rb[8];
-            float w0[8], w1[8];
-            const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
+            // round 3 (as k_run256v2): the six tiles in ONE batch of loads (the window's registers are not live yet), weights of my
+            // pieces as a running product: beta^(4095 - n), n = n0 + 512 it
+            float4 raw[8], rb[8], rc[8], rd[8], re[8], rf[8];
+            float wt0, wt1;
+            {
+                const int wave = tid >> 6, lane = tid & 63;
+                const int slot = 64 * wave + lane, q = slot >> 3;
                 const int i = (slot & 7) ^ ((q >> 1) & 7);
                 const int n = 16 * q + 2 * i;
-                w0[it] = exp2f((float)(4095 - n) * A.l2beta);
-                w1[it] = exp2f((float)(4094 - n) * A.l2beta);
+                wt0 = exp2f((float)(4095 - n) * A.l2beta);
+                wt1 = exp2f((float)(4094 - n) * A.l2beta);
             }
+            const float wstep = A.l2beta < -100.0f ? 0.0f : exp2f(-512.0f * A.l2beta);
             auto fold = [&](const float4 (&r)[8]) {
                 float2 p = make_float2(0.f, 0.f);
+                float a0 = wt0, a1 = wt1;
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
-                    p = cfma(make_float2(r[it].x, r[it].y), w0[it], p);
-                    p = cfma(make_float2(r[it].z, r[it].w), w1[it], p);
+                    p = cfma(make_float2(r[it].x, r[it].y), a0, p);
+                    p = cfma(make_float2(r[it].z, r[it].w), a1, p);
+                    a0 *= wstep; a1 *= wstep;
                 }
                 acc = cfma(acc, A.b256[16], p);
             };
-#pragma unroll 1
-            for (unsigned t = h0; t < tile_begin; t += 2) {
-                tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
-                tile_load(x4 + (size_t)(t + 1) * 2048, 256, rb, tid);
-                fold(raw); fold(rb);
-            }
+            static_assert(B2_WU == 6, "one batch of six warm-up tiles");
+            tile_load(x4 + (size_t)h0 * 2048, 256, raw, tid); tile_load(x4 + (size_t)(h0 + 1) * 2048, 256, rb, tid);
+            tile_load(x4 + (size_t)(h0 + 2) * 2048, 256, rc, tid); tile_load(x4 + (size_t)(h0 + 3) * 2048, 256, rd, tid);
+            tile_load(x4 + (size_t)(h0 + 4) * 2048, 256, re, tid); tile_load(x4 + (size_t)(h0 + 5) * 2048, 256, rf, tid);
+            fold(raw); fold(rb); fold(rc); fold(rd); fold(re); fold(rf);
         }
         c = wg_sum(acc, red, tid);
         if (h0 == 0) c = cfma(A.vend_in[0], exp2f((float)(4096 * B2_WU) * A.l2beta), c);

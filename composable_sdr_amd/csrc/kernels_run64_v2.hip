@@ -71,6 +71,12 @@ __global__ __launch_bounds__(256, 2) void k_run64v2(Run64v2Args A)
     const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
 
     if (tid < 64) tw_s[tid] = A.tw[tid];
+    const unsigned goff = dma_offset(tid);
+    const unsigned wave_u = qw;
+    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)L + 1024u * wave_u;
+    // the first tile the loop below walks (a run >= 1: its halo tile, into buffer 1) is requested before anything else (round 3, as
+    // k_run256v2): the run start is one burst of memory traffic, not a chain of round trips
+    if ((w == 0 ? first : first - 1) < last) dma_tile(x4 + (size_t)(w == 0 ? first : first - 1) * 2048, goff, lds_wave + (w == 0 ? 0u : (unsigned)(S2_BUF * 8u)));
     float2 c;                                           // DC state v before the next tile (same in every lane)
     unsigned tile_begin = first;
     if (w == 0) {
@@ -84,26 +90,41 @@ __global__ __launch_bounds__(256, 2) void k_run64v2(Run64v2Args A)
         float2 acc = make_float2(0.f, 0.f);
         {
             float4 raw[8];
-            float w0[8], w1[8];
-            const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
+            // weight of my piece `it` of a tile: beta^(4095 - n), n = n0 + 512 it: a running product (two registers instead of sixteen)
+            float wt0, wt1;
+            {
+                const int wave = tid >> 6, lane = tid & 63;
+                const int slot = 64 * wave + lane, q = slot >> 3;
                 const int i = (slot & 7) ^ ((q >> 1) & 7);
                 const int n = 16 * q + 2 * i;
-                w0[it] = exp2f((float)(4095 - n) * A.l2beta);
-                w1[it] = exp2f((float)(4094 - n) * A.l2beta);
+                wt0 = exp2f((float)(4095 - n) * A.l2beta);
+                wt1 = exp2f((float)(4094 - n) * A.l2beta);
             }
-#pragma unroll 1
-            for (unsigned t = h0; t < tile_begin; t++) {
-                tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
+            const float wstep = A.l2beta < -100.0f ? 0.0f : exp2f(-512.0f * A.l2beta);
+            auto fold = [&](const float4 (&r)[8]) {
                 float2 p = make_float2(0.f, 0.f);
+                float a0 = wt0, a1 = wt1;
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
-                    p = cfma(make_float2(raw[it].x, raw[it].y), w0[it], p);
-                    p = cfma(make_float2(raw[it].z, raw[it].w), w1[it], p);
+                    p = cfma(make_float2(r[it].x, r[it].y), a0, p);
+                    p = cfma(make_float2(r[it].z, r[it].w), a1, p);
+                    a0 *= wstep; a1 *= wstep;
                 }
                 acc = cfma(acc, A.b256[16], p);
+            };
+            unsigned t = h0;
+            if (tile_begin - h0 == (unsigned)S2_WU) {   // the usual window: six tiles in one batch of loads (one memory latency, not six)
+                float4 rb[8], rc[8], rd[8], re[8], rf[8];
+                tile_load(x4 + (size_t)t * 2048, 256, raw, tid); tile_load(x4 + (size_t)(t + 1) * 2048, 256, rb, tid);
+                tile_load(x4 + (size_t)(t + 2) * 2048, 256, rc, tid); tile_load(x4 + (size_t)(t + 3) * 2048, 256, rd, tid);
+                tile_load(x4 + (size_t)(t + 4) * 2048, 256, re, tid); tile_load(x4 + (size_t)(t + 5) * 2048, 256, rf, tid);
+                fold(raw); fold(rb); fold(rc); fold(rd); fold(re); fold(rf);
+                t += 6;
+            }
+#pragma unroll 1
+            for (; t < tile_begin; t++) {
+                tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
+                fold(raw);
             }
         }
         c = wg_sum(acc, red, tid);
@@ -121,9 +142,6 @@ __global__ __launch_bounds__(256, 2) void k_run64v2(Run64v2Args A)
 #pragma unroll
     for (int r = 0; r < 4; r++) kJ[r] = -A.alpha * exp2f((float)(64 * r + j) * A.l2beta);
     const float b256 = A.b256[1];
-    const unsigned goff = dma_offset(tid);
-    const unsigned wave_u = qw;
-    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)L + 1024u * wave_u;
     const int q = tid, sw = (q >> 1) & 7;
     const unsigned raw_a0 = (unsigned)q * 128u + ((unsigned)sw << 4);            // DC scan: slot i of my run: raw_a ^ (i << 4)
     // column layout of the raw image: sample of frame 16 qw + i, branch j sits at float2 1024 qw + 64 i + (colP ^ ((4 i) & 12))
@@ -270,8 +288,7 @@ __global__ __launch_bounds__(256, 2) void k_run64v2(Run64v2Args A)
         }
     };
 
-    if (tile_begin < last) dma_tile(x4 + (size_t)tile_begin * 2048, goff, lds_wave + (w == 0 ? 0u : (unsigned)(S2_BUF * 8u)));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the tile requested at the kernel's entry)
     if (w > 0) {                                        // the halo tile (buffer 1): DC blocker, pre-mix and the history only
         tile(tile_begin, 1, true);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
