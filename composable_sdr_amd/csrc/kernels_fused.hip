@@ -908,7 +908,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         { const char *e = getenv("CSDR_TRACE"); RA.trace_light = (e && atoi(e) == 2) ? 1u : 0u; }
         { const char *e = getenv("CSDR_WU"); RA.wu = e ? (uint32_t)atoi(e) : (uint32_t)WU; }       // experiments: fewer tiles = wrong DC state at run starts
         { const char *e = getenv("CSDR_WU_ROT"); RA.wu_rot = e ? (uint32_t)atoi(e) : 0u; }      // measured: no effect on the run-start burst
-        RA.pair_align = (v2 && c.fm) ? 1u : 0u;
+        RA.pair_align = (v2 && (c.fm || getenv("CSDR_PAIR_ALIGN_CF"))) ? 1u : 0u;
         { const char *e = getenv("CSDR_WU_BATCH6"); RA.wu_batch6 = e ? (uint32_t)atoi(e) : 1u; }
         RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;
         const bool whole = nf == nb_full * NB;

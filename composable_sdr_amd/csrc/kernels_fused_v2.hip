@@ -31,6 +31,9 @@
 #ifndef V2_PAIR
 #define V2_PAIR 1       // FM: whole 128-byte row lines per tile pair (0: every tile stores its own 64-byte halves, for A/B)
 #endif
+#ifndef V2_PAIR_CF
+#define V2_PAIR_CF 0    // CF32: 1 = the even tile of a pair keeps its results, the odd tile stores 256 bytes per row (A/B build: measured below)
+#endif
 #ifndef V2_BAR_E
 #define V2_BAR_E 0      // 1: the (redundant) barrier between the X reads and the Z writes of pass 1, for A/B
 #endif
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     // a row's 128-byte line reach the L2 back to back and leave it as ONE write (halves that arrive a tile apart are evicted
     // separately under the streaming reads: F32 output then costs as much HBM write energy as CF32 output of twice the size)
     float hold[16];
+    v2f holdc[V2_PAIR_CF ? 16 : 1];
     auto tile = [&](float2 (&old)[NB], float2 (&nw)[NB], unsigned b_, const int par) {
         unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)b_);            // keep the tile index (store / DMA bases) in SGPRs
         asm volatile("" : "+s"(b));
@@ -539,11 +543,19 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             V2STAMP(12);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             V2STAMP(13);
+            if (V2_PAIR_CF && par == 0 && b + 1 < last) {           // CF32 pairs (experiment): 256 bytes of a row per tile pair
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const char *rowp = obase + (size_t)XIDX(i) * row16;
-                if (V2_ABLATE & 2) asm volatile("" :: "v"(vv[i]), "s"(rowp));
-                else asm volatile(V2_SNOP "global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(vv[i]), "s"(rowp) : "memory");
+                for (int i = 0; i < 16; i++) holdc[i] = vv[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const char *rowp = obase + (size_t)XIDX(i) * row16;
+                    if (V2_ABLATE & 2) asm volatile("" :: "v"(vv[i]), "s"(rowp));
+                    else {
+                        if (V2_PAIR_CF && par == 1) asm volatile(V2_SNOP "global_store_dwordx2 %0, %1, %2 offset:-128" :: "v"(voff), "v"(holdc[i]), "s"(rowp) : "memory");
+                        asm volatile(V2_SNOP "global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(vv[i]), "s"(rowp) : "memory");
+                    }
+                }
             }
         }
         V2STAMP(14);
