@@ -176,7 +176,12 @@ def main():
         torch.cuda.synchronize()
 
     preheat_steps = 0
-    if a.preheat_ms > 0:                        # not part of W or K: load until the clocks have settled (reported as config.preheat_steps)
+    if a.preheat_ms > 0 and use_dist:           # every rank the SAME number of steps (a step may contain a collective): 0.25 ms per step assumed
+        preheat_steps = max(10, int(a.preheat_ms / 0.25))
+        for i in range(preheat_steps):
+            step(i)
+        torch.cuda.synchronize()
+    elif a.preheat_ms > 0:                      # not part of W or K: load until the clocks have settled (reported as config.preheat_steps)
         t_pre = time.perf_counter()
         while time.perf_counter() - t_pre < a.preheat_ms * 1e-3:
             for i in range(10):
