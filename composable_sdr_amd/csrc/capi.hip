@@ -980,10 +980,10 @@ int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, vo
         if (r) return r;
         CSDR_HIP(hipEventRecord(h->e_serial, (hipStream_t)stream));
         h->serial_pending = true;
-        if ((hipStream_t)stream != h->s_k) { h->last_user_stream = (hipStream_t)stream; h->user_stream_dirty = true; }
+        if (!h->s_k || (hipStream_t)stream != h->s_k) { h->last_user_stream = (hipStream_t)stream; h->user_stream_dirty = true; }
         return CSDR_OK;
     }
-    if (h && !h->in_submit && (hipStream_t)stream != h->s_k) {
+    if (h && !h->in_submit && (!h->s_k || (hipStream_t)stream != h->s_k)) {
         if (h->s_k && h->q_count) { DevGuard guard(h->device); CSDR_HIP(hipStreamSynchronize(h->s_k)); }   // host-buffer chunks still in flight come first
         h->last_user_stream = (hipStream_t)stream; h->user_stream_dirty = true;
     }
