@@ -1661,3 +1661,48 @@ def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod):
             e = np.sqrt(np.mean(np.abs(got.astype(np.complex128) - want) ** 2)) / np.sqrt(np.mean(np.abs(wf) ** 2))
             print(f"fused shard G={G} g={g} CF32: rel-rms (of the whole band) {e:.2e}")
             assert e < 2e-6, e
+
+
+def test_round3_entry_points_reset_seek_and_fallbacks():
+    """Housekeeping of the round-3 paths: reset / seek_frames on a fused interleaved shard and on a handle with pipelined chunks
+    restore the initial state; strides the fused shard kernels do not take (16) use the any-M route; bad sizes are rejected."""
+    import torch
+    from synth import synth_cf32_torch
+    M, kf, nf = 256, 0.3, 36864
+    dev = torch.device("cuda", 0)
+    xd = synth_cf32_torch(M * nf * 2, M, dev, seed=91).view(-1)
+    x = xd.cpu().numpy().view(np.complex64).reshape(-1)
+    # (1) fused shard: reset and seek
+    ch = cs.Chain(channels=M, demod="fm", kf=kf, chan_first=1, chan_stride=4, max_frames=nf)
+    assert "interleaved-shard" in ch.path
+    a1 = ch.process(x[: M * nf]); a2 = ch.process(x[M * nf:])
+    ch.reset()
+    b1 = ch.process(x[: M * nf])
+    assert np.array_equal(a1, b1)
+    ch.seek_frames(nf)                                    # the second chunk alone, from a fresh state at its stream position
+    c2 = ch.process(x[M * nf:])
+    d = np.abs(wrap_pm(c2[:, 64:].astype(np.float64) - a2[:, 64:], 1.0 / kf))      # behind the FIR / DC transient of the fresh start
+    assert np.median(d) < 1e-3
+    ch.close()
+    # (2) pipelined chunks, reset, pipelined chunks again
+    ch = cs.Chain(channels=M, demod="fm", kf=kf, max_frames=nf)
+    outs = [torch.empty(M * nf, dtype=torch.float32, device=dev) for _ in range(4)]
+    for i in range(2):
+        ch.submit_device(xd.data_ptr() + i * M * nf * 8, M * nf, outs[i].data_ptr())
+    ch.wait_device()
+    ch.reset()
+    for i in range(2):
+        ch.submit_device(xd.data_ptr() + i * M * nf * 8, M * nf, outs[2 + i].data_ptr())
+    ch.wait_device()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    with pytest.raises(cs.CsdrError):
+        ch.submit_device(xd.data_ptr(), M * 16 + 3, outs[0].data_ptr())
+    ch.close()
+    # (3) a stride without a fused shard kernel
+    g16 = cs.Chain(channels=M, demod="none", chan_first=5, chan_stride=16, max_frames=512)
+    assert "pruned-dft" in g16.path
+    y = g16.process(x[: M * 512])
+    w = O.Chain(M).process(x[: M * 512])[5::16]
+    assert rel_rms(y, w) < 1e-5 * np.sqrt(np.mean(np.abs(O.Chain(M).process(x[: M * 512])) ** 2)) / np.sqrt(np.mean(np.abs(w) ** 2)) + 1e-5
+    g16.close()
