@@ -31,6 +31,9 @@
 #ifndef V2_PAIR
 #define V2_PAIR 1       // FM: whole 128-byte row lines per tile pair (0: every tile stores its own 64-byte halves, for A/B)
 #endif
+#ifndef V2_STORE_AUX
+#define V2_STORE_AUX ""     // cache policy bits of the output stores (" nt", " sc1", " sc0 sc1") for A/B builds
+#endif
 #ifndef V2_PAIR_CF
 #define V2_PAIR_CF 0    // CF32: 1 = the even tile of a pair keeps its results, the odd tile stores 256 bytes per row (A/B build: measured below)
 #endif
@@ -453,8 +456,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                         for (int u = 0; u < NS; u++) {
                             // uniform part of the row: k2 of slot S0 + u without the lane's hb term (G = 8: XIDX(S0 + 2 hb + u) = Wv + 8 hb + 4 u)
                             const char *rowp = obase + (size_t)XIDX(S0 + u) * row16;
-                            if (V2_PAIR && par == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:-64" :: "v"(voff), "v"(hold[u]), "s"(rowp) : "memory");
-                            asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
+                            if (V2_PAIR && par == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:-64" V2_STORE_AUX :: "v"(voff), "v"(hold[u]), "s"(rowp) : "memory");
+                            asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" V2_STORE_AUX :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
                         }
                     }
                     if (f2 == 15) {
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                     for (int u = 0; u < 4; u++) {
                         const float ew = agc_energy_word(rr[u], A.agc_alpha);
                         const char *rowe = ebase + (size_t)XIDX(i + u) * row16;
-                        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(voff), "v"(ew), "s"(rowe) : "memory");
+                        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" V2_STORE_AUX :: "v"(voff), "v"(ew), "s"(rowe) : "memory");
                     }
                 }
                 if (V2_PAIR && par == 0 && b + 1 < last) continue;   // (uniform) the odd tile of the pair stores these
@@ -525,11 +528,11 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                     const char *rowp = obase + (size_t)XIDX(i + u) * row16;
                     if (V2_ABLATE & 2) asm volatile("" :: "v"(mq[u]), "s"(rowp));
                     else if (EN) {
-                        if (V2_PAIR && par == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:-64" :: "v"(voff), "v"(hold[i + u]), "s"(rowp) : "memory");
-                        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
+                        if (V2_PAIR && par == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:-64" V2_STORE_AUX :: "v"(voff), "v"(hold[i + u]), "s"(rowp) : "memory");
+                        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" V2_STORE_AUX :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
                     } else {
-                        if (V2_PAIR && par == 1) asm volatile(V2_SNOP "global_store_dword %0, %1, %2 offset:-64" :: "v"(voff), "v"(hold[i + u]), "s"(rowp) : "memory");
-                        asm volatile(V2_SNOP "global_store_dword %0, %1, %2" :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
+                        if (V2_PAIR && par == 1) asm volatile(V2_SNOP "global_store_dword %0, %1, %2 offset:-64" V2_STORE_AUX :: "v"(voff), "v"(hold[i + u]), "s"(rowp) : "memory");
+                        asm volatile(V2_SNOP "global_store_dword %0, %1, %2" V2_STORE_AUX :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
                     }
                 }
             }
@@ -552,8 +555,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                     const char *rowp = obase + (size_t)XIDX(i) * row16;
                     if (V2_ABLATE & 2) asm volatile("" :: "v"(vv[i]), "s"(rowp));
                     else {
-                        if (V2_PAIR_CF && par == 1) asm volatile(V2_SNOP "global_store_dwordx2 %0, %1, %2 offset:-128" :: "v"(voff), "v"(holdc[i]), "s"(rowp) : "memory");
-                        asm volatile(V2_SNOP "global_store_dwordx2 %0, %1, %2" :: "v"(voff), "v"(vv[i]), "s"(rowp) : "memory");
+                        if (V2_PAIR_CF && par == 1) asm volatile(V2_SNOP "global_store_dwordx2 %0, %1, %2 offset:-128" V2_STORE_AUX :: "v"(voff), "v"(holdc[i]), "s"(rowp) : "memory");
+                        asm volatile(V2_SNOP "global_store_dwordx2 %0, %1, %2" V2_STORE_AUX :: "v"(voff), "v"(vv[i]), "s"(rowp) : "memory");
                     }
                 }
             }
