@@ -25,7 +25,7 @@
 #define V2_FM_PACKED 1    // freqdem on packed pairs (fm_quad) instead of one sample at a time (fm_sample)
 #endif
 #ifndef V2_ABLATE
-#define V2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem, 8 one FIR tap, 16 no butterflies in the two DFT passes, 32 no DC scan arithmetic
+#define V2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem, 8 one FIR tap, 16 no butterflies in the two DFT passes, 32 no DC scan arithmetic, 64 no y' write-back, 128 no Z write (one LDS pass less each)
 #endif
 
 #ifndef V2_PAIR
@@ -330,7 +330,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             s = make_float2(fmaf(s.x, be, xr[i].x), fmaf(s.y, be, xr[i].y));
             y.z = fmaf(s.x, na, xr[i].z); y.w = fmaf(s.y, na, xr[i].w);
             s = make_float2(fmaf(s.x, be, xr[i].z), fmaf(s.y, be, xr[i].w));
-            *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = y;
+            if (V2_ABLATE & 64) asm volatile("" :: "v"(y));            // timing only: y' is not written back (one LDS pass less)
+            else *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = y;
         }
         V2STAMP(2);
         bar();                                          // B_c: y' (frame carry still missing) and the frame totals are visible
@@ -399,8 +400,10 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         if (V2_BAR_E) bar();
         V2STAMP(8);
 #pragma unroll
-        for (int i = 0; i < 16; i++)
+        for (int i = 0; i < 16; i++) {
+            if (V2_ABLATE & 128) { asm volatile("" :: "v"(vv[i])); continue; }     // timing only: Z is not written (one LDS pass less)
             if (XIDX(i) % G == 0) *reinterpret_cast<float2 *>(B + zw_a + 128 * XIDX(i)) = to_f2(vv[i]);
+        }
         V2STAMP(9);
         bar();                                          // B_f: Z complete
         V2STAMP(10);
