@@ -11,12 +11,12 @@ from composable_sdr_amd import _lib
 from synth import synth_cf32_torch
 
 M = int(os.environ.get("STEP_M", "256")); nf = int(os.environ.get("STEP_NF", str(262144 * 256 // M)))
-demod = os.environ.get("STEP_DEMOD", "fm"); steps = int(os.environ.get("STEP_STEPS", "40"))
+demod = os.environ.get("STEP_DEMOD", "fm"); steps = int(os.environ.get("STEP_STEPS", "40")); agc = float(os.environ.get("STEP_AGC", "0"))
 dev = torch.device("cuda", 0)
 xs = [synth_cf32_torch(M * nf, M, dev, seed=20260101 + 7919 * i) for i in range(2)]
 out = torch.empty(M * nf * 2, dtype=torch.float32, device=dev)
 for name, fl in (("no timer", 0), ("event pair per launch", _lib.FLAG_TIME_KERNELS), ("region", _lib.FLAG_TIME_KERNELS | _lib.FLAG_TIME_REGION)):
-    ch = cs.Chain(channels=M, demod=demod, max_frames=nf, flags=_lib.FLAG_QUIET | fl)
+    ch = cs.Chain(channels=M, demod=demod, agc=agc, max_frames=nf, flags=_lib.FLAG_QUIET | fl)
     for i in range(3):
         ch.process_device(xs[i & 1].data_ptr(), M * nf, out.data_ptr(), 0)
     torch.cuda.synchronize()
@@ -31,7 +31,7 @@ for name, fl in (("no timer", 0), ("event pair per launch", _lib.FLAG_TIME_KERNE
     ch.close()
 
 if os.environ.get("POWER") == "1":
-    ch = cs.Chain(channels=M, demod=demod, max_frames=nf, flags=_lib.FLAG_QUIET)
+    ch = cs.Chain(channels=M, demod=demod, agc=agc, max_frames=nf, flags=_lib.FLAG_QUIET)
     stop = False
     def sample():
         while not stop:
