@@ -222,9 +222,12 @@ typedef struct csdr_chain_cfg {
     uint32_t chan_stride;       /* G > 1: interleaved channel ownership for channel-sharded multi-GPU runs
                                  * (SURVEY 8e(A)): this handle produces the channels chan_first, chan_first + G, ...
                                  * (chan_first < G, G divides channels, chan_count 0 or channels/G); output row m is
-                                 * channel chan_first + G*m.  The M-point DFT of a frame is pruned to one length-G fold
-                                 * plus one (channels/G)-point DFT, so a shard does 1/G of the DFT and tail work
-                                 * (DC blocker, pre-mix and FIR still see every branch).  0 / 1 = contiguous shard. */
+                                 * channel chan_first + G*m.  channels = 256 or 1024 with G = 2, 4, 8: the fused run kernels'
+                                 * shard variants (the shift by chan_first rides on the pre-mix phasors, the DFT passes and
+                                 * the freqdem / stores run for the owned channels only); every other shape: the M-point DFT
+                                 * of a frame is pruned to one length-G fold plus one (channels/G)-point DFT on the any-M
+                                 * route.  Either way a shard does 1/G of the DFT and tail work, while DC blocker, pre-mix
+                                 * and FIR still see every branch.  0 / 1 = contiguous shard. */
 } csdr_chain_cfg;
 
 void csdr_chain_cfg_default(csdr_chain_cfg *cfg, uint32_t channels);
