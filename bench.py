@@ -47,11 +47,31 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agc-variant", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--preheat-ms", type=float, default=60.0,
-                    help="untimed load in front of the W warm-up steps (the same step, repeated for this long): the board's clock / power "
-                         "state needs tens of ms of load to settle, a 25-launch run (6 ms) sits entirely inside that transient "
-                         "(tools/short_run_time.py: 300 us per step cold, 232 us settled); 0 = off")
+    ap.add_argument("--preheat-ms", type=float, default=2500.0,
+                    help="back-to-back steps in front of the W warm-up steps, for at least this long, with one synchronisation at the end: "
+                         "reported as `sustained_long` (with the board's sclk / socket power sampled from rocm-smi meanwhile) and at the same "
+                         "time what brings the board into the power state a long stream sees (the cap's averaging window is hundreds of ms: "
+                         "profiles/r03_short_run_preheat.txt), so that the K timed steps behind it measure THAT state; 0 = off "
+                         "(the K-step figure from an idle board is always reported as `cold_window`)")
     return ap.parse_args()
+
+
+def physical_cores():
+    """distinct (package, core) pairs of /proc/cpuinfo; None when it cannot be told"""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except Exception:
+        return None
 
 
 def cpu_baseline(M, demod, kf, agc, x_host, seconds, mix=False):
@@ -103,8 +123,51 @@ def cpu_baseline(M, demod, kf, agc, x_host, seconds, mix=False):
         if ok:
             res["all_cores"] = {"value": round(tot / tmax / 1e6, 3), "unit": "MS/s", "cores": ok,
                                 "sample": f"{ok} processes (one per host core, os.cpu_count() = {ncores}), one independent chain each on its own reference-sized "
-                                          f"chunk, started together, {tot / 1e6:.1f} MS in {tmax:.1f} s"}
+                                          f"chunk, started together, {tot / 1e6:.1f} MS in {tmax:.1f} s",
+                                "sched_affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                                "physical_cores": physical_cores()}
     return res
+
+
+class SmiSampler:
+    """sclk / socket power from rocm-smi, sampled by a side thread while a run is in flight (each call is a child process)."""
+
+    def __init__(self, device=0):
+        import threading
+        self.samples, self.stop, self.device = [], False, device
+        self.t0 = time.perf_counter()
+        self.th = threading.Thread(target=self._run, daemon=True)
+        self.th.start()
+
+    def _run(self):
+        import subprocess
+        while not self.stop:
+            t = time.perf_counter() - self.t0
+            try:
+                o = subprocess.run(["/opt/rocm/bin/rocm-smi", "-d", str(self.device), "--showpower", "--showclocks", "--json"],
+                                   capture_output=True, text=True, timeout=20).stdout
+                for v in json.loads(o).values():
+                    sclk = pw = None
+                    for k, val in v.items():
+                        kl = k.lower()
+                        if "sclk clock speed" in kl:
+                            sclk = float(str(val).strip("()").lower().replace("mhz", ""))
+                        elif "power" in kl and "(w)" in kl:
+                            pw = float(val)
+                    self.samples.append((t, time.perf_counter() - self.t0, sclk, pw))
+            except Exception:
+                pass
+            time.sleep(0.05)
+
+    def finish(self, t_lo, t_hi):
+        """mean over the samples taken entirely inside [t_lo, t_hi] (seconds since the sampler started)"""
+        self.stop = True
+        self.th.join(timeout=30)
+        ok = [x for x in self.samples if x[0] >= t_lo and x[1] <= t_hi]
+        sc = [x[2] for x in ok if x[2] is not None]
+        pw = [x[3] for x in ok if x[3] is not None]
+        return {"samples": len(ok), "sclk_mhz_mean": round(sum(sc) / len(sc), 1) if sc else None,
+                "socket_power_w_mean": round(sum(pw) / len(pw), 1) if pw else None}
 
 
 def main():
@@ -149,9 +212,11 @@ def main():
     # channel shards: every rank sees the SAME stream (in production: broadcast over xGMI) and owns channels rank, rank + N, ...
     xs = [synth_cf32_torch(nx, M, dev, seed=20260101 + 7919 * (2 * (0 if chan else rank) + i)) for i in range(2)]
     out = torch.empty(M * nf * out_elem // 4, dtype=torch.float32, device=dev)
-    # a hipEvent pair around every launch of the dominant kernel, on its stream (CSDR_FLAG_TIME_REGION would time the K launches
-    # as one region instead: that figure contains the start-up latency of the first launch after the barrier, 7 us per launch at K = 20)
-    flags = _lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS
+    # the timed region carries ONE hipEvent in front of its first launch of the dominant kernel and one behind its last
+    # (CSDR_FLAG_TIME_REGION: total / launches, on the launch stream); the per-launch duration of the kernel itself comes from a
+    # separate pass of K launches with an event pair around every launch (`roofline.launch_ms`): the pairs cost the stream a few us
+    # per launch and stay out of `value`
+    flags = _lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS | _lib.FLAG_TIME_REGION
     if chan:
         from composable_sdr_amd.pipes import ChainConfig
         from composable_sdr_amd.sharded import ShardedChain
@@ -175,33 +240,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    preheat_steps = 0
-    if a.preheat_ms > 0 and use_dist:           # every rank the SAME number of steps (a step may contain a collective): 0.25 ms per step assumed
-        preheat_steps = max(10, int(a.preheat_ms / 0.25))
+    def timed(k, w):
+        for i in range(w):
+            step(i)
+        barrier()
+        chain.kernel_time()
+        t0 = time.perf_counter()
+        for i in range(k):
+            step(i)
+        barrier()
+        d = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d, chain.kernel_time()
+
+    # (0) the contract's W + K steps on an idle board: reported as `cold_window`, never `value`
+    barrier()
+    dt_cold, _ = timed(a.steps, a.warmup)
+    # (1) >= preheat_ms of back-to-back steps, one synchronisation at the end: `sustained_long`, and the state `value` is measured in
+    preheat_steps, sus_long = 0, None
+    if a.preheat_ms > 0:
+        est = max(dt_cold / a.steps, 1e-5)
+        preheat_steps = max(10, int(a.preheat_ms * 1e-3 / est) + 1)
+        if use_dist:                            # every rank the SAME number of steps (a step may contain a collective)
+            t = torch.tensor([preheat_steps], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            preheat_steps = int(t.item())
+        smi = SmiSampler(local) if rank == 0 else None
+        barrier()
+        t_a = time.perf_counter()
         for i in range(preheat_steps):
             step(i)
         torch.cuda.synchronize()
-    elif a.preheat_ms > 0:                      # not part of W or K: load until the clocks have settled (reported as config.preheat_steps)
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < a.preheat_ms * 1e-3:
-            for i in range(10):
-                step(i)
-            torch.cuda.synchronize()
-            preheat_steps += 10
-    for i in range(a.warmup):
-        step(i)
-    barrier()
-    chain.kernel_time()                         # drop pre-heat and warm-up launches
-    t0 = time.perf_counter()
+        t_b = time.perf_counter()
+        d_l = (t_b - t_a) / preheat_steps
+        if smi:
+            # samples from 0.5 s into the run (the power state has settled) to its end
+            board = smi.finish(t_a - smi.t0 + min(0.5, 0.25 * (t_b - t_a)), t_b - smi.t0)
+            sus_long = {"steps": preheat_steps, "seconds": round(t_b - t_a, 3), "ms_per_step": round(d_l * 1e3, 4),
+                        "value": round(nx * (1 if chan else world) / d_l / 1e6, 1), "unit": "MS/s", "board": board}
+    # (2) the contract: W warm-up steps, then EXACTLY K timed steps between barrier + synchronize
+    dt, (kname_r, kms_r, klaunches_r) = timed(a.steps, a.warmup)
+
+    # the dominant kernel's own launch duration: a separate pass of K launches with a hipEvent pair around every launch, on the
+    # launch stream, right behind the timed region (same board state); what rocprofv3's average for the kernel must agree with.
+    # Every rank runs it (no collective inside), rank 0 reports its own.
+    kch = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS,
+                   chan_first=(rank if chan else 0), chan_stride=(world if chan else 0))
+    for i in range(max(a.warmup, 2)):
+        kch.process_device(xs[i & 1].data_ptr(), nx, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    kch.kernel_time()
     for i in range(a.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
-    kname, kms, klaunches = chain.kernel_time()
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        kch.process_device(xs[i & 1].data_ptr(), nx, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    kname, kms, klaunches = kch.kernel_time()
+    kch.close()
 
     # N > 1, time stripes (the default): north_star's own partition -- interleaved channel ownership, every rank on the SAME
     # stream -- measured beside it in the same run and reported under "channel_shard" (strong scaling: the samples are counted once)
@@ -248,6 +344,7 @@ def main():
     alg_bytes_per_sample = 8 + (out_elem / M if a.mix else out_elem)   # read CF32 once + write W
     kavg_ms = kms / max(klaunches, 1)
     achieved = (nx * alg_bytes_per_sample) / (kavg_ms * 1e-3) / 1e9 if klaunches else None
+    kreg_ms = kms_r / max(klaunches_r, 1)
     # HBM bytes per launch from the committed PMC passes of this very configuration (tools/profile_all.sh +
     # tools/collect_all.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc runs); null when it has not been profiled
     tj = {}
@@ -282,8 +379,18 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                      "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4) if achieved else None,
                      "traffic": traffic, "launch_ms": round(kavg_ms, 4), "launches": klaunches,
+                     "traffic_source": "profiles/traffic.json: rocprofv3 --pmc passes of this configuration (FETCH_SIZE x 2 + WRITE_SIZE per launch, "
+                                       "tools/profile_all.sh + tools/collect_all.sh), not re-measured in this run",
+                     "launch_ms_timed_region": round(kreg_ms, 4) if klaunches_r else None,
+                     "frac_timed_region": round(nx * alg_bytes_per_sample / (kreg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if klaunches_r else None,
                      "alg_bytes_per_sample": alg_bytes_per_sample, "samples_per_launch": nx},
+        "cold_window": {"steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt_cold / a.steps * 1e3, 4),
+                        "value": round(total_samples / dt_cold / 1e6, 1), "unit": "MS/s",
+                        "note": "the same W + K steps started on an idle board (no pre-heat): inside the board's power transient"},
     }
+    if sus_long:
+        sus_long["hbm_roofline_frac_whole_step"] = round(sus_long["value"] * 1e6 * alg_bytes_per_sample / 1e9 / (HBM_PEAK_GBS * (1 if chan else world)), 4)
+        res["sustained_long"] = sus_long
 
     if world == 1:
         # beside the contract's K-step window: the same step sustained over 400 launches (what a long stream sees once the board's
@@ -309,7 +416,7 @@ def main():
         torch.cuda.synchronize()
         c0, r0 = ch2.agc_stats()
         t1 = time.perf_counter()
-        reps = max(3, a.steps // 2)
+        reps = max(3, a.steps // 2) if a.preheat_ms <= 0 else max(a.steps, int(min(a.preheat_ms, 1000.0) * 1e-3 / 0.0006))   # ~1 s of steps
         for i in range(reps):
             ch2.process_device(xs[(i + 1) & 1].data_ptr(), nx, out.data_ptr(), stream)
         torch.cuda.synchronize()

@@ -158,7 +158,9 @@ struct csdr_chain {
     bool call_indep = false; hipEvent_t call_ev_tail = nullptr;     // handed to the fused plan by the call in progress
     // entry points share the handle's state: a call on a caller's stream is remembered so that the host-buffer entry point
     // (own stream s_k) can order itself behind it, and the other way round
-    hipStream_t last_user_stream = nullptr; bool user_stream_dirty = false;
+    // (a handle-owned event recorded on the caller's stream behind the call's work: the caller may destroy the stream afterwards)
+    hipEvent_t e_user = nullptr; bool user_stream_dirty = false;
+    bool pd_last_indep = false;      // the previous csdr_chain_submit_device call ran as an independent launch
 };
 
 extern "C" {
@@ -970,24 +972,33 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
 
 static int chain_process_device_any(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream);
 
+// A call on a caller's stream is remembered by an event behind its work, so that the host-buffer entry point (own stream s_k) can
+// order itself behind it without keeping the caller's stream handle
+static int chain_mark_user_stream(csdr_chain *h, hipStream_t stream)
+{
+    if (!h->e_user) CSDR_HIP(hipEventCreateWithFlags(&h->e_user, hipEventDisableTiming));
+    CSDR_HIP(hipEventRecord(h->e_user, stream));
+    h->user_stream_dirty = true;
+    return CSDR_OK;
+}
+
 int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
 {
-    if (h && h->s_pd[0] && !h->in_submit) {
+    if (!h || h->in_submit) return chain_process_device_any(h, d_in, n_in, d_out, n_out, stream);
+    const bool own = h->s_k && (hipStream_t)stream == h->s_k;       // called by csdr_chain_submit / csdr_chain_process on the handle's stream
+    DevGuard guard(h->device);
+    if (!own && h->s_k && h->q_count) CSDR_HIP(hipStreamSynchronize(h->s_k));   // host-buffer chunks still in flight come first
+    if (h->s_pd[0]) {
         // the handle has pipelined chunks (csdr_chain_submit_device): this call follows them, and a later submit follows this call
-        DevGuard guard(h->device);
         for (int i = 0; i < 2; i++) if (h->pd_used[i]) CSDR_HIP(hipStreamWaitEvent((hipStream_t)stream, h->e_pd_done[i], 0));
-        int r = chain_process_device_any(h, d_in, n_in, d_out, n_out, stream);
-        if (r) return r;
+    }
+    int r = chain_process_device_any(h, d_in, n_in, d_out, n_out, stream);
+    if (r) return r;
+    if (h->s_pd[0]) {
         CSDR_HIP(hipEventRecord(h->e_serial, (hipStream_t)stream));
         h->serial_pending = true;
-        if (!h->s_k || (hipStream_t)stream != h->s_k) { h->last_user_stream = (hipStream_t)stream; h->user_stream_dirty = true; }
-        return CSDR_OK;
     }
-    if (h && !h->in_submit && (!h->s_k || (hipStream_t)stream != h->s_k)) {
-        if (h->s_k && h->q_count) { DevGuard guard(h->device); CSDR_HIP(hipStreamSynchronize(h->s_k)); }   // host-buffer chunks still in flight come first
-        h->last_user_stream = (hipStream_t)stream; h->user_stream_dirty = true;
-    }
-    return chain_process_device_any(h, d_in, n_in, d_out, n_out, stream);
+    return own ? CSDR_OK : chain_mark_user_stream(h, (hipStream_t)stream);
 }
 
 static int chain_process_device_any(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
@@ -1120,14 +1131,24 @@ int csdr_chain_submit_device(csdr_chain *h, const void *d_in, uint32_t n_in, voi
     if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
     if (!h->s_pd[0]) {
         CSDR_HIP(hipDeviceSynchronize());               // whatever the handle has queued on caller streams so far
-        for (int i = 0; i < 2; i++) {
-            CSDR_HIP(hipStreamCreateWithFlags(&h->s_pd[i], hipStreamNonBlocking));
-            CSDR_HIP(hipEventCreateWithFlags(&h->e_pd_done[i], hipEventDisableTiming));
+        // created into locals and published together: a partial failure leaves the handle as it was
+        hipStream_t st[2] = {nullptr, nullptr}; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        bool ok = true;
+        for (int i = 0; i < 2 && ok; i++) ok = hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 6 && ok; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            for (hipStream_t q : st) if (q) (void)hipStreamDestroy(q);
+            for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+            (void)hipGetLastError();
+            set_error("chain: cannot create the streams / events of the pipelined entry point");
+            return CSDR_ERR_HIP;
         }
-        for (int i = 0; i < 3; i++) CSDR_HIP(hipEventCreateWithFlags(&h->e_pd_tail[i], hipEventDisableTiming));
-        CSDR_HIP(hipEventCreateWithFlags(&h->e_serial, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) { h->s_pd[i] = st[i]; h->e_pd_done[i] = ev[i]; }
+        for (int i = 0; i < 3; i++) h->e_pd_tail[i] = ev[2 + i];
+        h->e_serial = ev[5];
         if (h->fused) fused_keep_tail(h->fused);
     }
+    if (h->s_k && h->q_count) CSDR_HIP(hipStreamSynchronize(h->s_k));       // host-buffer chunks still in flight come first
     const uint32_t nf = n_in / h->M, k = h->pd_count;
     const int si = (int)(k & 1);
     hipStream_t s = h->s_pd[si];
@@ -1139,6 +1160,9 @@ int csdr_chain_submit_device(csdr_chain *h, const void *d_in, uint32_t n_in, voi
     if (h->serial_pending) { CSDR_HIP(hipStreamWaitEvent(s, h->e_serial, 0)); h->serial_pending = false; }
     if (overlap) {
         if (h->pd_tail_rec) CSDR_HIP(hipStreamWaitEvent(s, h->e_pd_tail[(k + 2) % 3], 0));       // recorded by call k - 1
+        // a call k - 1 that was NOT independent reads the plan's ping-pong state (run 0) that this launch's last run overwrites:
+        // then this launch follows all of it, not only its tail copy
+        if (!h->pd_last_indep && h->pd_used[si ^ 1]) CSDR_HIP(hipStreamWaitEvent(s, h->e_pd_done[si ^ 1], 0));
     } else if (h->pd_used[si ^ 1]) CSDR_HIP(hipStreamWaitEvent(s, h->e_pd_done[si ^ 1], 0));
     h->call_indep = overlap; h->call_ev_tail = h->e_pd_tail[k % 3]; h->in_submit = true;
     const int r = csdr_chain_process_device(h, d_in, n_in, d_out, n_out, s);
@@ -1146,6 +1170,7 @@ int csdr_chain_submit_device(csdr_chain *h, const void *d_in, uint32_t n_in, voi
     if (r) return r;
     h->pd_tail_rec = h->fused && fused_tail_recorded(h->fused);
     if (overlap) h->pd_indep_calls++;
+    h->pd_last_indep = overlap;
     CSDR_HIP(hipEventRecord(h->e_pd_done[si], s));
     h->pd_used[si] = true; h->pd_count = k + 1;
     return CSDR_OK;
@@ -1206,7 +1231,7 @@ int csdr_chain_submit(csdr_chain *h, const float *in, uint32_t n_in, void *out)
     int r;
     if ((r = chain_host_init(h))) return r;
     if (h->user_stream_dirty) {                         // csdr_chain_process_device calls on caller streams precede this chunk
-        CSDR_HIP(hipStreamSynchronize(h->last_user_stream));
+        CSDR_HIP(hipEventSynchronize(h->e_user));
         h->user_stream_dirty = false;
     }
     csdr_chain::HostSlot &sl = h->slot[(h->q_head + h->q_count) % CSDR_CHAIN_INFLIGHT];
@@ -1277,7 +1302,7 @@ int csdr_chain_process(csdr_chain *h, const float *in, uint32_t n_in, void *out,
         DevGuard guard(h->device);
         if (!guard.ok) { set_error("chain: cannot select device %d", h->device); return CSDR_ERR_HIP; }
         if ((r = chain_host_init(h))) return r;
-        if (h->user_stream_dirty) { CSDR_HIP(hipStreamSynchronize(h->last_user_stream)); h->user_stream_dirty = false; }
+        if (h->user_stream_dirty) { CSDR_HIP(hipEventSynchronize(h->e_user)); h->user_stream_dirty = false; }
         csdr_chain::HostSlot &sl = h->slot[0];
         if (!sl.d_in && ((r = dev_alloc(&sl.d_in, h->max_nx)))) return r;
         if (!sl.d_out) { CSDR_HIP(hipMalloc(&sl.d_out, (size_t)h->C * h->max_nf * 8)); }
@@ -1299,6 +1324,7 @@ int csdr_chain_reset(csdr_chain *h)
     CSDR_HIP(hipDeviceSynchronize());                  // chunks still in flight are abandoned
     h->q_head = 0; h->q_count = 0;
     h->pd_used[0] = h->pd_used[1] = false; h->pd_tail_rec = false; h->serial_pending = false; h->pd_count = 0;
+    h->user_stream_dirty = false; h->pd_last_indep = false;
     int r = chain_init_state(h, nullptr);
     if (r) return r;
     CSDR_HIP(hipDeviceSynchronize());
@@ -1390,7 +1416,7 @@ int csdr_chain_destroy(csdr_chain *h)
         for (hipEvent_t e : {sl.e_in, sl.e_k, sl.e_out}) if (e) (void)hipEventDestroy(e);
     }
     for (hipStream_t st : {h->s_in, h->s_k, h->s_out, h->s_pd[0], h->s_pd[1]}) if (st) (void)hipStreamDestroy(st);
-    for (hipEvent_t e : {h->e_pd_done[0], h->e_pd_done[1], h->e_pd_tail[0], h->e_pd_tail[1], h->e_pd_tail[2], h->e_serial}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->e_pd_done[0], h->e_pd_done[1], h->e_pd_tail[0], h->e_pd_tail[1], h->e_pd_tail[2], h->e_serial, h->e_user}) if (e) (void)hipEventDestroy(e);
     delete h;
     return CSDR_OK;
 }

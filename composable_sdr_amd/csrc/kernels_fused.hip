@@ -846,7 +846,7 @@ int fused_reset(FusedPlan *p, hipStream_t s)
     return 0;
 }
 
-void fused_keep_tail(FusedPlan *p) { p->keep_tail = true; }
+void fused_keep_tail(FusedPlan *p) { p->keep_tail = p->cfg.G == 1; }     // interleaved shards never run as independent launches
 bool fused_tail_recorded(const FusedPlan *p) { return p->keep_tail && p->tail_valid; }
 
 static bool fused_v2_call(const FusedPlan *p, uint32_t nf)
@@ -915,7 +915,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         RA.indep = (call.indep && v2 && whole && !c.mix && p->keep_tail && p->tail_valid) ? 1u : 0u;
         RA.prev_tail = p->d_tail[p->tail_w];
         if (call.indep && !RA.indep) { set_error("fused: internal: independent launch requested from a call that cannot run as one"); return -1; }
-        if (p->keep_tail && v2 && whole) {
+        if (p->keep_tail && !shard && v2 && whole && nb_full >= WU + 1) {
             // this chunk's last WU + 1 tiles, for run 0 of the next call (queued in front of the launch: the copy only reads the input)
             const int nxt = (p->tail_w + 1) % 3;
             static const bool nocopy = getenv("CSDR_PD_NOCOPY") != nullptr;      // scheduling experiments only (wrong run-0 starts)

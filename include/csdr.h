@@ -255,7 +255,9 @@ int  csdr_chain_process_device(csdr_chain *h, const void *d_in_cf32, uint32_t n_
  * are accepted and run serialized.
  *   ready_event: hipEvent_t after which d_in is complete, or NULL if it already is when the call is made.
  *   d_in must stay untouched and d_out unread until csdr_chain_wait_device (stream = NULL: the host waits for every
- *   submitted chunk; else `stream` is made to wait).  csdr_chain_process_device orders itself behind submitted chunks. */
+ *   submitted chunk; else `stream` is made to wait).  csdr_chain_process_device orders itself behind submitted chunks.
+ * Stream lifetime: the handle never keeps a caller's `stream`; it records an event of its own behind the call's work, so a
+ * caller stream may be destroyed once the caller itself has no further use for it (its pending work still completes). */
 int  csdr_chain_submit_device(csdr_chain *h, const void *d_in_cf32, uint32_t n_in, void *d_out, uint32_t *n_out, void *ready_event);
 int  csdr_chain_wait_device(csdr_chain *h, void *stream);
 uint32_t csdr_chain_debug_independent_launches(const csdr_chain *h);   /* submit_device calls since create that ran as independent launches */

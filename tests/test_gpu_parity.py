@@ -552,12 +552,14 @@ def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
     env = dict(os.environ, CSDR_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29571", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "8192",
-           "--shard", shard, "--demod", "none", "--no-cpu-baseline", "--no-agc-variant"] + (["--mix"] if mix else [])
+           "--shard", shard, "--demod", "none", "--no-cpu-baseline", "--no-agc-variant", "--preheat-ms", "300"] + (["--mix"] if mix else [])
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
     assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["rccl_ranks"] == 2 and r["value"] > 0
+    assert r["cold_window"]["value"] > 0 and r["sustained_long"]["seconds"] >= 0.3 and r["sustained_long"]["value"] > 0
+    assert r["roofline"]["launches"] == 3 and r["roofline"]["launch_ms"] > 0
     if shard == "channel":
         assert r["scaling"] == "strong" and "channel-interleaved" in r["config"]["sharding"] and "interleaved-shard" in r["config"]["path"]
         assert ("all-reduce" in r["config"]["collective"]) == mix
@@ -1526,6 +1528,30 @@ def test_bench_layout_cfg3_256ch_fm_whole_chunk_matches_oracle():
     _fm_against_oracle(got, xh, M, kf, f"cfg3 {kname}", r)
 
 
+def test_bench_layout_cfg3_256ch_fm_agc_whole_chunk_matches_oracle():
+    """BASELINE configs[2] as literally written (256-ch PFB + AGC `-a 10` + FM) at the bench size, 256 x 262 144: k_run256v2<CF32>
+    + the time-parallel AGC tail against O.Chain(agc_db=10), EVERY sample: mute decisions exactly, open samples within the FM
+    tolerance of test_chain_agc_fm_matches_oracle."""
+    M, nf, kf = 256, 262144, 0.3
+    got, xh, kname, path = _bench_layout(M, nf, 35, demod="fm", kf=kf, agc=10.0)
+    assert kname == "k_run256v2<CF32>" and "agc-spec" in path, (kname, path)
+    want = O.Chain(M, demod="fm", kf=kf, agc_db=10.0).process(xh)
+    assert got.shape == want.shape
+    mism, nopen, med, q = 0, 0, [], []
+    for k0 in range(0, M, 32):
+        sl = slice(k0, k0 + 32)
+        mg, mw = got[sl] == 0, want[sl] == 0
+        mism += int(np.sum(mg != mw)); nopen += int(np.sum(~mw))
+        d = np.abs(wrap_pm(got[sl].astype(np.float64) - want[sl], 1.0 / kf))
+        if (~mw).any():
+            med.append(float(np.median(d[~mw])))
+        q.append(float(np.quantile(d, 0.999)))
+    print(f"cfg3 + AGC [{path}]: whole chunk vs oracle: squelch mismatches {mism}, open fraction {nopen / want.size:.3f}, open-sample median {max(med):.3e}, p99.9 {max(q):.3e}")
+    assert mism == 0
+    assert 0.05 < nopen / want.size < 0.95
+    assert max(med) < 2e-5 and max(q) < 5e-4
+
+
 def test_bench_layout_cfg2_64ch_deno_whole_chunk_matches_oracle():
     """k_run64v2 at 64 x 1 048 576 (BASELINE configs[1]) against O.Chain, every sample."""
     M, nf = 64, 1048576
@@ -1624,35 +1650,60 @@ def test_submit_device_independent_launches_match_serial_calls(demod):
         assert max_abs_err(ga[:, :n_or], want) < 1e-4 * np.abs(want).max()
 
 
-@pytest.mark.parametrize("M,G,demod", [(256, 2, "fm"), (256, 4, "none"), (256, 8, "fm"), (256, 8, "none"), (1024, 8, "fm"), (1024, 2, "fm"), (1024, 4, "none")])
-def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod):
+@pytest.mark.parametrize("M,G,demod,agc", [(256, 2, "fm", 0.0), (256, 4, "none", 0.0), (256, 8, "fm", 0.0), (256, 8, "none", 0.0), (1024, 8, "fm", 0.0), (1024, 2, "fm", 0.0),
+                                           (1024, 4, "none", 0.0), (256, 8, "fm", 10.0), (256, 2, "fm", 10.0)])
+def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod, agc):
     """k_run256v2<.., G> at run-kernel sizes (many runs with cold starts, paired F32 stores, ragged and tiny calls in between,
     state carried from call to call): every shard g must reproduce the rows g, g + G, ... of the whole-band fused chain on the
-    same calls (same kernels upstream of pass 1, so FM agrees to the rounding of a differently pruned butterfly)."""
+    same calls (same kernels upstream of pass 1, so FM agrees to the rounding of a differently pruned butterfly).
+    With the AGC on (k_run256v2<CF32, G> into the shard's [M / G][nf] plane + k_agc_spec on it: the configuration behind the
+    per-rank AGC figures of DESIGN 4.1c) the mute mask must equal the whole band's bit for bit, and the first run-sized call is
+    also compared with rows g::G of the oracle directly."""
     kf = 0.3
+    from composable_sdr_amd import _lib
     # M = 1024: k_run1024v2<FM, G> on the run-sized calls of whole 4-frame tiles, the whole-band kernel + row gather on the others (and for CF32)
     import torch
     from synth import synth_cf32_torch
     frames = [40000, 5, 33, 40016, 16, 40001, 36864] if M == 256 else [12288, 5, 33, 12292, 16, 12289, 8192]
     # (generated on the GPU: numpy takes minutes for 46 M samples of 256 carriers)
     x = synth_cf32_torch(M * sum(frames), M, torch.device("cuda", 0), seed=500 + G, dc=(0.04, 0.03)).cpu().numpy().view(np.complex64).reshape(-1)
-    full = cs.Chain(channels=M, demod=demod, kf=kf, max_frames=max(frames))
+    full = cs.Chain(channels=M, demod=demod, kf=kf, agc=agc, max_frames=max(frames))
     wf, pos = [], 0
     for f in frames:
         wf.append(full.process(x[pos * M:(pos + f) * M])); pos += f
     wf = np.concatenate(wf, axis=1)
     full.close()
+    want_or = O.Chain(M, demod=demod, kf=kf, agc_db=agc).process(x[: M * frames[0]]) if agc else None     # 10 M samples: ~1 s of oracle
     for g in sorted({0, 1, G - 1}):
-        ch = cs.Chain(channels=M, demod=demod, kf=kf, chan_first=g, chan_stride=G, max_frames=max(frames))
+        ch = cs.Chain(channels=M, demod=demod, kf=kf, agc=agc, chan_first=g, chan_stride=G, max_frames=max(frames),
+                      flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
         assert "interleaved-shard" in ch.path
-        got, pos = [], 0
+        got, pos, knames = [], 0, []
         for f in frames:
             got.append(ch.process(x[pos * M:(pos + f) * M])); pos += f
+            knames.append(ch.kernel_time()[0])
         got = np.concatenate(got, axis=1)
         ch.close()
+        if M == 256:                                     # the run-sized calls went through the fused shard kernel itself
+            kwant = f"k_run256v2<{'FM' if (demod == 'fm' and not agc) else 'CF32'}>/G{G}"
+            assert [knames[i] for i in (0, 3, 5, 6)] == [kwant] * 4, (knames, kwant)
         want = wf[g::G]
         assert got.shape == want.shape
-        if demod == "fm":
+        if agc:
+            mism = int(np.sum((got == 0) != (want == 0)))
+            d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
+            op = want != 0
+            print(f"fused shard G={G} g={g} FM + AGC: mute-mask mismatches vs whole band {mism}, open {op.mean():.3f}, open median {np.median(d[op]):.2e}, p99.9 {np.quantile(d, 0.999):.2e}")
+            assert mism == 0
+            assert 0.05 < op.mean() < 0.95
+            assert np.median(d[op]) < 2e-5 and np.quantile(d, 0.999) < 5e-4
+            wo, go = want_or[g::G], got[:, : frames[0]]
+            mo = int(np.sum((go == 0) != (wo == 0)))
+            do = np.abs(wrap_pm(go.astype(np.float64) - wo, 1.0 / kf))
+            print(f"    first call vs oracle rows {g}::{G}: mute-mask mismatches {mo}, open median {np.median(do[wo != 0]):.2e}, p99.9 {np.quantile(do, 0.999):.2e}")
+            assert mo == 0
+            assert np.median(do[wo != 0]) < 2e-5 and np.quantile(do, 0.999) < 5e-4
+        elif demod == "fm":
             d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
             tone = (np.arange(g, M, G) % 4) == 1
             print(f"fused shard G={G} g={g} FM: median {np.median(d):.2e}, tone-channel max {d[tone].max() if tone.any() else 0:.2e}")
@@ -1661,6 +1712,67 @@ def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod):
             e = np.sqrt(np.mean(np.abs(got.astype(np.complex128) - want) ** 2)) / np.sqrt(np.mean(np.abs(wf) ** 2))
             print(f"fused shard G={G} g={g} CF32: rel-rms (of the whole band) {e:.2e}")
             assert e < 2e-6, e
+
+
+def test_fused_interleaved_shard_run_sized_call_matches_oracle_rows():
+    """One run-sized call of the fused shard kernels compared DIRECTLY with the oracle (not with the whole-band kernel):
+    k_run256v2<FM, 8> and k_run256v2<CF32, 2> on 40 000 frames x 256 channels against O.Chain(...)[g::G]; the kernel name is
+    taken from the launch timer, as the bench-layout tests do."""
+    import torch
+    from composable_sdr_amd import _lib
+    from synth import synth_cf32_torch
+    M, nf, kf = 256, 40000, 0.3
+    x = synth_cf32_torch(M * nf, M, torch.device("cuda", 0), seed=611).cpu().numpy().view(np.complex64).reshape(-1)
+    w_fm = O.Chain(M, demod="fm", kf=kf).process(x)
+    w_cf = O.Chain(M).process(x)
+    r = np.abs(w_cf)
+    for G, g, demod in [(8, 3, "fm"), (2, 1, "none"), (4, 2, "fm")]:
+        ch = cs.Chain(channels=M, demod=demod, kf=kf, chan_first=g, chan_stride=G, max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
+        got = ch.process(x)
+        kname = ch.kernel_time()[0]
+        ch.close()
+        assert kname == f"k_run256v2<{'FM' if demod == 'fm' else 'CF32'}>/G{G}", kname
+        if demod == "fm":
+            want, rr = w_fm[g::G], r[g::G]
+            d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
+            rmin = np.minimum(rr, np.concatenate([np.zeros((rr.shape[0], 1), rr.dtype), rr[:, :-1]], axis=1))
+            ref = 1.0 / (2 * np.pi * kf)
+            strong = rmin > 0.25 * r.max()
+            print(f"{kname} g={g} vs oracle rows: median {np.median(d):.2e}, weighted max {(d * rmin).max() / r.max():.2e}, strong max {d[strong].max():.2e}")
+            assert (d * rmin).max() / r.max() < 2 * ref * 1e-4 and np.median(d) < 2e-5 and d[strong].max() < 2e-5
+        else:
+            want = w_cf[g::G]
+            e = np.sqrt(np.mean(np.abs(got.astype(np.complex128) - want) ** 2)) / np.sqrt(np.mean(np.abs(w_cf) ** 2))
+            print(f"{kname} g={g} vs oracle rows: rel-rms (of the whole band) {e:.2e}, max-abs {np.abs(got - want).max():.2e}")
+            assert e < 1e-5 and np.abs(got - want).max() < 1e-4 * np.abs(w_cf).max()
+
+
+def test_submit_device_on_interleaved_shard_with_short_chunks():
+    """csdr_chain_submit_device on a chan_stride = 2 chain with chunks of 1 .. 6 whole tiles.  Shards never
+    run as independent launches and must not save a tail (the copy of the last WU + 1 tiles would read in front of the chunk):
+    same result as csdr_chain_process_device."""
+    import torch
+    from synth import synth_cf32_torch
+    M, kf = 256, 0.3
+    dev = torch.device("cuda", 0)
+    frames = [32, 16, 96, 40000, 48, 7]
+    xd = synth_cf32_torch(M * sum(frames), M, dev, seed=88).view(-1)
+    kw = dict(channels=M, demod="fm", kf=kf, chan_first=1, chan_stride=2, max_frames=max(frames))
+    a, b = cs.Chain(**kw), cs.Chain(**kw)
+    pos, oa, ob = 0, [], []
+    for f in frames:
+        ya = torch.zeros(M // 2 * f, dtype=torch.float32, device=dev); yb = torch.zeros_like(ya)
+        ptr = xd.data_ptr() + pos * M * 8
+        a.submit_device(ptr, M * f, ya.data_ptr())
+        b.process_device(ptr, M * f, yb.data_ptr(), 0)
+        oa.append(ya); ob.append(yb); pos += f
+    a.wait_device()
+    torch.cuda.synchronize()
+    assert a.independent_launches() == 0
+    for f, ya, yb in zip(frames, oa, ob):
+        assert torch.equal(ya, yb), f
+    a.status(); b.status()
+    a.close(); b.close()
 
 
 def test_round3_entry_points_reset_seek_and_fallbacks():
