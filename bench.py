@@ -161,7 +161,7 @@ class SmiSampler:
 
     def finish(self, t_lo, t_hi):
         """mean over the samples taken entirely inside [t_lo, t_hi] (seconds since the sampler started)"""
-        self.stop = True
+        self.stop = True                         # (set by the caller right after the run already: the join below happens later)
         self.th.join(timeout=30)
         ok = [x for x in self.samples if x[0] >= t_lo and x[1] <= t_hi]
         sc = [x[2] for x in ok if x[2] is not None]
@@ -228,6 +228,10 @@ def main():
         chain.seek_frames(rank * a.steps * nf)      # rank r's stripe of one long stream
     stream = torch.cuda.current_stream().cuda_stream
     xv = [x.view(-1) for x in xs]
+    # second handle for the per-launch kernel timing pass behind the timed region (created now: allocations between the two
+    # would be an idle gap)
+    kch = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS,
+                   chan_first=(rank if chan else 0), chan_stride=(world if chan else 0))
 
     def step(i):
         if chan and a.mix:
@@ -260,35 +264,51 @@ def main():
     barrier()
     dt_cold, _ = timed(a.steps, a.warmup)
     # (1) >= preheat_ms of back-to-back steps, one synchronisation at the end: `sustained_long`, and the state `value` is measured in
-    preheat_steps, sus_long = 0, None
+    preheat_steps, sus_long, smi = 0, None, None
     if a.preheat_ms > 0:
         est = max(dt_cold / a.steps, 1e-5)
         preheat_steps = max(10, int(a.preheat_ms * 1e-3 / est) + 1)
-        if use_dist:                            # every rank the SAME number of steps (a step may contain a collective)
-            t = torch.tensor([preheat_steps], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            preheat_steps = int(t.item())
         smi = SmiSampler(local) if rank == 0 else None
-        barrier()
-        t_a = time.perf_counter()
-        for i in range(preheat_steps):
-            step(i)
-        torch.cuda.synchronize()
-        t_b = time.perf_counter()
+        for attempt in range(4):                # the estimate comes from a K-step window: re-run longer until the run lasts preheat_ms
+            if use_dist:                        # every rank the SAME number of steps (a step may contain a collective)
+                t = torch.tensor([preheat_steps], dtype=torch.int64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                preheat_steps = int(t.item())
+            barrier()
+            t_a = time.perf_counter()
+            for i in range(preheat_steps):
+                step(i)
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            el = t_b - t_a
+            if use_dist:
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                el = float(t.item())
+            if el >= 0.9 * a.preheat_ms * 1e-3:
+                break
+            preheat_steps = int(preheat_steps * min(50.0, 1.15 * a.preheat_ms * 1e-3 / max(el, 1e-6))) + 1
         d_l = (t_b - t_a) / preheat_steps
         if smi:
-            # samples from 0.5 s into the run (the power state has settled) to its end
-            board = smi.finish(t_a - smi.t0 + min(0.5, 0.25 * (t_b - t_a)), t_b - smi.t0)
-            sus_long = {"steps": preheat_steps, "seconds": round(t_b - t_a, 3), "ms_per_step": round(d_l * 1e3, 4),
-                        "value": round(nx * (1 if chan else world) / d_l / 1e6, 1), "unit": "MS/s", "board": board}
+            smi.stop = True                     # no join here: an idle gap of 0.1 s in front of the timed region would put the board back
+                                                # into its idle state (first run of this file: 295 us per step behind a 0.3 s join)
+        sus_long = {"steps": preheat_steps, "seconds": round(t_b - t_a, 3), "ms_per_step": round(d_l * 1e3, 4),
+                    "value": round(nx * (1 if chan else world) / d_l / 1e6, 1), "unit": "MS/s"}
     # (2) the contract: W warm-up steps, then EXACTLY K timed steps between barrier + synchronize
     dt, (kname_r, kms_r, klaunches_r) = timed(a.steps, a.warmup)
+    # (3) the same step over 400 further launches (`sustained`), still back to back
+    d_s = None
+    if world == 1:
+        n_sus = 400
+        t_s = time.perf_counter()
+        for i in range(n_sus):
+            step(i)
+        torch.cuda.synchronize()
+        d_s = (time.perf_counter() - t_s) / n_sus
 
     # the dominant kernel's own launch duration: a separate pass of K launches with a hipEvent pair around every launch, on the
     # launch stream, right behind the timed region (same board state); what rocprofv3's average for the kernel must agree with.
     # Every rank runs it (no collective inside), rank 0 reports its own.
-    kch = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS,
-                   chan_first=(rank if chan else 0), chan_stride=(world if chan else 0))
     for i in range(max(a.warmup, 2)):
         kch.process_device(xs[i & 1].data_ptr(), nx, out.data_ptr(), stream)
     torch.cuda.synchronize()
@@ -298,6 +318,9 @@ def main():
     torch.cuda.synchronize()
     kname, kms, klaunches = kch.kernel_time()
     kch.close()
+    if sus_long is not None and smi is not None:
+        # samples from 0.5 s into the long run (the power state has settled) to its end
+        sus_long["board"] = smi.finish(t_a - smi.t0 + min(0.5, 0.25 * (t_b - t_a)), t_b - smi.t0)
 
     # N > 1, time stripes (the default): north_star's own partition -- interleaved channel ownership, every rank on the SAME
     # stream -- measured beside it in the same run and reported under "channel_shard" (strong scaling: the samples are counted once)
@@ -392,17 +415,9 @@ def main():
         sus_long["hbm_roofline_frac_whole_step"] = round(sus_long["value"] * 1e6 * alg_bytes_per_sample / 1e9 / (HBM_PEAK_GBS * (1 if chan else world)), 4)
         res["sustained_long"] = sus_long
 
-    if world == 1:
-        # beside the contract's K-step window: the same step sustained over 400 launches (what a long stream sees once the board's
-        # power state has settled; reported, never `value`)
-        n_sus = 400
-        torch.cuda.synchronize()
-        t_s = time.perf_counter()
-        for i in range(n_sus):
-            step(i)
-        torch.cuda.synchronize()
-        d_s = (time.perf_counter() - t_s) / n_sus
-        res["sustained"] = {"steps": n_sus, "ms_per_step": round(d_s * 1e3, 4), "value": round(nx / d_s / 1e6, 1), "unit": "MS/s",
+    if d_s is not None:
+        # beside the contract's K-step window: the same step over 400 further launches, right behind it
+        res["sustained"] = {"steps": 400, "ms_per_step": round(d_s * 1e3, 4), "value": round(nx / d_s / 1e6, 1), "unit": "MS/s",
                             "hbm_roofline_frac_whole_step": round(nx * alg_bytes_per_sample / d_s / 1e9 / HBM_PEAK_GBS, 4)}
     if chan2:
         res["channel_shard"] = chan2

@@ -48,6 +48,8 @@ void fused_destroy(FusedPlan *plan);
 // run_args points at the RunArgs the first-generation k_run256 would have been launched with.
 int  run256_v2_launch(const void *run_args, bool fm, unsigned G, unsigned nruns, hipStream_t s);
 int  run256_v2_blocks_per_cu(bool fm);
+// third-generation run kernel (kernels_run256_v3.hip): one 512-thread workgroup per CU, front / back wave roles; whole band, no energy words
+int  run256_v3_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s);
 
 
 // M = 64 run kernel (kernels_fused_small.hip): same call interface

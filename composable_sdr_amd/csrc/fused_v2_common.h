@@ -11,6 +11,9 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifndef V2_DMA_AUX
 #define V2_DMA_AUX ""       // cache-policy bits of the tile DMA (" nt", " sc1", ...) for A/B builds
 #endif
+#ifndef V2_DMA_AUX_STREAM
+#define V2_DMA_AUX_STREAM V2_DMA_AUX    // the same for the tiles of a run that no other run's warm-up window covers (dma_tile<true>: selective policy, A/B builds)
+#endif
 
 __device__ __forceinline__ void bar()              // LDS-only barrier: outstanding global stores / LDS-DMA are not waited for
 {
@@ -32,6 +35,7 @@ __device__ __forceinline__ unsigned dma_offset(int tid)
     const int slot = 64 * wave + lane, q = slot >> 3, i = (slot & 7) ^ ((q >> 1) & 7);
     return (unsigned)(8 * q + i) * 16u;
 }
+template <bool STREAM = false>
 __device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, unsigned goff, unsigned lds_wave)
 {
     // the eight destination addresses are recomputed per call (one s_add each): as loop invariants they are sixteen SGPRs that
@@ -42,8 +46,12 @@ __device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, u
         const unsigned dst = lds_wave + 4096u * (unsigned)it;
         const float4 *src = tile_base + 256 * it;
         unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3" V2_DMA_AUX "\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(goff), "s"(dst), "s"(src) : "memory");
+        if (STREAM)
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3" V2_DMA_AUX_STREAM "\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(goff), "s"(dst), "s"(src) : "memory");
+        else
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3" V2_DMA_AUX "\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(goff), "s"(dst), "s"(src) : "memory");
     }
 }
 

@@ -740,6 +740,7 @@ struct FusedPlan {
     uint32_t resident_wgs = 512;     // workgroups of k_run256 the device holds at once
     uint32_t resident_wgs_v2 = 512;  // workgroups of k_run256v2 the device holds at once
     bool use_v2 = true;              // CSDR_RUN_V1=1: first-generation run kernel (A/B)
+    bool use_v3 = false;             // CSDR_RUN_V3=1: k_run256v3 (one 512-thread workgroup per CU, front / back wave roles) for whole-band calls
     // independent launches (csdr_chain_submit_device): the last WU + 1 raw tiles of the previous chunk, three slots (the launch
     // two calls back may still be reading its slot when this call's copy is queued on the other stream)
     float *d_shard_tail = nullptr;   // interleaved shard: whole-band result of a call's ragged end, [256][< 16] CF32 at most
@@ -824,6 +825,7 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
         p->resident_wgs_v2 = (uint32_t)(cus * run256_v2_blocks_per_cu(cfg.fm));
         if (const char *e = getenv("CSDR_RESIDENT_WGS")) p->resident_wgs = p->resident_wgs_v2 = (uint32_t)atol(e);
         if (const char *e = getenv("CSDR_RUN_V1")) p->use_v2 = atoi(e) == 0;
+        if (const char *e = getenv("CSDR_RUN_V3")) p->use_v3 = atoi(e) != 0;
         if (const char *e = getenv("CSDR_RUN_WEIGHTS")) {
             int k = 0;
             for (const char *q = e; *q && k < 8; k++) { p->slot_weight[k] = (float)atof(q); q = strchr(q, ','); if (!q) break; q++; }
@@ -884,14 +886,17 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         // whole-band calls whose output fits 32-bit byte offsets take the second-generation kernel
         const bool v2 = shard || (p->use_v2 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32));
         if (A.energy && !v2) { set_error("fused: energy words requested from a call that takes k_run256 (shard or output >= 4 GiB)"); return -1; }   // CSDR_ERR_INVALID
-        p->name = v2 ? (c.fm ? "k_run256v2<FM>" : "k_run256v2<CF32>") : (c.fm ? "k_run256<FM>" : "k_run256<CF32>");
+        // third generation: one 512-thread workgroup per CU (half the cold starts), whole band, no energy words
+        const bool v3 = v2 && !shard && p->use_v3 && !A.energy;
+        p->name = v3 ? (c.fm ? "k_run256v3<FM>" : "k_run256v3<CF32>") : (v2 ? (c.fm ? "k_run256v2<FM>" : "k_run256v2<CF32>") : (c.fm ? "k_run256<FM>" : "k_run256<CF32>"));
         if (shard) p->name += "/G" + std::to_string(c.G);
         RunArgs RA{};
         A.nf = nb_full * NB; A.nb = nb_full;
         RA.t = A; RA.yfirst = p->d_yfirst; RA.pk = phase_consts(c.fm_ref);
         // one run per resident workgroup slot (a single round), runs balanced to within one tile,
         // at least 8 tiles per run so that the warm-up reads stay below 7/8 of a run
-        uint32_t nruns = v2 ? p->resident_wgs_v2 : p->resident_wgs;
+        uint32_t nruns = v3 ? p->cus : (v2 ? p->resident_wgs_v2 : p->resident_wgs);
+        if (v3) { if (const char *e = getenv("CSDR_V3_RUNS")) nruns = (uint32_t)atol(e); }
         if (nruns > A.nb / 8) nruns = A.nb / 8;
         if (nruns < 1) nruns = 1;
         RA.nruns = nruns; RA.S = (A.nb + nruns - 1) / nruns;
@@ -927,6 +932,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         if (timer && (r = timer->begin(s))) return r;
         static const size_t extra_lds = getenv("CSDR_EXTRA_LDS") ? (size_t)atol(getenv("CSDR_EXTRA_LDS")) : 0;   // occupancy experiments
         if (nb_full == 0) { /* shard, fewer than 16 frames: the tile kernel below does the whole call */ }
+        else if (v3) { if ((r = run256_v3_launch(&RA, c.fm, nruns, s))) return r; }
         else if (v2) { if ((r = run256_v2_launch(&RA, c.fm, c.G, nruns, s))) return r; }
         else if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), extra_lds, s, RA);
         else hipLaunchKernelGGL(k_run256<false>, dim3(nruns), dim3(256), extra_lds, s, RA);

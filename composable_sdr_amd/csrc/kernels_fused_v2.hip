@@ -28,6 +28,12 @@
 #define V2_ABLATE 0      // timing experiments only: 1 no input DMA in the loop, 2 no output stores, 4 no freqdem, 8 one FIR tap, 16 no butterflies in the two DFT passes, 32 no DC scan arithmetic, 64 no y' write-back, 128 no Z write (one LDS pass less each)
 #endif
 
+#ifndef V2_COLSCAN
+#define V2_COLSCAN 0     // 1 (A/B build, verdict r03 #1 (iii)): no row-layout scan pass over the tile image -- the raw column is read once
+                         // (b64, column layout) and the in-run part of the DC blocker runs on the registers as 16-lane DPP row scans
+                         // (fused_common.h: col_run_scan / col_run_carries, k_run256's scheme): two LDS passes of the tile less
+                         // (scan read + y' write-back), 2 KiB of run totals + 2 KiB of run carries instead
+#endif
 #ifndef V2_PAIR
 #define V2_PAIR 1       // FM: whole 128-byte row lines per tile pair (0: every tile stores its own 64-byte halves, for A/B)
 #endif
@@ -56,7 +62,7 @@ namespace {
 constexpr int V2_BUF = 4096;                       // float2 per tile buffer (32 KiB)
 // two tile buffers, then: STASH 256, T 16, RED 16, pass-1 twiddles 256
 constexpr int V2_STASH = 2 * V2_BUF;
-constexpr int V2_F2 = V2_STASH + 256 + 32 + 256;   // 8736 float2 = 69 888 B: two workgroups per CU
+constexpr int V2_F2 = V2_STASH + 256 + 32 + 256 + (V2_COLSCAN ? 512 : 0);   // 8736 float2 = 69 888 B: two workgroups per CU (V2_COLSCAN: + run totals and run carries, 73 984 B)
 
 struct V2Args {
     RunArgs r;
@@ -81,6 +87,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     __shared__ __attribute__((aligned(16))) float2 L[V2_F2];
     float2 *R = L, *ST = L + V2_STASH, *Tt = ST + 256, *red = Tt + 16;
     float2 *tw_s = red + 16;
+    float2 *TRc = tw_s + 256, *Ec = TRc + 256;          // V2_COLSCAN: run totals, run carries of the tile in work
+    (void)TRc; (void)Ec;
     float2 *H = L + V2_BUF;                             // run start only: the halo tile's image, then scratch of the one-frame DFT (buffer 1 is free until the first tile's B_a)
     float2 *E = ST;                                     // run start only: 256 run carries (the stash area, before the stash is initialised)
     const int tid = threadIdx.x, j = tid;
@@ -300,7 +308,42 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b_ * 16 + 15] = __builtin_amdgcn_s_memrealtime();
         bar();                                          // B_a: the tile image has landed (every wave waited for its own DMA); the other buffer is free
         V2STAMP(1);
+#ifdef V2_SELECTIVE_POLICY
+        // A/B builds (verdict r03 #1 (ii)): the last WU + 1 tiles of a run are the next run's warm-up window + halo, already fetched once
+        // at the launch's start; every other tile is read exactly once per launch and gets the streaming policy
+        if (!(V2_ABLATE & 1) && b + 1 < last) {
+            if (b + 1 + (WU + 1) < last) dma_tile<true>(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
+            else dma_tile(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
+        }
+#else
         if (!(V2_ABLATE & 1) && b + 1 < last) dma_tile(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
+#endif
+#if V2_COLSCAN
+        // ---- DC blocker on the column-layout registers: thread j reads its raw column once; a run of 16 consecutive samples is one
+        // 16-lane DPP row of one frame, so the zero-state scan inside a run is four v_fmac_dpp steps per component (col_run_scan);
+        // the run totals cross the frame through 2 KiB of LDS (col_run_carries: carry into every run from the earlier runs of its
+        // frame, frame totals), the frame states V[f] chain in registers as before
+#pragma unroll
+        for (int f = 0; f < NB; f++) nw[f] = Bf[256 * f + col_off];
+        col_run_scan(nw, TRc, A, tid);
+        V2STAMP(2);
+        bar();                                          // B_c: run totals visible
+        col_run_carries(TRc, Ec, Tt, A, tid);
+        bar();                                          // B_c2: run carries and frame totals visible
+        V2STAMP(3);
+        {
+            v2f V = to_v(c);
+            const float kj = -A.alpha * A.bj[j & 15];
+            const v2f kJv = {kJ, kJ}, bv = {b256, b256}, kjv = {kj, kj};
+#pragma unroll
+            for (int f = 0; f < NB; f++) {
+                v2f y = __builtin_elementwise_fma(V, kJv, to_v(nw[f]));
+                nw[f] = to_f2(__builtin_elementwise_fma(to_v(Ec[16 * f + (j >> 4)]), kjv, y));
+                V = __builtin_elementwise_fma(V, bv, to_v(Tt[f]));
+            }
+            c = to_f2(V);
+        }
+#else
         // ---- DC blocker inside a frame: thread q owns the run of 16 consecutive samples q.  First the run total (zero state),
         // a decayed DPP row scan over the 16 runs of the frame gives the state e at my run's start (frame state still
         // missing: it is added in column layout below), then the blocker itself from that state
@@ -349,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             }
             c = to_f2(V);
         }
+#endif
         if (b + 1 == A.nb) {                            // the stream's last 13 frames of y
 #pragma unroll
             for (int f = 3; f < NB; f++) A.yhist_out[(f - 3) * M256 + j] = nw[f];

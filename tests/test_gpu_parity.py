@@ -558,7 +558,7 @@ def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
     assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["rccl_ranks"] == 2 and r["value"] > 0
-    assert r["cold_window"]["value"] > 0 and r["sustained_long"]["seconds"] >= 0.3 and r["sustained_long"]["value"] > 0
+    assert r["cold_window"]["value"] > 0 and r["sustained_long"]["seconds"] >= 0.25 and r["sustained_long"]["value"] > 0
     assert r["roofline"]["launches"] == 3 and r["roofline"]["launch_ms"] > 0
     if shard == "channel":
         assert r["scaling"] == "strong" and "channel-interleaved" in r["config"]["sharding"] and "interleaved-shard" in r["config"]["path"]
@@ -1773,6 +1773,48 @@ def test_submit_device_on_interleaved_shard_with_short_chunks():
         assert torch.equal(ya, yb), f
     a.status(); b.status()
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("demod", ["fm", "none"])
+def test_run256_v3_matches_second_generation_kernel_and_oracle(demod, monkeypatch):
+    """k_run256v3 (one 512-thread workgroup per CU, front / back wave roles, CSDR_RUN_V3=1) on run-sized, ragged and small calls
+    with the state carried from call to call, against k_run256v2 on the same calls (same arithmetic per tile; the run starts sit
+    elsewhere, so the agreement is the run-start tolerance) and against the oracle on the first calls."""
+    import torch
+    from composable_sdr_amd import _lib
+    from synth import synth_cf32_torch
+    M, kf = 256, 0.3
+    frames = [40000, 33, 40016, 16, 40001, 36864, 32768 + 16]
+    x = synth_cf32_torch(M * sum(frames), M, torch.device("cuda", 0), seed=4242, dc=(0.09, -0.04)).cpu().numpy().view(np.complex64).reshape(-1)
+    kw = dict(channels=M, demod=demod, kf=kf, max_frames=max(frames), flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
+    monkeypatch.setenv("CSDR_RUN_V3", "1")
+    a = cs.Chain(**kw)
+    monkeypatch.setenv("CSDR_RUN_V3", "0")
+    b = cs.Chain(**kw)
+    ga, gb, pos, names = [], [], 0, []
+    for f in frames:
+        xa = x[pos * M:(pos + f) * M]
+        ga.append(a.process(xa)); gb.append(b.process(xa)); pos += f
+        names.append((a.kernel_time()[0], b.kernel_time()[0]))
+    a.close(); b.close()
+    tag = "FM" if demod == "fm" else "CF32"
+    assert [n[0] for i, n in enumerate(names) if frames[i] >= 32768] == [f"k_run256v3<{tag}>"] * 5, names
+    assert [n[1] for i, n in enumerate(names) if frames[i] >= 32768] == [f"k_run256v2<{tag}>"] * 5, names
+    ga, gb = np.concatenate(ga, axis=1), np.concatenate(gb, axis=1)
+    n_or = sum(frames[:3])
+    want = O.Chain(M, demod=demod, kf=kf).process(x[: M * n_or])
+    if demod == "fm":
+        d = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / kf))
+        do = np.abs(wrap_pm(ga[:, :n_or].astype(np.float64) - want, 1.0 / kf))
+        ds = np.abs(wrap_pm(gb[:, :n_or].astype(np.float64) - want, 1.0 / kf))
+        print(f"k_run256v3 vs v2 FM: tone channels max {d[1::4].max():.3e}, median {np.median(d):.3e}; vs oracle tone p99.9 {np.quantile(do[1::4], 0.999):.3e} (v2: {np.quantile(ds[1::4], 0.999):.3e})")
+        assert d[1::4].max() < 5e-6 and np.median(d) < 5e-6
+        assert np.quantile(do[1::4], 0.999) < 2e-5 and np.median(do) < 1.05 * np.median(ds) + 1e-7
+    else:
+        print(f"k_run256v3 vs v2 CF32: rel-rms {rel_rms(ga, gb):.3e}; vs oracle {rel_rms(ga[:, :n_or], want):.3e} (v2: {rel_rms(gb[:, :n_or], want):.3e})")
+        assert rel_rms(ga, gb) < 1e-6
+        assert rel_rms(ga[:, :n_or], want) < 1.05 * rel_rms(gb[:, :n_or], want) + 1e-7 and rel_rms(ga[:, :n_or], want) < 3e-5
+        assert max_abs_err(ga[:, :n_or], want) < 1e-4 * np.abs(want).max()
 
 
 def test_round3_entry_points_reset_seek_and_fallbacks():
