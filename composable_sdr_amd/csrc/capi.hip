@@ -140,7 +140,6 @@ struct csdr_chain {
     DcTilePlan *dctile = nullptr;   // generic path with the DC blocker: single-pass scan kernel
     uint32_t n_cus = 256;            // compute units of the device (run count of the fused M = 1024 kernel)
     AgcTailPlan *agc_tail = nullptr; // AGC on: time-parallel verified tail (unless CSDR_FLAG_AGC_SEQUENTIAL)
-    AgcMaskPlan *agc_mask = nullptr; // fused M = 256 FM chain with the AGC on: the run kernel writes freqdem(Y) + energy words, the AGC is a mask pass
     // DeAM: the chain runs as DeNo into d_amz, then the ampmodem peak detector (kernels_am.hip) [+ mix]
     bool am = false, am_mix = false;
     // DeWBFM: the chain runs as DeNBFM 0.6 into d_wbf, then de-emphasis + decimator (kernels_wbfm.hip) [+ mix]
@@ -741,14 +740,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         FusedConfig fc{};
         fc.M = M; fc.p = h->p; fc.C = C; fc.c0 = c0; fc.max_nf = h->max_nf; fc.G = G;
         fc.dc_block = cfg->dc_block != 0; fc.dc = h->dc;
-        // FM + AGC on the whole-band M = 256 plan, CSDR_AGC_FM_MASK=1: the gain drops out of arg(conj(y') y), so the run kernel
-        // demodulates the channelizer output itself and leaves an energy word per sample; the AGC is a mask pass over those
-        // (kernels_agc_mask.hip).  2.0 GB instead of 2.6 GB per 67 M samples and identical mute decisions, but 627 us against
-        // 601 us per step: not the default.
-        const bool mask_route = agc_on && cfg->demod == CSDR_DEMOD_FM && !cfg->mix && fused_supported(M, h->p) && !small_supported(M, h->p) &&
-                                !big_supported(M, h->p) && c0 == 0 && C == M && (uint64_t)C * h->max_nf * 8u < (1ull << 32) &&
-                                !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL) && getenv("CSDR_AGC_FM_MASK") && !getenv("CSDR_RUN_V1");   // opt-in: measured slower
-        fc.fm = cfg->demod == CSDR_DEMOD_FM && (!agc_on || mask_route); fc.fm_ref = h->fm_ref;
+        fc.fm = cfg->demod == CSDR_DEMOD_FM && !agc_on; fc.fm_ref = h->fm_ref;
         fc.mix = cfg->mix != 0 && !agc_on; fc.taps = h->taps.data(); fc.d_theta = h->d_theta;
         if (small_supported(M, h->p)) {
             if ((r = small_create(fc, &h->small))) return fail(r);
@@ -762,10 +754,6 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             if ((r = fused_create(fc, &h->fused))) return fail(r);
             h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (G > 1 ? "+interleaved-shard" : "") + (agc_on ? "+agc" : "");
             h->timed_kernel = fused_name(h->fused);
-            if (mask_route && fused_whole_band_v2(h->fused)) {
-                if ((r = agc_mask_create(C, h->max_nf, &h->agc_mask))) return fail(r);
-                h->path += "-mask";
-            } else if (mask_route) { set_error("chain: internal: mask route without k_run256v2"); return fail(CSDR_ERR_INVALID); }
         }
         if (agc_on) {
             // d_A: channel-major CF32 from the channelizer; d_B: per-channel tail output in front of --mix
@@ -824,7 +812,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         CSDR_HIP_CLEAN(hipMemcpy(h->d_wbh, taps.data(), sizeof(float) * taps.size(), hipMemcpyHostToDevice), csdr_chain_destroy(h));
         h->path += "+wbfm";
     }
-    if (h->d_agc && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL) && !h->agc_mask) {
+    if (h->d_agc && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL)) {
         if ((r = agc_tail_create(C, h->max_nf, &h->agc_tail))) return fail(r);
         h->path += h->use_fused ? "-spec" : "+agc-spec";
     }
@@ -837,6 +825,10 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
                "nco.d_theta=0x%08x dc_block=%u(alpha=%g) agc=%g dB demod=%s kf=%g mix=%u\n",
                h->path.c_str(), dev, M, c0, c0 + C - 1, M > 1 ? M * h->p : 0, m, As, h->d_theta, cfg->dc_block,
                cfg->dc_alpha, cfg->agc_threshold_db, am ? "AM" : (wbfm ? "WBFM" : (cfg->demod == CSDR_DEMOD_FM ? "FM" : "none")), cfg->kf, cfg_in->mix);
+        // per-channel outputs / AGC / demod tails beyond the fused kernels' channel counts run stage by stage through HBM
+        if (!h->use_fused && !h->mix_identity && M > 1024)
+            printf("csdr chain: note: %u channels with per-channel output run on the any-M route (DC blocker, FIR, DFT and tail as separate kernels, "
+                   "~0.09 of the HBM roofline on MI355X); fused kernels exist for 64, 256 and 1024 channels, and for DeNo --mix over all channels of any count\n", M);
         fflush(stdout);
     }
     *out = h;
@@ -1060,19 +1052,6 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         FusedCall fcall{};
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         fcall.indep = h->call_indep; fcall.ev_tail = h->call_ev_tail;
-        if (h->agc_mask) {
-            // the last channelizer frame of the call before this one.  Snapshot it: a run-sized call with a ragged tail flips the
-            // plan's ping-pong twice, so the k_tile256 tail launch writes the very buffer fused_rp_next() names now (the chain's own
-            // d_rp pair is idle on this route: the fused plan keeps the freqdem history)
-            CSDR_HIP(hipMemcpyAsync(h->d_rp[0], fused_rp_next(h->fused), sizeof(float2) * h->C, hipMemcpyDeviceToDevice, s));
-            const float2 *rp_prev = h->d_rp[0];
-            fcall.d_out = d_out; fcall.d_energy = reinterpret_cast<float *>(h->d_A); fcall.agc_alpha = h->agc.alpha;
-            if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
-            h->theta += n_in * h->d_theta;
-            if ((r = agc_mask_process(h->agc_mask, reinterpret_cast<const float *>(h->d_A), (float *)d_out, nf, h->d_agc, h->agc, h->fm_ref, rp_prev, s))) return r;
-            if (n_out) *n_out = h->C * nf;
-            return CSDR_OK;
-        }
         if (h->small) { if ((r = small_process(h->small, fcall, s, &h->timer))) return r; h->timed_kernel = small_name(h->small); }   // k_run64v2 or k_run64, by call
         else if (h->big) { if ((r = big_process(h->big, fcall, s, &h->timer))) return r; h->timed_kernel = big_name(h->big); }   // k_run1024v2 or k_run1024, by call
         else if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
@@ -1155,7 +1134,7 @@ int csdr_chain_submit_device(csdr_chain *h, const void *d_in, uint32_t n_in, voi
     // An independent launch (fused M = 256 chain without AGC / AM / WBFM tails, run-kernel-sized whole-tile chunk, previous
     // chunk's tail on file) reads nothing an earlier launch writes: it only waits for the input and for the copy of the
     // previous chunk's tail.  Every other call is ordered behind everything the handle has in flight.
-    const bool overlap = h->use_fused && h->fused && !h->d_agc && !h->am && !h->wbfm && !h->agc_mask && fused_can_overlap(h->fused, nf);
+    const bool overlap = h->use_fused && h->fused && !h->d_agc && !h->am && !h->wbfm && fused_can_overlap(h->fused, nf);
     if (ready_event) CSDR_HIP(hipStreamWaitEvent(s, (hipEvent_t)ready_event, 0));
     if (h->serial_pending) { CSDR_HIP(hipStreamWaitEvent(s, h->e_serial, 0)); h->serial_pending = false; }
     if (overlap) {
@@ -1370,10 +1349,10 @@ int csdr_chain_debug_agc(csdr_chain *h, uint32_t *checked, uint32_t *redone)
     if (!h) return CSDR_ERR_INVALID;
     if (checked) *checked = 0;
     if (redone) *redone = 0;
-    if (!h->agc_tail && !h->agc_mask) return 0;
+    if (!h->agc_tail) return 0;
     DevGuard guard(h->device);
     (void)hipDeviceSynchronize();
-    return h->agc_mask ? agc_mask_stats(h->agc_mask, checked, redone) : agc_tail_stats(h->agc_tail, checked, redone);
+    return agc_tail_stats(h->agc_tail, checked, redone);
 }
 const char *csdr_chain_path(const csdr_chain *h) { return h ? h->path.c_str() : ""; }
 
@@ -1402,7 +1381,6 @@ int csdr_chain_destroy(csdr_chain *h)
     if (h->big) big_destroy(h->big);
     if (h->dctile) dctile_destroy(h->dctile);
     if (h->agc_tail) agc_tail_destroy(h->agc_tail);
-    if (h->agc_mask) agc_mask_destroy(h->agc_mask);
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
                     h->d_agc, h->d_rp[0], h->d_rp[1], h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1], h->d_tw_g, h->d_fold_ph, h->d_fold, h->d_u0, h->d_u0hist,

@@ -157,14 +157,6 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
 int agc_tail_stats(AgcTailPlan *p, unsigned *checked, unsigned *redone);
 void agc_tail_reset(AgcTailPlan *p);     // the AGC state was re-initialised: the next call pilots (kernels_agc_tail.hip)
 
-// ---- AGC + squelch behind an FM chain as a mask pass over 4-byte energy words (kernels_agc_mask.hip) ----
-struct AgcMaskPlan;
-int agc_mask_create(uint32_t C, uint32_t max_nf, AgcMaskPlan **out);
-void agc_mask_destroy(AgcMaskPlan *p);
-int agc_mask_process(AgcMaskPlan *p, const float *E, float *out, uint32_t nf, AgcState *st, const AgcParams &prm, float fm_ref,
-                     const float2 *rp_prev, hipStream_t s);
-int agc_mask_stats(AgcMaskPlan *p, unsigned *checked, unsigned *redone);
-
 // ---- hipEvent bracket around the dominant kernel (CSDR_FLAG_TIME_KERNELS) ----
 struct KernelTimer {
     std::vector<hipEvent_t> ev;          // pairs

@@ -20,8 +20,6 @@ struct FusedCall {
     void *d_out;             // [C][nf] CF32 / F32, or [nf] when mixing
     uint32_t nf;
     uint32_t theta0;         // NCO phase of the first sample
-    float *d_energy = nullptr;   // FM plans, optional: [C][nf] energy words for the AGC mask pass (fused_common.h: agc_energy_word)
-    float agc_alpha = 0.f;
     // pipelined entry point (csdr_chain_submit_device): run the launch without reading anything an earlier launch wrote, if the
     // plan can (fused_can_overlap); ev_tail is recorded on s once the chunk's last tiles are saved for the next call's run 0
     bool indep = false;
@@ -36,8 +34,6 @@ int  fused_create(const FusedConfig &cfg, FusedPlan **out);
 int  fused_reset(FusedPlan *plan, hipStream_t s);
 int  fused_process(FusedPlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
 const char *fused_name(const FusedPlan *plan);
-const float2 *fused_rp_next(const FusedPlan *plan);   // [C] freqdem r' (last Y frame) the NEXT call starts from
-bool fused_whole_band_v2(const FusedPlan *plan);       // large calls take k_run256v2 (energy words are emitted by it and by k_tile256 only)
 void fused_seek(FusedPlan *plan, uint64_t frames);   // after fused_reset: global frame index of the next frame
 // sticky device-side error word (bit0/bit1: an inter-workgroup wait hit its spin limit); reads, then clears it; synchronises
 int  fused_status(FusedPlan *plan, unsigned *status);
@@ -48,7 +44,7 @@ void fused_destroy(FusedPlan *plan);
 // run_args points at the RunArgs the first-generation k_run256 would have been launched with.
 int  run256_v2_launch(const void *run_args, bool fm, unsigned G, unsigned nruns, hipStream_t s);
 int  run256_v2_blocks_per_cu(bool fm);
-// third-generation run kernel (kernels_run256_v3.hip): one 512-thread workgroup per CU, front / back wave roles; whole band, no energy words
+// third-generation run kernel (kernels_run256_v3.hip): one 512-thread workgroup per CU, front / back wave roles; whole band
 int  run256_v3_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s);
 
 

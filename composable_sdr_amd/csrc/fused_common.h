@@ -252,15 +252,6 @@ template <int CTRL> __device__ __forceinline__ float dpp(float v)
 }
 template <int CTRL> __device__ __forceinline__ float2 dpp2(float2 v) { return make_float2(dpp<CTRL>(v.x), dpp<CTRL>(v.y)); }
 
-// what the AGC mask pass (kernels_agc_mask.hip) reads instead of the channelizer output: agc_energy() of agc_common.h, bit for
-// bit, with the sign bit (free: the value is >= 0) telling whether both components of Y are negative (the only thing the
-// freqdem sample next to a muted one depends on)
-__device__ __forceinline__ float agc_energy_word(float2 y, float alpha)
-{
-    const float e = alpha * fmaf(y.x, y.x, y.y * y.y);
-    return __uint_as_float(__float_as_uint(e) | (__float_as_uint(y.x) & __float_as_uint(y.y) & 0x80000000u));
-}
-
 struct TileArgs {
     const float2 *x;            // new input, nf*256 samples
     void *out;                  // [C][nf] F32 (FM) or CF32
@@ -279,8 +270,6 @@ struct TileArgs {
     uint32_t epoch, nf, nb, c0, C, parity0;
     uint32_t out_stride, out_t0;   // output row length (frames of the whole call) and this launch's first frame in it
     float alpha, beta, fm_ref;
-    float *energy;              // FM only, optional: [C][nf] agc_alpha |Y|^2 of every output sample, sign bit = (re < 0 && im < 0): all the AGC mask pass needs
-    float agc_alpha;
     float wtile[LOOKBACK + 2];  // beta^(4096 k)
     float b16[16];              // beta^(16 r)
     float b256[17];             // beta^(256 f)

@@ -308,19 +308,6 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
 #pragma unroll
                 for (int f = 0; f < NB; f++) if (f < nvalid) o[f] = m[f];
             }
-            if (A.energy) {                             // the AGC mask pass's input
-                float *eo = A.energy + row;
-#pragma unroll
-                for (int f = 0; f < NB; f++) m[f] = agc_energy_word(v[f], A.agc_alpha);
-                if (((A.out_stride | A.out_t0) % 4u) == 0 && nvalid == NB) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        *reinterpret_cast<float4 *>(eo + 4 * q) = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
-                } else {
-#pragma unroll
-                    for (int f = 0; f < NB; f++) if (f < nvalid) eo[f] = m[f];
-                }
-            }
         }
     } else if (owned) {
         float2 *o = (float2 *)A.out + row;
@@ -875,7 +862,6 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     A.vend_in = p->d_vend[p->cur];   A.vend_out = p->d_vend[p->cur ^ 1];
     A.rp_in = p->d_rp[p->cur];       A.rp_out = p->d_rp[p->cur ^ 1];
     A.out_stride = nf; A.out_t0 = 0;
-    A.energy = (c.fm && !c.mix) ? call.d_energy : nullptr; A.agc_alpha = call.agc_alpha;
     A.parity0 = (uint32_t)(p->frames_done & 1);
     const uint32_t nb_full = nf / NB;
     const bool shard = c.G > 1;      // interleaved shard: every whole tile goes through k_run256v2<.., G> (the tile kernel only knows whole bands)
@@ -885,9 +871,8 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         // a second launch of the tile kernel on the state the run kernel leaves behind
         // whole-band calls whose output fits 32-bit byte offsets take the second-generation kernel
         const bool v2 = shard || (p->use_v2 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32));
-        if (A.energy && !v2) { set_error("fused: energy words requested from a call that takes k_run256 (shard or output >= 4 GiB)"); return -1; }   // CSDR_ERR_INVALID
-        // third generation: one 512-thread workgroup per CU (half the cold starts), whole band, no energy words
-        const bool v3 = v2 && !shard && p->use_v3 && !A.energy;
+        // third generation: one 512-thread workgroup per CU (half the cold starts), whole band
+        const bool v3 = v2 && !shard && p->use_v3;
         p->name = v3 ? (c.fm ? "k_run256v3<FM>" : "k_run256v3<CF32>") : (v2 ? (c.fm ? "k_run256v2<FM>" : "k_run256v2<CF32>") : (c.fm ? "k_run256<FM>" : "k_run256<CF32>"));
         if (shard) p->name += "/G" + std::to_string(c.G);
         RunArgs RA{};
@@ -944,7 +929,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         if (rem) {
             if (nb_full) p->cur ^= 1;                            // the tail starts from the run kernel's state
             TileArgs T = p->proto;
-            T.x = call.d_in + (size_t)nb_full * NB * c.M; T.out = A.out; T.energy = A.energy; T.agc_alpha = A.agc_alpha;
+            T.x = call.d_in + (size_t)nb_full * NB * c.M; T.out = A.out;
             if (shard) { T.c0 = 0; T.C = c.M; T.out = p->d_shard_tail; }   // whole band into [256][rem], the owned rows are gathered below
             T.yhist_in = p->d_yhist[p->cur]; T.yhist_out = p->d_yhist[p->cur ^ 1];
             T.vend_in = p->d_vend[p->cur];   T.vend_out = p->d_vend[p->cur ^ 1];
@@ -980,8 +965,6 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     return 0;
 }
 
-const float2 *fused_rp_next(const FusedPlan *p) { return p->d_rp[p->cur]; }
-bool fused_whole_band_v2(const FusedPlan *p) { return p->use_v2 && p->cfg.c0 == 0 && p->cfg.C == p->cfg.M && (uint64_t)p->cfg.C * p->cfg.max_nf * 8u < (1ull << 32); }
 const char *fused_name(const FusedPlan *p) { return p->name.c_str(); }
 void fused_seek(FusedPlan *p, uint64_t frames) { p->frames_done = frames; }
 

@@ -68,8 +68,6 @@ struct V2Args {
     RunArgs r;
 };
 
-// EN (FM only): also emit the energy words of the AGC mask pass.  The extra bases make hipcc spill SGPRs, so this variant's
-// asm stores carry their wait states (fused_v2_common.h); the plain variants stay spill-free and without them.
 // G > 1: INTERLEAVED CHANNEL SHARD g = A.c0 of G (rank g of G owns the channels g, g + G, ...; G | 16).  With
 // k = k1 + 16 k2 ownership only depends on k1, and W16^(a k1) = W16^(a g) W16^(a k1'), k1 = g + k1': the factor W16^(a g) is a
 // constant of polyphase branch j = 16 a + b1 and rides on its pre-mix phasor for free, after which the shard needs the pass-1
@@ -77,10 +75,10 @@ struct V2Args {
 // frame, and 256 / G radix-16 butterflies + 4096 / G freqdem samples + stores per tile in pass 2.  Those are spread over ALL
 // 256 threads: thread (q, f2), q = s NK1 + j1, takes row k1' = G j1 and the slice s of the 16 output slots, and the slice is
 // wave-uniform (G = 8: up to one lane bit), so that every wave runs a pass-2 butterfly pruned to its own quad of slots.
-template <bool FM, bool EN, int G>
+template <bool FM, int G>
 __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 {
-    static_assert(G == 1 || (!EN && (G == 2 || G == 4 || G == 8)), "interleaved shards: G = 2, 4, 8, no energy words");
+    static_assert(G == 1 || G == 2 || G == 4 || G == 8, "interleaved shards: G = 2, 4, 8");
     constexpr int NK1 = 16 / G;                         // owned pass-1 rows per frame = output slots per slice
     const RunArgs &RA = VA.r;
     const TileArgs &A = RA.t;
@@ -560,24 +558,12 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 #pragma unroll
                     for (int u = 0; u < 4; u++) mq[u] = fm_sample(rp[u], rr[u], k1s);
                 }
-                if (EN) {                                           // AGC mask pass input: energy word of every output sample (same rows, same offsets)
-                    char *ebase = reinterpret_cast<char *>(A.energy) + (size_t)16 * b * 4u;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const float ew = agc_energy_word(rr[u], A.agc_alpha);
-                        const char *rowe = ebase + (size_t)XIDX(i + u) * row16;
-                        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" V2_STORE_AUX :: "v"(voff), "v"(ew), "s"(rowe) : "memory");
-                    }
-                }
                 if (V2_PAIR && par == 0 && b + 1 < last) continue;   // (uniform) the odd tile of the pair stores these
 #pragma unroll
                 for (int u = 0; u < 4; u++) {                       // stores go out between the quads
                     const char *rowp = obase + (size_t)XIDX(i + u) * row16;
                     if (V2_ABLATE & 2) asm volatile("" :: "v"(mq[u]), "s"(rowp));
-                    else if (EN) {
-                        if (V2_PAIR && par == 1) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 offset:-64" V2_STORE_AUX :: "v"(voff), "v"(hold[i + u]), "s"(rowp) : "memory");
-                        asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" V2_STORE_AUX :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
-                    } else {
+                    else {
                         if (V2_PAIR && par == 1) asm volatile(V2_SNOP "global_store_dword %0, %1, %2 offset:-64" V2_STORE_AUX :: "v"(voff), "v"(hold[i + u]), "s"(rowp) : "memory");
                         asm volatile(V2_SNOP "global_store_dword %0, %1, %2" V2_STORE_AUX :: "v"(voff), "v"(mq[u]), "s"(rowp) : "memory");
                     }
@@ -642,15 +628,11 @@ static V2Args make_v2(const void *run_args)
 int run256_v2_launch(const void *run_args, bool fm, unsigned G, unsigned nruns, hipStream_t s)
 {
     const V2Args VA = make_v2(run_args);
-#define V2_LAUNCH(F, E, GG) hipLaunchKernelGGL((k_run256v2<F, E, GG>), dim3(nruns), dim3(256), 0, s, VA)
-    if (G == 1) {
-        if (fm && VA.r.t.energy) V2_LAUNCH(true, true, 1);
-        else if (fm) V2_LAUNCH(true, false, 1);
-        else V2_LAUNCH(false, false, 1);
-    } else if (VA.r.t.energy) { set_error("k_run256v2: no energy words from an interleaved shard"); return -1; }
-    else if (G == 2) { if (fm) V2_LAUNCH(true, false, 2); else V2_LAUNCH(false, false, 2); }
-    else if (G == 4) { if (fm) V2_LAUNCH(true, false, 4); else V2_LAUNCH(false, false, 4); }
-    else if (G == 8) { if (fm) V2_LAUNCH(true, false, 8); else V2_LAUNCH(false, false, 8); }
+#define V2_LAUNCH(F, GG) hipLaunchKernelGGL((k_run256v2<F, GG>), dim3(nruns), dim3(256), 0, s, VA)
+    if (G == 1) { if (fm) V2_LAUNCH(true, 1); else V2_LAUNCH(false, 1); }
+    else if (G == 2) { if (fm) V2_LAUNCH(true, 2); else V2_LAUNCH(false, 2); }
+    else if (G == 4) { if (fm) V2_LAUNCH(true, 4); else V2_LAUNCH(false, 4); }
+    else if (G == 8) { if (fm) V2_LAUNCH(true, 8); else V2_LAUNCH(false, 8); }
     else { set_error("k_run256v2: interleaved shards of stride %u are not built (2, 4, 8)", G); return -1; }
 #undef V2_LAUNCH
     return 0;
@@ -659,8 +641,8 @@ int run256_v2_launch(const void *run_args, bool fm, unsigned G, unsigned nruns, 
 int run256_v2_blocks_per_cu(bool fm)
 {
     int occ = 0;
-    if (fm) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<true, false, 1>), 256, 0);
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<false, false, 1>), 256, 0);
+    if (fm) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<true, 1>), 256, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (k_run256v2<false, 1>), 256, 0);
     return occ < 1 ? 1 : occ;
 }
 

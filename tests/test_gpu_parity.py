@@ -1351,38 +1351,6 @@ def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatc
     a.close(); b.close()
 
 
-def test_agc_fm_mask_route_same_mute_decisions_as_exact_route(monkeypatch):
-    """CSDR_AGC_FM_MASK=1 (kernels_agc_mask.hip): the run kernel demodulates the channelizer output itself (a positive gain
-    drops out of arg(conj(y') y)) and leaves an energy word per sample, the AGC is a mask pass over those.  Against the
-    default route (CF32 plane + time-parallel tail) on chunk-sized and run-sized calls: every zero in the same place (same
-    gains, same squelch states), the samples next to a muted one (0 or ref*pi) identical, un-muted samples equal to the
-    rounding of an algebraically identical expression."""
-    M = 256
-    frames = [4096, 33, 40000, 40001, 17]     # 40001: a run-sized call with a ragged tail (run kernel + k_tile256 tail in one call)
-    x = synth_cf32(M * sum(frames), M, seed=11)
-    kw = dict(channels=M, demod="fm", kf=0.3, agc=10.0, max_frames=max(frames))
-    monkeypatch.setenv("CSDR_AGC_FM_MASK", "1")
-    a = cs.Chain(**kw)
-    monkeypatch.delenv("CSDR_AGC_FM_MASK")
-    b = cs.Chain(**kw)
-    assert "mask" in a.path and "mask" not in b.path
-    pos = 0
-    for f in frames:
-        xa = x[pos * M:(pos + f) * M]; pos += f
-        ga, gb = a.process(xa), b.process(xa)
-        za, zb = ga == 0, gb == 0
-        d = np.abs(ga.astype(np.float64) - gb); d = np.minimum(d, np.abs(d - 1 / 0.3))
-        edge = zb & ~np.roll(zb, 1, axis=1) | ~zb & np.roll(zb, 1, axis=1)          # samples next to a mute / un-mute
-        print(f"mask route {f} frames: zeros {int(za.sum())} / {int(zb.sum())}, mismatches {int((za != zb).sum())}, max |diff| {d.max():.2e}, at edges {d[edge].max() if edge.any() else 0:.2e}")
-        assert int(zb.sum()) > 0 and int((~zb).sum()) > 0
-        assert np.array_equal(za, zb)
-        assert d.max() < 5e-5 and np.median(d[~zb]) < 1e-7
-    a.close(); b.close()
-
-
-# --------------------------------------------------------------------------- full-size properties of the cfg4 / cfg5 shapes
-
-
 def test_full_size_cfg4_shape_1024ch_fm_properties(monkeypatch):
     """configs[3] shape on one GPU (1024 ch, 65 536 frames = 67 M samples per chunk, k_run1024):
     (1) one chunk == 8 chunks (DC state, FIR window, freqdem r' and the run splits carry over),
