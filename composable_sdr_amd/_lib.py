@@ -90,6 +90,7 @@ SIGNATURES = {
     "csdr_chain_path": (C.c_char_p, [_vp]),
     "csdr_chain_debug_trace": (_i32, [_vp, _vp, _u32]),
     "csdr_chain_debug_agc": (_i32, [_vp, _vp, _vp]),
+    "csdr_chain_debug_agc_tile_major_calls": (_u32, [_vp]),
     "csdr_chain_kernel_time": (C.c_char_p, [_vp, C.POINTER(C.c_double), _pu32]),
 }
 

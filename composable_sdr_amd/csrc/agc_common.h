@@ -20,7 +20,13 @@ __device__ __forceinline__ void agc_gain_update(float e, float &g, float &y2h, f
 {
     y2h = fmaf(1.0f - alpha, y2h, e * (g * g));
     const float upd = __builtin_amdgcn_exp2f((-0.5f * alpha) * __builtin_amdgcn_logf(y2h));
-    g = (y2h > 1e-6f) ? g * upd : g;
+    // g = (y2h > 1e-6f) ? g * upd : g, the condition in an SGPR pair: the VCC select hipcc emits costs 16 cycles on the chain
+    {
+        unsigned long long mk;
+        const float gu = g * upd, g0 = g, thr = 1e-6f;
+        asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(mk) : "v"(y2h), "v"(thr));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(g) : "v"(g0), "v"(gu), "s"(mk));
+    }
     g = __builtin_amdgcn_fmed3f(g, 0.0f, 1e6f);
 }
 

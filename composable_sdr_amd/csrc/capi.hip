@@ -123,6 +123,7 @@ struct csdr_chain {
     float2 *d_u0 = nullptr, *d_u0hist = nullptr;     // branch-0 samples of the call behind p - 1 of history; history between calls (two copies, ping-pong)
     int u0_cur = 0;
     float2 *d_u = nullptr, *d_hist_tmp = nullptr, *d_A = nullptr, *d_B = nullptr;
+    size_t a_guard = 0;              // fused M = 256 chain with the AGC tail: d_A has this many readable elements in front of and behind the plane (tile-major route)
     AgcState *d_agc = nullptr;
     float2 *d_rp[2] = {nullptr, nullptr}; int rp_cur = 0;
     // host-API staging: CSDR_CHAIN_INFLIGHT slots (device in / out, page-locked host in / out), three streams
@@ -757,7 +758,10 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         }
         if (agc_on) {
             // d_A: channel-major CF32 from the channelizer; d_B: per-channel tail output in front of --mix
-            if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf))) return fail(r);
+            // (the fused M = 256 plans may write it tile-major for k_agc_spec_tm, which reads up to a segment in front of / behind the plane)
+            h->a_guard = h->fused ? agc_tail_tm_guard(C) : 0;
+            if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf + 2 * h->a_guard))) return fail(r);
+            if (h->a_guard) CSDR_HIP_CLEAN(hipMemset(h->d_A, 0, sizeof(float2) * ((size_t)C * h->max_nf + 2 * h->a_guard)), csdr_chain_destroy(h));
             if (cfg->mix && (r = dev_alloc(&h->d_B, (size_t)C * h->max_nf))) return fail(r);
         }
     } else {
@@ -838,12 +842,12 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
 uint32_t csdr_chain_out_elem_size(const csdr_chain *h) { return h && (h->cfg.demod == CSDR_DEMOD_FM || h->am || h->wbfm) ? 4u : 8u; }
 
 // AGC on: Z[C][nf] (channel-major CF32 in d_A) -> AGC + squelch [+ freqdem] [+ mix] -> d_out
-static int chain_agc_tail(csdr_chain *h, const float2 *Z, uint32_t nf, void *d_out, hipStream_t s)
+static int chain_agc_tail(csdr_chain *h, const float2 *Z, uint32_t nf, void *d_out, hipStream_t s, bool tm = false)
 {
     const bool fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix && h->M > 1;
     void *T = mixo ? (void *)h->d_B : d_out;
     int r = agc_tail_process(h->agc_tail, Z, T, fm, nf, h->d_agc, h->agc, h->fm_ref,
-                             fm ? h->d_rp[h->rp_cur] : nullptr, fm ? h->d_rp[h->rp_cur ^ 1] : nullptr, s);
+                             fm ? h->d_rp[h->rp_cur] : nullptr, fm ? h->d_rp[h->rp_cur ^ 1] : nullptr, s, tm);
     if (r) return r;
     if (fm) h->rp_cur ^= 1;
     if (mixo) return launch_mix((const float *)T, (float *)d_out, h->C, fm ? nf : 2 * nf, s);
@@ -1048,8 +1052,11 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
     int r;
     if (h->use_fused) {
         const bool agc_on = h->d_agc != nullptr, fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix != 0;
-        float2 *Z = (agc_on && (fm || mixo || h->agc_tail)) ? h->d_A : (float2 *)d_out;
+        float2 *Z = (agc_on && (fm || mixo || h->agc_tail)) ? h->d_A + h->a_guard : (float2 *)d_out;
         FusedCall fcall{};
+        // AGC tail behind the fused M = 256 chain, run-sized calls of whole tiles: the plane between the two kernels is tile-major
+        const bool tm = agc_on && h->agc_tail && h->fused && Z != (float2 *)d_out && agc_tail_tm_supported(h->agc_tail, nf) && fused_tile_major_ok(h->fused, nf);
+        fcall.tile_major = tm;
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         fcall.indep = h->call_indep; fcall.ev_tail = h->call_ev_tail;
         if (h->small) { if ((r = small_process(h->small, fcall, s, &h->timer))) return r; h->timed_kernel = small_name(h->small); }   // k_run64v2 or k_run64, by call
@@ -1057,7 +1064,7 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         else if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
         h->theta += n_in * h->d_theta;
         if (agc_on && h->agc_tail) {
-            if ((r = chain_agc_tail(h, Z, nf, d_out, s))) return r;
+            if ((r = chain_agc_tail(h, Z, nf, d_out, s, tm))) return r;
         } else if (agc_on) {
             if ((r = launch_agc(Z, h->C, nf, h->d_agc, h->agc, s))) return r;
             if (fm) {
@@ -1354,6 +1361,7 @@ int csdr_chain_debug_agc(csdr_chain *h, uint32_t *checked, uint32_t *redone)
     (void)hipDeviceSynchronize();
     return agc_tail_stats(h->agc_tail, checked, redone);
 }
+uint32_t csdr_chain_debug_agc_tile_major_calls(const csdr_chain *h) { return h && h->agc_tail ? agc_tail_tm_calls(h->agc_tail) : 0u; }
 const char *csdr_chain_path(const csdr_chain *h) { return h ? h->path.c_str() : ""; }
 
 const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *launches)

@@ -152,8 +152,13 @@ struct AgcTailPlan;
 int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out);
 void agc_tail_destroy(AgcTailPlan *p);
 // Z[C][nf] -> out[C][nf] (CF32, or F32 when fm); st (and rp_in -> rp_out when fm) carry the per-channel state
+// tm: Z is a TILE-MAJOR plane -- sample (c, t) at ((t >> 4) C + c) 16 + (t & 15), agc_tail_tm_guard(C) readable elements in front of
+// Z and behind the plane -- which the fused M = 256 run kernels write for calls agc_tail_tm_supported() accepts (k_agc_spec_tm)
 int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32_t nf, AgcState *st, const AgcParams &prm,
-                     float fm_ref, const float2 *rp_in, float2 *rp_out, hipStream_t s);
+                     float fm_ref, const float2 *rp_in, float2 *rp_out, hipStream_t s, bool tm = false);
+bool agc_tail_tm_supported(const AgcTailPlan *p, uint32_t nf);
+size_t agc_tail_tm_guard(uint32_t C);
+uint32_t agc_tail_tm_calls(const AgcTailPlan *p);
 int agc_tail_stats(AgcTailPlan *p, unsigned *checked, unsigned *redone);
 void agc_tail_reset(AgcTailPlan *p);     // the AGC state was re-initialised: the next call pilots (kernels_agc_tail.hip)
 

@@ -24,7 +24,12 @@ struct FusedCall {
     // plan can (fused_can_overlap); ev_tail is recorded on s once the chunk's last tiles are saved for the next call's run 0
     bool indep = false;
     hipEvent_t ev_tail = nullptr;
+    // CF32 plans: write the output TILE-MAJOR -- block t / 16 holds the 128-byte lines of all C rows back to back (a tile's whole
+    // output is one contiguous C x 128 bytes) -- instead of row-major [C][nf]: what the time-parallel AGC tail reads (k_agc_spec_tm).
+    // Only for calls fused_tile_major_ok() accepts.
+    bool tile_major = false;
 };
+bool fused_tile_major_ok(const FusedPlan *plan, uint32_t nf);
 void fused_keep_tail(FusedPlan *plan);                  // from now on every run-kernel call saves its last WU + 1 raw tiles
 bool fused_can_overlap(const FusedPlan *plan, uint32_t nf);
 bool fused_tail_recorded(const FusedPlan *plan);       // the last call saved its tail (and recorded FusedCall::ev_tail)   // the next call of nf frames can run with FusedCall::indep

@@ -387,6 +387,7 @@ struct RunArgs {
     uint32_t pair_align;        // k_run256v2<FM>: run boundaries rounded down to even tiles (whole 128-byte output lines per tile pair)
     uint32_t wu_batch6;         // k_run256v2: the six warm-up tiles in one batch of loads (0: two batches of three)
     uint32_t wu, wu_rot;        // k_run256v2: read-only warm-up tiles in front of a run's halo tile (WU = 6); runs walk them in rotated order
+    uint32_t tile_step;         // k_run256v2 / v3: bytes between consecutive tiles in the output (16 frames x element size for row-major rows; C x 128 tile-major)
 };
 
 __device__ __forceinline__ float2 wg_sum(float2 v, float2 *red, int tid)

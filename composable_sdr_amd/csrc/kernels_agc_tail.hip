@@ -91,7 +91,8 @@ __device__ __forceinline__ bool same_state(const AgcSeg &a, const AgcSeg &b, boo
 }
 
 struct TailArgs {
-    const float2 *Z;        // [C][nf] channelizer output
+    const float2 *Z;        // [C][nf] channelizer output; tm: TILE-MAJOR plane, sample (c, t) at ((t >> 4) C + c) 16 + (t & 15), with
+                            // TM_GUARD blocks of readable memory in front of block 0 and behind the last one
     void *out;              // [C][nf] CF32 or F32
     const AgcState *st_in;  // [C] state before the call
     const AgcState *st_spec;// [C] state the speculative warm-ups start from: st_in, except on a stream's first call (k_agc_pilot)
@@ -100,7 +101,15 @@ struct TailArgs {
     uint32_t C, nf, L, W, nseg;
     AgcParams p;
     float ref;
+    uint32_t tm;            // 1: Z is tile-major (what the fused run kernels write for k_agc_spec_tm)
 };
+constexpr uint32_t TM_GUARD = 512;      // blocks of 16 samples: >= max(W, L) / 16 of the tile-major route (W, L <= 8192)
+
+// index of sample (c, t) in the channelizer plane
+__device__ __forceinline__ size_t z_index(const TailArgs &A, uint32_t c, uint32_t t)
+{
+    return A.tm ? ((size_t)(t >> 4) * A.C + c) * 16u + (t & 15u) : (size_t)c * A.nf + t;
+}
 
 // LDS slot of 16-byte piece `pc` (0..7) of stream `j` (0..63): XOR swizzle, conflict-free for the cooperative
 // side (8 streams x 8 pieces per instruction) and for the owner side (64 streams, one piece per instruction)
@@ -373,6 +382,260 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec(TailArgs A, uint32_t groups
     if (!mover && mine) A.seg_end[(size_t)c * A.nseg + sg] = q;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_agc_spec_tm (round 4): the same speculation on a TILE-MAJOR channelizer plane.
+//
+// k_agc_spec's 64 streams are 64 segments of one channel: every block iteration fetches 64 lines that lie a segment (8 KiB)
+// apart, one DRAM page each (4.1 TB/s however many were in flight), through registers, and the worker wave pays ~33
+// instructions per sample for the freqdem with VCC selects.  Here the fused run kernels write the CF32 plane tile-major -- block
+// B of 16 frames holds the 128-byte lines of all C channels back to back, i.e. a tile's whole output is ONE contiguous 32 KiB --
+// and a workgroup's 64 streams are 64 CHANNELS at the same segment: every lane is at the same time position, block kk of the
+// workgroup is one contiguous 8 KiB, and nothing in the kernel depends on the lane any more except the state.
+//   * mover wave: eight global_load_lds_dwordx4 per block (HBM -> LDS ring without registers, XOR swizzle on the source address as
+//     in k_run256v2), TM_DEPTH blocks ahead; its vmcnt queue holds nothing else, so `s_waitcnt vmcnt(8 n)` is exact;
+//   * worker wave: the recurrence out of the ring, freqdem as fm_quad_rn (packed, SGPR-mask selects, bit-identical to
+//     fm_sample_rn), and the outputs straight from its registers as 64-byte (F32) / 128-byte (CF32) row pieces -- nothing goes back
+//     through the ring;
+//   * one LDS-only barrier per block.
+// Channels per workgroup Cw = min(C, 64); for C < 64 (interleaved shards of eight) a workgroup takes 64 / C segments.
+// Same records, same verification (k_agc_fix), same bits as k_agc_spec.
+constexpr int TM_DEPTH = 3;                 // blocks in flight
+constexpr int TM_SLOTS = TM_DEPTH + 2;      // ring slots of 8 KiB: TM_DEPTH in flight, one with the gain wave, one with the post wave
+
+typedef float tm_v2f __attribute__((ext_vector_type(2)));
+
+// Four consecutive samples of one stream through the gain recurrence + squelch (bit for bit agc_tail_step x 4).  WANT_Y: also the
+// (muted) AGC outputs.  What is off the dependent chain runs packed (alpha |x|^2 of two samples in three v_pk, y = x g in one), the
+// "does the squelch state move at all" test works on the v_cmp lane masks in SGPRs (scalar unit), and the mute is an AND with a
+// per-lane all-ones / zero word: the VCC selects hipcc emits for `cond ? a : b` cost 16 cycles each on gfx950.
+template <bool WANT_Y>
+__device__ __forceinline__ void agc_gain_quad(const float4 va, const float4 vb, AgcSeg &q, const AgcParams &p, float2 (&y)[4])
+{
+    const tm_v2f xr0 = {va.x, va.z}, xi0 = {va.y, va.w}, xr1 = {vb.x, vb.z}, xi1 = {vb.y, vb.w};
+    const tm_v2f al = {p.alpha, p.alpha};
+    // agc_energy: alpha * fmaf(x.x, x.x, x.y * x.y), two samples per instruction
+    const tm_v2f e0 = al * __builtin_elementwise_fma(xr0, xr0, xi0 * xi0), e1 = al * __builtin_elementwise_fma(xr1, xr1, xi1 * xi1);
+    const float e[4] = {e0.x, e0.y, e1.x, e1.y};
+    const float2 x[4] = {make_float2(va.x, va.y), make_float2(va.z, va.w), make_float2(vb.x, vb.y), make_float2(vb.z, vb.w)};
+    float gs[4];
+    unsigned long long mex[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (WANT_Y) { const tm_v2f yy = (tm_v2f){x[i].x, x[i].y} * (tm_v2f){q.g, q.g}; y[i] = make_float2(yy.x, yy.y); }
+        agc_gain_update(e[i], q.g, q.y2, p.alpha);
+        gs[i] = q.g;
+        asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(mex[i]) : "v"(q.g), "v"(p.g_thr));       // threshold exceeded after this sample
+    }
+    uint32_t S = (uint32_t)q.mode;
+    unsigned long long m3, m1;
+    asm("v_cmp_eq_u32_e64 %0, 3, %1" : "=s"(m3) : "v"(S));
+    asm("v_cmp_eq_u32_e64 %0, 1, %1" : "=s"(m1) : "v"(S));
+    const unsigned long long all_ex = mex[0] & mex[1] & mex[2] & mex[3], any_ex = mex[0] | mex[1] | mex[2] | mex[3];
+    const unsigned long long steady = (m3 & all_ex) | (m1 & ~any_ex);
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+    if ((act & ~steady) == 0ull) {
+        if (WANT_Y) {
+            const uint32_t keep = __float_as_uint(fm_sel(m3, __uint_as_float(0xffffffffu), 0.0f));     // SIGNALHI holds through the quad: open
+#pragma unroll
+            for (int i = 0; i < 4; i++) y[i] = make_float2(__uint_as_float(__float_as_uint(y[i].x) & keep), __uint_as_float(__float_as_uint(y[i].y) & keep));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            S = squelch_next(S, gs[i] < p.g_thr, p);
+            if (WANT_Y && S != 3u) y[i] = make_float2(0.f, 0.f);      // reference mute rule (Liquid.chs:703-704)
+        }
+        q.mode = (int32_t)S;
+    }
+}
+
+// Gain wave (wave 0): tile DMA TM_DEPTH blocks ahead, the recurrence out of the ring, y back in place (blocks >= kreal - 1).
+// Post wave (wave 1): block it - 1's y -> freqdem (FM: fm_quad_rn) -> row pieces straight to HBM; its vmcnt queue holds stores only.
+template <bool FM>
+__global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg, uint32_t Cw, uint32_t nsub)
+{
+    __shared__ float4 ring[TM_SLOTS][64 * 8];
+    const int lane = threadIdx.x & 63;
+    const bool post = threadIdx.x >= 64;                        // wave-uniform
+    const uint32_t cg = blockIdx.x % ncg, sgrp = blockIdx.x / ncg;      // neighbouring workgroups: neighbouring 8 KiB of the same blocks
+    const uint32_t nblk = (A.W + A.L) / 16u, kreal = A.W / 16u;
+    const size_t blk_bytes = (size_t)A.C * 128u;                // one block of the plane
+    // stream jj of the workgroup: channel cg Cw + jj % Cw, segment sgrp nsub + jj / Cw
+    auto seg_of = [&](uint32_t jj) { return sgrp * nsub + jj / Cw; };
+    auto ch_of = [&](uint32_t jj) { return cg * Cw + jj % Cw; };
+    const uint32_t sg = seg_of((uint32_t)lane), ch = ch_of((uint32_t)lane);
+    const bool mine = sg < A.nseg && ch < A.C;
+    const uint32_t endv = mine ? min(A.nf, sg * A.L + A.L) : 0u;
+    // block `it` of my stream starts at sample t0(it); whole blocks only (nf, L, W are multiples of 16)
+    auto live_at = [&](uint32_t it) { const int32_t t0 = (int32_t)(sg * A.L) - (int32_t)A.W + (int32_t)(16 * it); return mine && t0 >= 0 && (uint32_t)t0 < endv; };
+
+    if (post) {
+        const FmRnK fk = fm_rn_consts(A.ref);
+        // FM: r' in front of the block in work: the previous call's last output for a stream that starts at sample 0 from the true
+        // state, the last warm-up output (read out of block kreal - 1's slot) for the others
+        float2 rp = (FM && mine && !((uint64_t)sg * A.L > A.W)) ? A.rp_in[ch] : make_float2(0.f, 0.f);
+        // Outputs leave as whole row pieces, cooperatively: the results go back into the block's ring slot (slot8 layout, this wave
+        // owns the slot by now) and store instruction mm writes piece lane & 7 of stream 8 mm + (lane >> 3) -- eight lanes per 128-byte
+        // line.  F32: a block is only 64 bytes of a row, so an even block's results wait in registers and the odd block stores both
+        // (segments start on 128-byte lines: L is a multiple of 32 on this route).
+        uint32_t ooff[8];                                       // byte offset of (stream 8 mm + (lane >> 3))'s segment start + my piece
+        bool ook[8];
+#pragma unroll
+        for (int mm = 0; mm < 8; mm++) {
+            const uint32_t jj = 8u * mm + ((uint32_t)lane >> 3), s2 = seg_of(jj), c2 = ch_of(jj);
+            ook[mm] = s2 < A.nseg && c2 < A.C;
+            ooff[mm] = ook[mm] ? (uint32_t)(((size_t)c2 * A.nf + (size_t)s2 * A.L) * (FM ? 4u : 8u)) + 16u * ((uint32_t)lane & 7u) : 0u;
+        }
+        char *obase = reinterpret_cast<char *>(A.out);
+        float4 hold[4];
+        bool held = false;                                      // (uniform per sub-segment; nsub > 1: lanes of different segments agree, the segments are equally long except the call's last)
+        // store the lines of blocks [k0, k0 + nb) (nb = 1: CF32 block or a lone F32 block; nb = 2: an F32 pair) out of `buf`
+        auto coop_store = [&](float4 *buf, uint32_t k0, bool pair) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int mm = 0; mm < 8; mm++) {
+                const uint32_t jj = 8u * mm + ((uint32_t)lane >> 3), s2 = seg_of(jj);
+                const uint32_t e2 = min(A.nf, s2 * A.L + A.L);
+                const int32_t t0 = (int32_t)(s2 * A.L) - (int32_t)A.W + (int32_t)(16 * k0);
+                // F32: pieces 0..3 are block k0, pieces 4..7 block k0 + 1 (pair) -- each must lie inside the segment
+                const int32_t tp = t0 + (FM ? 16 * (int32_t)(((uint32_t)lane & 7u) >> 2) : 0);
+                const bool ok = ook[mm] && t0 >= 0 && (uint32_t)tp < e2 && (FM && !pair ? ((uint32_t)lane & 7u) < 4u : true);
+                if (ok) {
+                    const float4 v = buf[slot8((int)jj, lane & 7)];
+                    *reinterpret_cast<float4 *>(obase + ooff[mm] + (size_t)(16u * (k0 - kreal)) * (FM ? 4u : 8u)) = v;
+                }
+            }
+        };
+        for (uint32_t it = 0; it <= nblk; it++) {
+            lds_barrier();                                      // block it - 1's y is in its slot; the gain wave is on block it
+            if (it == 0) continue;
+            const uint32_t k = it - 1;
+            if (k + 1 < kreal) continue;                        // warm-up blocks leave nothing here, except the last one: r' of the segment
+            float4 *buf = ring[k % TM_SLOTS];
+            const bool lv = live_at(k);
+            if (k < kreal) { if (FM && lv) { const float4 v7 = buf[slot8(lane, 7)]; rp = make_float2(v7.z, v7.w); } continue; }
+            if (!FM) { coop_store(buf, k, false); continue; }
+            float4 mq[4];
+            if (lv) {
+                float4 v[8];
+#pragma unroll
+                for (int pc = 0; pc < 8; pc++) v[pc] = buf[slot8(lane, pc)];
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    const float2 y[4] = {make_float2(v[2 * h].x, v[2 * h].y), make_float2(v[2 * h].z, v[2 * h].w),
+                                         make_float2(v[2 * h + 1].x, v[2 * h + 1].y), make_float2(v[2 * h + 1].z, v[2 * h + 1].w)};
+                    const float2 rq[4] = {rp, y[0], y[1], y[2]};
+                    float m[4];
+                    fm_quad_rn(rq, y, fk, m);
+                    rp = y[3];
+                    mq[h] = make_float4(m[0], m[1], m[2], m[3]);
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 4; h++) mq[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const bool odd = ((k - kreal) & 1u) != 0u;
+            if (!odd) {
+#pragma unroll
+                for (int h = 0; h < 4; h++) hold[h] = mq[h];
+                held = true;
+                // a segment's (or the call's) last block has no partner when the block count is odd: it leaves alone
+                const bool last_any = __builtin_amdgcn_ballot_w64(lv && !live_at(k + 1)) != 0ull || k + 1 == nblk;
+                if (last_any) {
+#pragma unroll
+                    for (int h = 0; h < 4; h++) buf[slot8(lane, h)] = hold[h];
+                    coop_store(buf, k, false);
+                    held = false;
+                }
+            } else {
+#pragma unroll
+                for (int h = 0; h < 4; h++) { buf[slot8(lane, h)] = hold[h]; buf[slot8(lane, 4 + h)] = mq[h]; }
+                coop_store(buf, k - 1, true);
+                held = false;
+            }
+        }
+        (void)held;
+        return;
+    }
+
+    // ---- gain wave
+    // lane l of DMA instruction m fills ring piece 64 m + l = slot8(jj, pc): jj = 8 m + (l >> 3), pc = (l & 7) ^ ((jj ^ (jj >> 3)) & 7)
+    uint32_t voff[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        const uint32_t jj = 8u * m + ((uint32_t)lane >> 3), pc = ((uint32_t)lane & 7u) ^ ((jj ^ (jj >> 3)) & 7u);
+        uint32_t s2 = seg_of(jj);
+        if (s2 >= A.nseg) s2 = A.nseg - 1;                      // a stream that does not exist reads what its neighbour reads
+        uint32_t c2 = ch_of(jj);
+        if (c2 >= A.C) c2 = A.C - 1;
+        const int64_t b0 = ((int64_t)s2 * A.L - (int64_t)A.W) / 16 + (int64_t)TM_GUARD;     // >= 0: the plane has TM_GUARD blocks in front
+        voff[m] = (uint32_t)((size_t)b0 * blk_bytes + (size_t)c2 * 128u + pc * 16u);
+    }
+    const char *base = reinterpret_cast<const char *>(A.Z) - (size_t)TM_GUARD * blk_bytes;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float4 *)&ring[0][0];
+    auto dma = [&](uint32_t kk_) {
+        const uint32_t kk = (uint32_t)__builtin_amdgcn_readfirstlane((int)kk_);     // (uniform anyway: keeps the operands below in SGPRs)
+        const char *src = base + (size_t)kk * blk_bytes;
+        unsigned dst = lds0 + (kk % TM_SLOTS) * 8192u;
+        asm volatile("" : "+s"(dst));
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const unsigned d = dst + 1024u * (unsigned)m;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff[m]), "s"(d), "s"(src) : "memory");
+        }
+    };
+    AgcSeg q;
+    {
+        // segments that begin <= W samples into the call run from sample 0 and from the TRUE state; the others warm up from st_spec
+        const uint32_t cc = mine ? ch : 0u;
+        const AgcState s0 = ((uint64_t)sg * A.L > A.W) ? A.st_spec[cc] : A.st_in[cc];
+        q.g = s0.g; q.y2 = s0.y2; q.mode = (int32_t)s_encode(s0.mode, s0.timer); q.timer = 0;
+        const float2 r0 = FM ? A.rp_in[cc] : make_float2(0.f, 0.f);
+        q.rx = r0.x; q.ry = r0.y; q.pad0 = q.pad1 = 0;
+    }
+    for (uint32_t d = 0; d < (uint32_t)TM_DEPTH && d < nblk; d++) dma(d);
+    for (uint32_t it = 0; it <= nblk; it++) {
+        if (it < nblk) {
+            // block `it` has landed once at most min(TM_DEPTH - 1, nblk - 1 - it) younger blocks (8 instructions each) are in flight:
+            // this wave's vmcnt queue holds the DMA and nothing else (the state records below are stored after the loop)
+            const uint32_t younger = min((uint32_t)TM_DEPTH - 1u, nblk - 1u - it);
+            if (younger >= 2u) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger == 1u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        lds_barrier();                                          // the post wave has left block it - 2's slot, and takes block it - 1's y
+        if (it >= nblk) break;
+        if (it + TM_DEPTH < nblk) dma(it + TM_DEPTH);           // into the slot block it - 2 had
+        if (it == kreal) {
+            // state at the segment start, after the warm-up: kept in registers until the loop is over (a store here would sit in the
+            // vmcnt queue in front of the DMA counts above)
+        }
+        float4 *buf = ring[it % TM_SLOTS];
+        if (!live_at(it)) continue;
+        float4 v[8];
+#pragma unroll
+        for (int pc = 0; pc < 8; pc++) v[pc] = buf[slot8(lane, pc)];
+        if (it + 1 < kreal) {
+#pragma unroll
+            for (int h = 0; h < 4; h++) { float2 y[4]; agc_gain_quad<false>(v[2 * h], v[2 * h + 1], q, A.p, y); }
+        } else {
+            if (it == kreal) A.seg_start[(size_t)ch * A.nseg + sg] = q;     // (one 32-byte store per stream and launch)
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                float2 y[4];
+                agc_gain_quad<true>(v[2 * h], v[2 * h + 1], q, A.p, y);
+                buf[slot8(lane, 2 * h)] = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
+                buf[slot8(lane, 2 * h + 1)] = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
+                if (h == 3) { q.rx = y[3].x; q.ry = y[3].y; }
+            }
+        }
+    }
+    if (mine) A.seg_end[(size_t)ch * A.nseg + sg] = q;
+}
+
 // verification + exact repair, one workgroup per channel, one thread per segment boundary.
 // A boundary holds when the state the segment was started from (recorded, S_s) is BITWISE the end state of the
 // segment before it (E_{s-1}).  S_0 is the true state, so when every boundary holds every segment is, by
@@ -387,7 +650,6 @@ __device__ __forceinline__ void repair_segment(const TailArgs &A, uint32_t c, ui
 {
     const uint32_t t0 = s * A.L, t1 = min(A.nf, t0 + A.L);
     const size_t rowo = (size_t)c * A.nf;
-    const float2 *row = A.Z + rowo;
     auto one = [&](float2 x, uint32_t t) {
         const float2 y = agc_tail_step(x, cur, A.p);
         if (FM) {
@@ -396,6 +658,18 @@ __device__ __forceinline__ void repair_segment(const TailArgs &A, uint32_t c, ui
         } else ((float2 *)A.out)[rowo + t] = y;
     };
     uint32_t t = t0;
+    if (A.tm) {                                                 // tile-major: t0, t1 are multiples of 16, a block is one 128-byte line
+        for (; t + 16 <= t1; t += 16) {
+            const float4 *src = reinterpret_cast<const float4 *>(A.Z + z_index(A, c, t));
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = src[i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { one(make_float2(v[i].x, v[i].y), t + 2 * i); one(make_float2(v[i].z, v[i].w), t + 2 * i + 1); }
+        }
+        return;
+    }
+    const float2 *row = A.Z + rowo;
     if (((rowo + t) & 1) && t < t1) { one(row[t], t); t++; }    // up to a 16-byte boundary
     for (; t + 16 <= t1; t += 16) {                             // a line per iteration, all eight loads in flight
         float4 v[8];
@@ -412,16 +686,28 @@ __device__ __forceinline__ void repair_segment(const TailArgs &A, uint32_t c, ui
 // call in rounds (80 ms at the bench size).  The pilot runs the recurrence over the first `n` samples of every channel once, one
 // lane per channel, output discarded: the state it reaches is SETTLED, and that is all a warm-up needs to start from (the
 // verification in k_agc_fix keeps the result exact whatever the speculation started from).
-__global__ __launch_bounds__(64) void k_agc_pilot(TailArgs A, uint32_t n, AgcState *st_spec)
+__global__ __launch_bounds__(64) void k_agc_pilot(TailArgs A, uint32_t n_, AgcState *st_spec)
 {
     const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    uint32_t n = n_;
     if (c >= A.C) return;
     const AgcState s0 = A.st_in[c];
     AgcSeg cur; cur.g = s0.g; cur.y2 = s0.y2; cur.mode = (int32_t)s_encode(s0.mode, s0.timer); cur.timer = 0; cur.rx = cur.ry = 0.f; cur.pad0 = cur.pad1 = 0;
     const size_t rowo = (size_t)c * A.nf;
     const float2 *row = A.Z + rowo;
     uint32_t t = 0;
-    if ((rowo & 1) && t < n) { (void)agc_tail_step(row[t], cur, A.p); t++; }
+    if (A.tm) {
+        for (; t + 16 <= n; t += 16) {
+            const float4 *src = reinterpret_cast<const float4 *>(A.Z + z_index(A, c, t));
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = src[i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { (void)agc_tail_step(make_float2(v[i].x, v[i].y), cur, A.p); (void)agc_tail_step(make_float2(v[i].z, v[i].w), cur, A.p); }
+        }
+        n = t;
+    }
+    if (!A.tm && (rowo & 1) && t < n) { (void)agc_tail_step(row[t], cur, A.p); t++; }
     for (; t + 16 <= n; t += 16) {
         float4 v[8];
 #pragma unroll
@@ -474,6 +760,8 @@ __global__ __launch_bounds__(256) void k_agc_fix(TailArgs A, AgcState *st_out, f
 
 struct AgcTailPlan {
     uint32_t C = 0, max_nf = 0, L = 0, Lmin = 384, W = 1024, max_seg = 0;   // L > 0: fixed by CSDR_AGC_L
+    uint32_t L_tm = 0;               // tile-major route: fixed segment length (CSDR_AGC_L_TM), 0 = chosen per call
+    uint32_t tm_calls = 0;           // calls that took k_agc_spec_tm since create
     AgcSeg *d_start = nullptr, *d_end = nullptr;
     AgcState *d_st_tmp = nullptr;    // [C] settled state of the pilot (first call of a stream)
     bool fresh = true;               // the AGC state is the create-time one: the next call runs the pilot
@@ -487,6 +775,7 @@ int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
     AgcTailPlan *p = new AgcTailPlan();
     p->C = C; p->max_nf = max_nf;
     if (const char *e = getenv("CSDR_AGC_L")) { p->L = (uint32_t)atol(e); p->L = (p->L + 15u) / 16u * 16u; if (p->L < 16) p->L = 16; }
+    if (const char *e = getenv("CSDR_AGC_L_TM")) { p->L_tm = ((uint32_t)atol(e) + 15u) / 16u * 16u; if (p->L_tm < 16) p->L_tm = 16; if (p->L_tm > 8176u) p->L_tm = 8176u; }
     if (const char *e = getenv("CSDR_AGC_W")) p->W = (uint32_t)atol(e);
     p->W = (p->W + 15u) / 16u * 16u;
     {
@@ -519,6 +808,7 @@ void agc_tail_destroy(AgcTailPlan *p)
 }
 
 void agc_tail_reset(AgcTailPlan *p) { if (p) p->fresh = true; }
+uint32_t agc_tail_tm_calls(const AgcTailPlan *p) { return p ? p->tm_calls : 0u; }
 
 int agc_tail_stats(AgcTailPlan *p, unsigned *checked, unsigned *redone)
 {
@@ -530,8 +820,20 @@ int agc_tail_stats(AgcTailPlan *p, unsigned *checked, unsigned *redone)
 }
 
 // Z[C][nf] -> out[C][nf] (CF32, or F32 when fm); st and rp are updated in place.
+// the tile-major route (k_agc_spec_tm): whole 16-frame blocks, at least two segments, channel count a multiple or a divisor of 64
+bool agc_tail_tm_supported(const AgcTailPlan *p, uint32_t nf)
+{
+    static const bool off = getenv("CSDR_AGC_TM") && atoi(getenv("CSDR_AGC_TM")) == 0;      // A/B: the row-major route for every call
+    if (off || !p || !nf || nf % 16u || p->W > 8192u || p->W % 16u) return false;
+    if (!(p->C % 64u == 0 || (p->C < 64u && 64u % p->C == 0))) return false;
+    if (nf < 4u * p->W) return false;                            // short calls: a handful of segments, the row-major kernel's ground
+    if (((uint64_t)nf / 16u + 2ull * TM_GUARD) * p->C * 128ull >= (1ull << 32)) return false;     // 32-bit byte offsets inside the plane
+    return true;
+}
+size_t agc_tail_tm_guard(uint32_t C) { return (size_t)TM_GUARD * 16u * C; }      // float2 elements in front of and behind a tile-major plane
+
 int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32_t nf, AgcState *st, const AgcParams &prm,
-                     float fm_ref, const float2 *rp_in, float2 *rp_out, hipStream_t s)
+                     float fm_ref, const float2 *rp_in, float2 *rp_out, hipStream_t s, bool tm)
 {
     if (!nf || !p->C) return 0;
     if ((uint64_t)p->C * nf >= (1ull << 32)) { set_error("agc tail: C*nf = %llu samples exceeds 2^32", (unsigned long long)p->C * nf); return CSDR_ERR_SIZE; }
@@ -539,7 +841,19 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     // SIMD busy), not more -- shorter segments re-read more warm-up ((W + L) / L times the data) and a second round of
     // workgroups costs more than it brings.  L / 16 is made odd: with a power-of-two L the 64 streams of a group and
     // the groups of all channels hit the same few HBM channels at every step (L = 1024: 0.37 ms, 1040: 0.34 ms).
-    uint32_t L = p->L;
+    if (tm && !agc_tail_tm_supported(p, nf)) { set_error("agc tail: internal: tile-major plane for a call the tile-major kernel does not take"); return CSDR_ERR_INVALID; }
+    const uint32_t Cw = p->C < 64u ? p->C : 64u, nsub = 64u / Cw, ncg = p->C / Cw;     // tile-major: channels per workgroup, segments per workgroup, channel groups
+    uint32_t L = tm ? p->L_tm : p->L;
+    if (!L && tm) {
+        // as many workgroups as the device holds at once: ncg channel groups x (nseg / nsub) segment groups
+        uint64_t nseg_t = (uint64_t)p->wg_slots * nsub / ncg;
+        if (nseg_t < 2) nseg_t = 2;
+        L = (uint32_t)((nf + nseg_t - 1) / nseg_t);
+        L = (L + 31u) / 32u * 32u;                               // F32 rows leave as whole 128-byte lines per block pair
+        if (L < p->Lmin) L = p->Lmin;
+        if (L > 8160u) L = 8160u;
+    }
+    if (tm && (L % 32u)) L = (L + 31u) / 32u * 32u;
     if (!L) {
         const uint32_t gmax = p->wg_slots / p->C ? p->wg_slots / p->C : 1u;
         const uint64_t nseg_t = 64ull * gmax;
@@ -553,7 +867,7 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     TailArgs A{};
     A.Z = Z; A.out = out; A.st_in = st; A.rp_in = rp_in; A.seg_start = p->d_start; A.seg_end = p->d_end;
     A.C = p->C; A.nf = nf; A.L = L; A.W = p->W; A.nseg = nseg; A.p = prm; A.ref = fm_ref;
-    A.st_spec = st;
+    A.st_spec = st; A.tm = tm ? 1u : 0u;
     if (p->fresh && nseg > 1) {
         const uint32_t n = nf < p->pilot_n ? nf : p->pilot_n;
         hipLaunchKernelGGL(k_agc_pilot, dim3((p->C + 63u) / 64u), dim3(64), 0, s, A, n, p->d_st_tmp);
@@ -565,7 +879,12 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     const bool pairs = (nf & 1u) == 0 && (uint64_t)p->C * nf >= 2;
     const uint32_t groups = (nseg + 63u) / 64u;
     const dim3 grid(p->C * groups), block(128);
-    if (pairs) {
+    if (tm) {
+        p->tm_calls++;
+        const dim3 gtm(ncg * ((nseg + nsub - 1) / nsub));
+        if (fm) hipLaunchKernelGGL((k_agc_spec_tm<true>), gtm, block, 0, s, A, ncg, Cw, nsub);
+        else hipLaunchKernelGGL((k_agc_spec_tm<false>), gtm, block, 0, s, A, ncg, Cw, nsub);
+    } else if (pairs) {
         if (fm) hipLaunchKernelGGL((k_agc_spec<true, true>), grid, block, 0, s, A, groups);
         else hipLaunchKernelGGL((k_agc_spec<false, true>), grid, block, 0, s, A, groups);
     } else {

@@ -844,6 +844,17 @@ static bool fused_v2_call(const FusedPlan *p, uint32_t nf)
     return p->use_v2 && c.G == 1 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32) && nf / NB >= p->run_min_tiles;
 }
 
+bool fused_tile_major_ok(const FusedPlan *p, uint32_t nf)
+{
+    // the calls that go to k_run256v2 / v3 as whole tiles: CF32 output below 4 GiB, no mix inside the plan
+    const FusedConfig &c = p->cfg;
+    const bool shard = c.G > 1;
+    if (c.fm || c.mix || nf % NB || !nf) return false;
+    if ((uint64_t)c.C * nf * 8u >= (1ull << 32)) return false;
+    if (shard) return true;
+    return p->use_v2 && c.c0 == 0 && c.C == c.M && nf / NB >= p->run_min_tiles;
+}
+
 bool fused_can_overlap(const FusedPlan *p, uint32_t nf)
 {
     return p->keep_tail && p->tail_valid && fused_v2_call(p, nf) && nf % NB == 0 && !p->cfg.mix;
@@ -862,6 +873,10 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     A.vend_in = p->d_vend[p->cur];   A.vend_out = p->d_vend[p->cur ^ 1];
     A.rp_in = p->d_rp[p->cur];       A.rp_out = p->d_rp[p->cur ^ 1];
     A.out_stride = nf; A.out_t0 = 0;
+    if (call.tile_major) {
+        if (!fused_tile_major_ok(p, nf)) { set_error("fused: internal: tile-major output requested from a call that cannot write it"); return -1; }
+        A.out_stride = NB;                   // a row's 16 frames of a tile are one 128-byte line; rows follow each other inside the tile's block
+    }
     A.parity0 = (uint32_t)(p->frames_done & 1);
     const uint32_t nb_full = nf / NB;
     const bool shard = c.G > 1;      // interleaved shard: every whole tile goes through k_run256v2<.., G> (the tile kernel only knows whole bands)
@@ -901,6 +916,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         RA.pair_align = (v2 && (c.fm || getenv("CSDR_PAIR_ALIGN_CF"))) ? 1u : 0u;
         { const char *e = getenv("CSDR_WU_BATCH6"); RA.wu_batch6 = e ? (uint32_t)atoi(e) : 1u; }
         RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;
+        RA.tile_step = call.tile_major ? c.C * 128u : (uint32_t)NB * (c.fm ? 4u : 8u);
         const bool whole = nf == nb_full * NB;
         RA.indep = (call.indep && v2 && whole && !c.mix && p->keep_tail && p->tail_valid) ? 1u : 0u;
         RA.prev_tail = p->d_tail[p->tail_w];

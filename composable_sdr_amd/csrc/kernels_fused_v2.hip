@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                 }
                 // slot u of mine is register slot S0 (+ 2 hb) + u: k2 = XIDX(slot); the lane part of the row (j1, hb) is in voff
                 float2 *stp = ST + k1 * 16 + S0 + (G == 8 ? 2 * hb : 0);
-                char *obase = reinterpret_cast<char *>(A.out) + (size_t)16 * b * (FM ? 4u : 8u);
+                char *obase = reinterpret_cast<char *>(A.out) + (size_t)b * RA.tile_step;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile image (issued a tile ago)
                 if (FM) {
                     float2 rp[NS], rr[NS];
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         if (!(V2_ABLATE & 16)) fft16_v(vv);             // vv[i] = Y[k1 + 16 XIDX(i)] of frame f2
         V2STAMP(11);
         // ---- tail
-        char *obase = reinterpret_cast<char *>(A.out) + (size_t)16 * b * (FM ? 4u : 8u);
+        char *obase = reinterpret_cast<char *>(A.out) + (size_t)b * RA.tile_step;
         if (FM) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile image (issued a tile ago): nothing else is outstanding
 #pragma unroll

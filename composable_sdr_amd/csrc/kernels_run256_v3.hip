@@ -397,7 +397,7 @@ __global__ __launch_bounds__(512) void k_run256v3(V3Args VA)
             }
             fft16_v(vv);                                // vv[i] = Y[k1 + 16 XIDX(i)] of frame f2
             // ---- tail
-            char *obase = reinterpret_cast<char *>(A.out) + (size_t)16 * b * (FM ? 4u : 8u);
+            char *obase = reinterpret_cast<char *>(A.out) + (size_t)b * RA.tile_step;
             if (FM) {
 #pragma unroll
                 for (int i = 0; i < 16; i += 4) {

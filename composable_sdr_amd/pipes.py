@@ -372,6 +372,10 @@ class Chain:
         check(lib().csdr_chain_debug_agc(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def agc_tile_major_calls(self):
+        """calls since create whose AGC tail ran on a tile-major plane (k_agc_spec_tm)"""
+        return lib().csdr_chain_debug_agc_tile_major_calls(self.h)
+
     def reset(self):
         check(lib().csdr_chain_reset(self.h))
         self._pending = []                              # the native side abandons chunks still in flight

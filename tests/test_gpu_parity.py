@@ -910,6 +910,69 @@ def test_agc_tail_default_segment_rule_bit_identical(M, demod):
     a.close(); b.close()
 
 
+def _bursty_torch(M, nf, seed, dev):
+    """_bursty's "bursts" signal at run-kernel sizes, generated on the GPU: noise + every third channel keyed on and off with gaps
+    of 200 .. 1500 channel samples (around the 1000-sample squelch timeout)"""
+    import torch
+    from synth import channel_centre
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    n = M * nf
+    x = torch.randn(n, 2, generator=g, device=dev, dtype=torch.float32) * 0.02
+    t = torch.arange(n, device=dev, dtype=torch.float64)
+    rng = np.random.default_rng(seed)
+    for k in range(1, M, 3):
+        gate = np.ones(nf, dtype=np.float32)
+        pos, on = 0, bool(k & 1)
+        while pos < nf:
+            ln = int(rng.integers(200, 1500))
+            gate[pos:pos + ln] = 1.0 if on else 0.0
+            pos += ln; on = not on
+        amp = torch.from_numpy(gate).to(dev).repeat_interleave(M) * (0.4 / np.sqrt(M / 3))
+        ph = channel_centre(k, M) * t + 0.3 * torch.sin(2 * np.pi * t / (M * 50.0))
+        x[:, 0] += (amp * torch.cos(ph)).float(); x[:, 1] += (amp * torch.sin(ph)).float()
+    return x.reshape(-1)
+
+
+@pytest.mark.parametrize("demod,G", [("fm", 1), ("none", 1), ("fm", 8), ("fm", 2)])
+def test_agc_tail_tile_major_route_is_bit_identical_to_sequential(demod, G, monkeypatch):
+    """k_agc_spec_tm (round 4: the fused 256-channel chains write the CF32 plane tile-major, a workgroup's 64 streams are 64 channels
+    at one segment, contiguous 8 KiB per block by LDS-DMA, packed freqdem) against the one-lane-per-channel kernels, BIT FOR BIT, on
+    a keyed signal that makes segment boundaries fail (short warm-up, short segments), over run-sized calls with the state carried;
+    whole band and interleaved shards (C = 32: two segments per workgroup; C = 128)."""
+    import torch
+    from composable_sdr_amd import _lib
+    M, kf = 256, 0.3
+    monkeypatch.setenv("CSDR_AGC_W", "512")
+    monkeypatch.setenv("CSDR_AGC_L_TM", "688")
+    frames = [36864, 40000, 33, 32768 + 48]
+    dev = torch.device("cuda", 0)
+    xd = _bursty_torch(M, sum(frames), 4321 + G, dev)
+    kw = dict(channels=M, demod=demod, kf=kf, agc=8.0, max_frames=max(frames))
+    if G > 1:
+        kw.update(chan_first=G - 1, chan_stride=G)
+    a = cs.Chain(flags=_lib.FLAG_QUIET, **kw)
+    b = cs.Chain(flags=_lib.FLAG_QUIET | _lib.FLAG_AGC_SEQUENTIAL, **kw)
+    C, w = M // G, (1 if demod == "fm" else 2)
+    pos = 0
+    for f in frames:
+        oa = torch.zeros(C * f * w, dtype=torch.float32, device=dev); ob = torch.zeros_like(oa)
+        ptr = xd.data_ptr() + pos * M * 8
+        a.process_device(ptr, M * f, oa.data_ptr(), 0)
+        b.process_device(ptr, M * f, ob.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert torch.equal(oa.view(torch.int32), ob.view(torch.int32)), (demod, G, f, pos)
+        opened = float((ob != 0).float().mean())
+        assert 0.02 < opened < 0.98 or f < 100, opened
+        pos += f
+    checked, redone = a.agc_stats()
+    tmc = a.agc_tile_major_calls()
+    print(f"tile-major AGC tail {demod} G={G}: {tmc} of {len(frames)} calls on k_agc_spec_tm; segments checked {checked}, recomputed {redone}")
+    assert tmc == 3                                      # the 33-frame call is not whole tiles: row-major route
+    assert redone > 0                                    # the keyed signal does make speculation fail: the repair path ran
+    a.status(); b.status()
+    a.close(); b.close()
+
+
 def test_agc_tail_steady_state_needs_no_recompute():
     """on a stationary signal (the bench's) the speculation always verifies after the first call"""
     from composable_sdr_amd import _lib
@@ -1661,16 +1724,17 @@ def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod, a
             mism = int(np.sum((got == 0) != (want == 0)))
             d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
             op = want != 0
-            print(f"fused shard G={G} g={g} FM + AGC: mute-mask mismatches vs whole band {mism}, open {op.mean():.3f}, open median {np.median(d[op]):.2e}, p99.9 {np.quantile(d, 0.999):.2e}")
+            print(f"fused shard G={G} g={g} FM + AGC: mute-mask mismatches vs whole band {mism}, open {op.mean():.3f}, p99.9 {np.quantile(d, 0.999):.2e}")
             assert mism == 0
-            assert 0.05 < op.mean() < 0.95
-            assert np.median(d[op]) < 2e-5 and np.quantile(d, 0.999) < 5e-4
+            tones = ((np.arange(g, M, G) % 4) == 1).any()          # the fixture's carriers sit on channels k = 1 (mod 4)
+            assert op.mean() < 0.95 and (op.mean() > 0.05 or not tones)
+            assert (not tones or np.median(d[op]) < 2e-5) and np.quantile(d, 0.999) < 5e-4      # (noise-only shards open for the create-time transient only)
             wo, go = want_or[g::G], got[:, : frames[0]]
             mo = int(np.sum((go == 0) != (wo == 0)))
             do = np.abs(wrap_pm(go.astype(np.float64) - wo, 1.0 / kf))
-            print(f"    first call vs oracle rows {g}::{G}: mute-mask mismatches {mo}, open median {np.median(do[wo != 0]):.2e}, p99.9 {np.quantile(do, 0.999):.2e}")
+            print(f"    first call vs oracle rows {g}::{G}: mute-mask mismatches {mo}, p99.9 {np.quantile(do, 0.999):.2e}")
             assert mo == 0
-            assert np.median(do[wo != 0]) < 2e-5 and np.quantile(do, 0.999) < 5e-4
+            assert (not tones or np.median(do[wo != 0]) < 2e-5) and np.quantile(do, 0.999) < 5e-4
         elif demod == "fm":
             d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
             tone = (np.arange(g, M, G) % 4) == 1
