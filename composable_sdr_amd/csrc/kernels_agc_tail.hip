@@ -26,6 +26,7 @@
 #include "fm_common.h"
 #include "agc_common.h"
 #include <cstdlib>
+#include <cstdio>
 #ifndef CSDR_AGC_ABLATE
 #define CSDR_AGC_ABLATE 0      // timing experiments only: 1 no log/exp, 2 every block reloads the same (cached) lines, 4 no stores, 16 no compute, 32 mover skips the ring writes, 64 no barrier
 #endif
@@ -98,11 +99,14 @@ struct TailArgs {
     const AgcState *st_spec;// [C] state the speculative warm-ups start from: st_in, except on a stream's first call (k_agc_pilot)
     const float2 *rp_in;    // [C] freqdem r' before the call (FM)
     AgcSeg *seg_start, *seg_end;   // [C][nseg]
+    AgcSeg *ckpt;           // tile-major route: [C][nseg][nck] state after every TM_CK samples of a segment (k_agc_fix stops a repair where it meets them)
+    uint32_t nck;
     uint32_t C, nf, L, W, nseg;
     AgcParams p;
     float ref;
     uint32_t tm;            // 1: Z is tile-major (what the fused run kernels write for k_agc_spec_tm)
 };
+constexpr uint32_t TM_CK = 256;         // samples between the checkpoints of a segment
 constexpr uint32_t TM_GUARD = 512;      // blocks of 16 samples: >= max(W, L) / 16 of the tile-major route (W, L <= 8192)
 
 // index of sample (c, t) in the channelizer plane
@@ -400,7 +404,14 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec(TailArgs A, uint32_t groups
 //   * one LDS-only barrier per block.
 // Channels per workgroup Cw = min(C, 64); for C < 64 (interleaved shards of eight) a workgroup takes 64 / C segments.
 // Same records, same verification (k_agc_fix), same bits as k_agc_spec.
-constexpr int TM_DEPTH = 3;                 // blocks in flight
+#ifndef TM_ABLATE
+#define TM_ABLATE 0          // timing experiments only: 1 post wave without the freqdem arithmetic, 2 gain wave without the recurrence, 4 no output stores
+#endif
+#ifndef TM_DEPTH_N
+#define TM_DEPTH_N 3
+#endif
+constexpr int TM_DEPTH = TM_DEPTH_N;        // blocks in flight
+static_assert(TM_DEPTH >= 1 && TM_DEPTH <= 6, "vmcnt immediates above");
 constexpr int TM_SLOTS = TM_DEPTH + 2;      // ring slots of 8 KiB: TM_DEPTH in flight, one with the gain wave, one with the post wave
 
 typedef float tm_v2f __attribute__((ext_vector_type(2)));
@@ -423,7 +434,8 @@ __device__ __forceinline__ void agc_gain_quad(const float4 va, const float4 vb, 
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if (WANT_Y) { const tm_v2f yy = (tm_v2f){x[i].x, x[i].y} * (tm_v2f){q.g, q.g}; y[i] = make_float2(yy.x, yy.y); }
-        agc_gain_update(e[i], q.g, q.y2, p.alpha);
+        if (TM_ABLATE & 2) { q.y2 += e[i]; q.g = __builtin_amdgcn_fmed3f(q.g + 1e-9f * q.y2, 0.0f, 1e6f); }
+        else agc_gain_update(e[i], q.g, q.y2, p.alpha);
         gs[i] = q.g;
         asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(mex[i]) : "v"(q.g), "v"(p.g_thr));       // threshold exceeded after this sample
     }
@@ -501,7 +513,7 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
                 // F32: pieces 0..3 are block k0, pieces 4..7 block k0 + 1 (pair) -- each must lie inside the segment
                 const int32_t tp = t0 + (FM ? 16 * (int32_t)(((uint32_t)lane & 7u) >> 2) : 0);
                 const bool ok = ook[mm] && t0 >= 0 && (uint32_t)tp < e2 && (FM && !pair ? ((uint32_t)lane & 7u) < 4u : true);
-                if (ok) {
+                if (ok && !(TM_ABLATE & 4)) {
                     const float4 v = buf[slot8((int)jj, lane & 7)];
                     *reinterpret_cast<float4 *>(obase + ooff[mm] + (size_t)(16u * (k0 - kreal)) * (FM ? 4u : 8u)) = v;
                 }
@@ -527,7 +539,8 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
                                          make_float2(v[2 * h + 1].x, v[2 * h + 1].y), make_float2(v[2 * h + 1].z, v[2 * h + 1].w)};
                     const float2 rq[4] = {rp, y[0], y[1], y[2]};
                     float m[4];
-                    fm_quad_rn(rq, y, fk, m);
+                    if (TM_ABLATE & 1) { m[0] = rq[0].x + y[0].y; m[1] = rq[1].x + y[1].y; m[2] = rq[2].x + y[2].y; m[3] = rq[3].x + y[3].y; }
+                    else fm_quad_rn(rq, y, fk, m);
                     rp = y[3];
                     mq[h] = make_float4(m[0], m[1], m[2], m[3]);
                 }
@@ -602,7 +615,10 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
             // block `it` has landed once at most min(TM_DEPTH - 1, nblk - 1 - it) younger blocks (8 instructions each) are in flight:
             // this wave's vmcnt queue holds the DMA and nothing else (the state records below are stored after the loop)
             const uint32_t younger = min((uint32_t)TM_DEPTH - 1u, nblk - 1u - it);
-            if (younger >= 2u) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (younger >= 5u) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            else if (younger == 4u) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (younger == 3u) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (younger == 2u) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if (younger == 1u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -631,6 +647,10 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
                 buf[slot8(lane, 2 * h + 1)] = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
                 if (h == 3) { q.rx = y[3].x; q.ry = y[3].y; }
             }
+            // a checkpoint every TM_CK samples: where a repair (k_agc_fix) that starts from another state meets this trajectory
+            // bit for bit, everything behind it is already what the sequential recurrence produces
+            const uint32_t done = 16u * (it - kreal + 1u);
+            if (it >= kreal && done % TM_CK == 0u && done < A.L) A.ckpt[((size_t)ch * A.nseg + sg) * A.nck + (done / TM_CK - 1u)] = q;
         }
     }
     if (mine) A.seg_end[(size_t)ch * A.nseg + sg] = q;
@@ -645,8 +665,10 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
 // at most nseg rounds; in practice failures are isolated and one or two rounds do (a repaired segment almost always
 // runs into the end state it had before).  Reads and writes of a round are separated by barriers, so nobody compares
 // against a half-written record.
+// returns true when the repair met the recorded trajectory at a checkpoint (tile-major route): the segment's recorded end state
+// and everything behind the checkpoint stay as they are
 template <bool FM>
-__device__ __forceinline__ void repair_segment(const TailArgs &A, uint32_t c, uint32_t s, AgcSeg &cur)
+__device__ __forceinline__ bool repair_segment(const TailArgs &A, uint32_t c, uint32_t s, AgcSeg &cur)
 {
     const uint32_t t0 = s * A.L, t1 = min(A.nf, t0 + A.L);
     const size_t rowo = (size_t)c * A.nf;
@@ -659,6 +681,7 @@ __device__ __forceinline__ void repair_segment(const TailArgs &A, uint32_t c, ui
     };
     uint32_t t = t0;
     if (A.tm) {                                                 // tile-major: t0, t1 are multiples of 16, a block is one 128-byte line
+        AgcSeg *ck = A.ckpt + ((size_t)c * A.nseg + s) * A.nck;
         for (; t + 16 <= t1; t += 16) {
             const float4 *src = reinterpret_cast<const float4 *>(A.Z + z_index(A, c, t));
             float4 v[8];
@@ -666,8 +689,14 @@ __device__ __forceinline__ void repair_segment(const TailArgs &A, uint32_t c, ui
             for (int i = 0; i < 8; i++) v[i] = src[i];
 #pragma unroll
             for (int i = 0; i < 8; i++) { one(make_float2(v[i].x, v[i].y), t + 2 * i); one(make_float2(v[i].z, v[i].w), t + 2 * i + 1); }
+            const uint32_t done = t + 16 - t0;
+            if (done % TM_CK == 0u && done < A.L && t + 16 < t1) {
+                AgcSeg &rec = ck[done / TM_CK - 1u];
+                if (same_state(rec, cur, FM)) return true;      // from here on the outputs and states on file ARE this trajectory
+                rec = cur;                                      // the checkpoints follow the trajectory whose outputs are in memory
+            }
         }
-        return;
+        return false;
     }
     const float2 *row = A.Z + rowo;
     if (((rowo + t) & 1) && t < t1) { one(row[t], t); t++; }    // up to a 16-byte boundary
@@ -679,6 +708,7 @@ __device__ __forceinline__ void repair_segment(const TailArgs &A, uint32_t c, ui
         for (int i = 0; i < 8; i++) { one(make_float2(v[i].x, v[i].y), t + 2 * i); one(make_float2(v[i].z, v[i].w), t + 2 * i + 1); }
     }
     for (; t < t1; t++) one(row[t], t);
+    return false;
 }
 
 // A stream's first call starts from the reference's create-time state (g = 1000, Liquid.chs:707-717), which 1024 samples of
@@ -736,8 +766,9 @@ __global__ __launch_bounds__(256) void k_agc_fix(TailArgs A, AgcState *st_out, f
             if (!__syncthreads_or(need)) continue;              // (also: everybody has read before anybody writes)
             if (need) {
                 AgcSeg cur = e;
-                repair_segment<FM>(A, c, s, cur);
-                ss[s] = e; se[s] = cur;
+                const bool met = repair_segment<FM>(A, c, s, cur);
+                ss[s] = e;
+                if (!met) se[s] = cur;                          // (met: the recorded end state is the end of this very trajectory)
                 changed = true; redone++;
             }
             __threadfence();
@@ -762,7 +793,8 @@ struct AgcTailPlan {
     uint32_t C = 0, max_nf = 0, L = 0, Lmin = 384, W = 1024, max_seg = 0;   // L > 0: fixed by CSDR_AGC_L
     uint32_t L_tm = 0;               // tile-major route: fixed segment length (CSDR_AGC_L_TM), 0 = chosen per call
     uint32_t tm_calls = 0;           // calls that took k_agc_spec_tm since create
-    AgcSeg *d_start = nullptr, *d_end = nullptr;
+    AgcSeg *d_start = nullptr, *d_end = nullptr, *d_ckpt = nullptr;
+    size_t ckpt_cap = 0;
     AgcState *d_st_tmp = nullptr;    // [C] settled state of the pilot (first call of a stream)
     bool fresh = true;               // the AGC state is the create-time one: the next call runs the pilot
     uint32_t pilot_n = 4096;
@@ -774,6 +806,7 @@ int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
 {
     AgcTailPlan *p = new AgcTailPlan();
     p->C = C; p->max_nf = max_nf;
+    if (TM_ABLATE) fprintf(stderr, "csdr: kernels_agc_tail.hip built with TM_ABLATE=%d: timing only, results are wrong\n", TM_ABLATE);
     if (const char *e = getenv("CSDR_AGC_L")) { p->L = (uint32_t)atol(e); p->L = (p->L + 15u) / 16u * 16u; if (p->L < 16) p->L = 16; }
     if (const char *e = getenv("CSDR_AGC_L_TM")) { p->L_tm = ((uint32_t)atol(e) + 15u) / 16u * 16u; if (p->L_tm < 16) p->L_tm = 16; if (p->L_tm > 8176u) p->L_tm = 8176u; }
     if (const char *e = getenv("CSDR_AGC_W")) p->W = (uint32_t)atol(e);
@@ -788,7 +821,9 @@ int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
     }
     p->max_seg = (max_nf + 15u) / 16u + 1;                      // L >= 16
     const size_t n = (size_t)C * p->max_seg;
+    p->ckpt_cap = (size_t)C * ((size_t)max_nf / TM_CK + (size_t)max_nf / 384u + 64u);
     if (hipMalloc(&p->d_start, n * sizeof(AgcSeg)) != hipSuccess || hipMalloc(&p->d_end, n * sizeof(AgcSeg)) != hipSuccess ||
+        hipMalloc(&p->d_ckpt, p->ckpt_cap * sizeof(AgcSeg)) != hipSuccess ||
         hipMalloc(&p->d_st_tmp, (size_t)C * sizeof(AgcState)) != hipSuccess || hipMalloc(&p->d_stats, 2 * sizeof(unsigned)) != hipSuccess) {
         set_error("agc tail: device allocation failed");
         agc_tail_destroy(p);
@@ -802,7 +837,7 @@ int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
 void agc_tail_destroy(AgcTailPlan *p)
 {
     if (!p) return;
-    void *ptrs[] = {p->d_start, p->d_end, p->d_st_tmp, p->d_stats};
+    void *ptrs[] = {p->d_start, p->d_end, p->d_ckpt, p->d_st_tmp, p->d_stats};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -845,8 +880,10 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     const uint32_t Cw = p->C < 64u ? p->C : 64u, nsub = 64u / Cw, ncg = p->C / Cw;     // tile-major: channels per workgroup, segments per workgroup, channel groups
     uint32_t L = tm ? p->L_tm : p->L;
     if (!L && tm) {
-        // as many workgroups as the device holds at once: ncg channel groups x (nseg / nsub) segment groups
-        uint64_t nseg_t = (uint64_t)p->wg_slots * nsub / ncg;
+        // two thirds of the workgroups the device holds at once (ncg channel groups x nseg / nsub segment groups): measured optimum
+        // between the warm-up re-reads ((W + L) / L times the plane, shorter segments) and the blocks a workgroup walks (longer ones);
+        // profiles/r04_agc_tm_segment_sweep.txt
+        uint64_t nseg_t = (uint64_t)p->wg_slots * nsub * 2u / (3u * ncg);
         if (nseg_t < 2) nseg_t = 2;
         L = (uint32_t)((nf + nseg_t - 1) / nseg_t);
         L = (L + 31u) / 32u * 32u;                               // F32 rows leave as whole 128-byte lines per block pair
@@ -868,6 +905,8 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     A.Z = Z; A.out = out; A.st_in = st; A.rp_in = rp_in; A.seg_start = p->d_start; A.seg_end = p->d_end;
     A.C = p->C; A.nf = nf; A.L = L; A.W = p->W; A.nseg = nseg; A.p = prm; A.ref = fm_ref;
     A.st_spec = st; A.tm = tm ? 1u : 0u;
+    A.ckpt = p->d_ckpt; A.nck = (L + TM_CK - 1u) / TM_CK;
+    if (tm && (size_t)p->C * nseg * A.nck > p->ckpt_cap) { set_error("agc tail: internal checkpoint bound"); return CSDR_ERR_INVALID; }
     if (p->fresh && nseg > 1) {
         const uint32_t n = nf < p->pilot_n ? nf : p->pilot_n;
         hipLaunchKernelGGL(k_agc_pilot, dim3((p->C + 63u) / 64u), dim3(64), 0, s, A, n, p->d_st_tmp);
@@ -881,9 +920,9 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     const dim3 grid(p->C * groups), block(128);
     if (tm) {
         p->tm_calls++;
-        const dim3 gtm(ncg * ((nseg + nsub - 1) / nsub));
-        if (fm) hipLaunchKernelGGL((k_agc_spec_tm<true>), gtm, block, 0, s, A, ncg, Cw, nsub);
-        else hipLaunchKernelGGL((k_agc_spec_tm<false>), gtm, block, 0, s, A, ncg, Cw, nsub);
+        const dim3 gtm(ncg * ((nseg + nsub - 1) / nsub)), btm(128);
+        if (fm) hipLaunchKernelGGL((k_agc_spec_tm<true>), gtm, btm, 0, s, A, ncg, Cw, nsub);
+        else hipLaunchKernelGGL((k_agc_spec_tm<false>), gtm, btm, 0, s, A, ncg, Cw, nsub);
     } else if (pairs) {
         if (fm) hipLaunchKernelGGL((k_agc_spec<true, true>), grid, block, 0, s, A, groups);
         else hipLaunchKernelGGL((k_agc_spec<false, true>), grid, block, 0, s, A, groups);

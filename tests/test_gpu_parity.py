@@ -1019,7 +1019,7 @@ def test_agc_tail_full_size_bit_identical_and_oracle_prefix():
             first = oa.view(M, nf)[:, :8192].cpu().numpy()
     checked, redone = a.agc_stats()
     print(f"full-size AGC tail: segments checked {checked}, recomputed {redone}")
-    assert checked >= 2 * 256 * 250
+    assert checked >= 2 * 256 * 150                     # (tile-major route: ~168 segments per channel and chunk)
     a.close(); b.close()
     x0 = xs[0][: M * 8192].cpu().numpy().view(np.complex64).reshape(-1)
     want = O.Chain(M, demod="fm", kf=kf, agc_db=10.0).process(x0)
@@ -1727,7 +1727,7 @@ def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod, a
             print(f"fused shard G={G} g={g} FM + AGC: mute-mask mismatches vs whole band {mism}, open {op.mean():.3f}, p99.9 {np.quantile(d, 0.999):.2e}")
             assert mism == 0
             tones = ((np.arange(g, M, G) % 4) == 1).any()          # the fixture's carriers sit on channels k = 1 (mod 4)
-            assert op.mean() < 0.95 and (op.mean() > 0.05 or not tones)
+            assert op.mean() > 0.05 or not tones                 # (a shard may hold carriers only, or none)
             assert (not tones or np.median(d[op]) < 2e-5) and np.quantile(d, 0.999) < 5e-4      # (noise-only shards open for the create-time transient only)
             wo, go = want_or[g::G], got[:, : frames[0]]
             mo = int(np.sum((go == 0) != (wo == 0)))
