@@ -357,6 +357,42 @@ def main():
                  "rccl_ranks": dist.get_world_size()}
         sc2.chain.close()
 
+    # N > 1: SURVEY 8e(B) for the AGC configuration -- linear front end on time stripes, ONE all-to-all of the channel-major CF32
+    # plane (RCCL over xGMI), AGC + squelch + freqdem tails on channel blocks -- measured in the same run, reported under "hybrid"
+    # (weak scaling like the time stripes: every rank brings its own stripe; `-a 10` whatever --agc says: without the AGC the time
+    # stripes need no exchange at all)
+    hyb = None
+    if world > 1 and M % world == 0 and not a.mix and a.demod in ("fm", "none"):
+        from composable_sdr_amd.pipes import ChainConfig
+        from composable_sdr_amd.sharded import ShardedChain
+        agc_h = a.agc if a.agc != 0.0 else 10.0
+        sch = ShardedChain(ChainConfig(channels=M, demod=a.demod, kf=a.kf, agc=agc_h, max_frames=nf, device=local, flags=_lib.FLAG_QUIET), mode="hybrid")
+        plane = torch.empty(M * nf * 2, dtype=torch.float32, device=dev)
+        recv = torch.empty_like(plane)
+
+        def step3(i):
+            sch.process_device_hybrid(xv[i & 1], plane, recv, out, stream)
+        reps3 = max(3, a.steps // 2)
+        for i in range(2):
+            step3(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(reps3):
+            step3(i)
+        barrier()
+        d3 = time.perf_counter() - t1
+        t = torch.tensor([d3], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d3 = float(t.item())
+        hyb = {"value": round(nx * world * reps3 / d3 / 1e6, 1), "unit": "MS/s", "ms_per_step": round(d3 / reps3 * 1e3, 4), "steps": reps3, "scaling": "weak",
+               "agc_db": agc_h, "path": sch.chain.path + " -> all_to_all -> " + sch.tail.path,
+               "sharding": f"hybrid (SURVEY 8e(B)): DC blocker + pre-mix + firpfbch on time stripes (one per rank), all-to-all of the [{M}][{nf}] CF32 plane, "
+                           f"AGC + squelch{' + freqdem' if a.demod == 'fm' else ''} on channel blocks of {M // world}",
+               "collective": f"RCCL all_to_all_single of {M * nf * 8 / 2**20:.0f} MiB per rank and step ({world - 1}/{world} of it crosses xGMI)",
+               "rccl_ranks": dist.get_world_size()}
+        sch.chain.close(); sch.tail.close()
+        del plane, recv
+
     if rank != 0:
         dist.barrier()
         dist.destroy_process_group()
@@ -421,6 +457,8 @@ def main():
                             "hbm_roofline_frac_whole_step": round(nx * alg_bytes_per_sample / d_s / 1e9 / HBM_PEAK_GBS, 4)}
     if chan2:
         res["channel_shard"] = chan2
+    if hyb:
+        res["hybrid"] = hyb
     if world == 1 and not a.no_agc_variant and a.agc == 0.0 and M == 256 and not a.mix:
         # cfg3 with the AGC on (squelch threshold -a 10 between the tone and the noise channels): the PFB kernel
         # writes channel-major CF32, the time-parallel verified AGC tail (bit-identical to the sequential

@@ -9,6 +9,7 @@ _SO = os.environ.get("CSDR_LIB") or os.path.join(_HERE, "libcsdr_hip.so")   # CS
 DEMOD_NONE, DEMOD_FM, DEMOD_AM, DEMOD_WBFM = 0, 1, 2, 3
 FLAG_TIME_KERNELS, FLAG_FORCE_GENERIC, FLAG_QUIET, FLAG_AGC_SEQUENTIAL, FLAG_NO_MIX_IDENTITY = 1, 2, 4, 8, 16
 FLAG_TIME_REGION = 32
+FLAG_TAIL_ONLY = 64
 
 ERR_INVALID, ERR_HIP, ERR_NODEV, ERR_SIZE, ERR_NOMEM = -1, -2, -3, -4, -5
 

@@ -142,6 +142,7 @@ struct csdr_chain {
     uint32_t n_cus = 256;            // compute units of the device (run count of the fused M = 1024 kernel)
     AgcTailPlan *agc_tail = nullptr; // AGC on: time-parallel verified tail (unless CSDR_FLAG_AGC_SEQUENTIAL)
     // DeAM: the chain runs as DeNo into d_amz, then the ampmodem peak detector (kernels_am.hip) [+ mix]
+    bool tail_only = false;          // CSDR_FLAG_TAIL_ONLY: AGC [+ freqdem] [+ mix] on a channel-major CF32 plane
     bool am = false, am_mix = false;
     // DeWBFM: the chain runs as DeNBFM 0.6 into d_wbf, then de-emphasis + decimator (kernels_wbfm.hip) [+ mix]
     bool wbfm = false, wbfm_mix = false; uint32_t wb_decim = 4, wb_hlen = 0; BiquadParams wb_bq{};
@@ -671,6 +672,42 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     if (wbfm) { eff.demod = CSDR_DEMOD_FM; eff.kf = 0.6f; eff.mix = 0; }
     const csdr_chain_cfg *cfg = &eff;
     if (cfg->channels < 1 || cfg->channels > (1u << 16)) { set_error("chain: channels %u out of range", cfg->channels); return CSDR_ERR_INVALID; }
+    if (cfg_in->flags & CSDR_FLAG_TAIL_ONLY) {
+        // the per-channel tail alone (hybrid multi-GPU partition): rows in, rows out; state = AGC {g, y2', mode, timer} + freqdem r' per row
+        if (cfg_in->agc_threshold_db == 0.0f || am || wbfm) { set_error("chain: CSDR_FLAG_TAIL_ONLY needs the AGC on (-a != 0) and demod none / FM (without the AGC a time stripe needs no tail shard)"); return CSDR_ERR_INVALID; }
+        if (cfg->demod == CSDR_DEMOD_FM && !(cfg->kf > 0.f)) { set_error("chain: FM needs kf > 0"); return CSDR_ERR_INVALID; }
+        int dev; int r = check_device(cfg->device, &dev); if (r) return r;
+        DevGuard guard(dev);
+        if (!guard.ok) { set_error("chain: cannot select device %d", dev); return CSDR_ERR_HIP; }
+        csdr_chain *h = new (std::nothrow) csdr_chain();
+        if (!h) return CSDR_ERR_NOMEM;
+        h->cfg = *cfg; h->cfg.chan_first = 0; h->cfg.chan_count = 0; h->cfg.chan_stride = 0; h->cfg.dc_block = 0;
+        h->device = dev; h->tail_only = true;
+        h->M = cfg->channels; h->C = cfg->channels; h->c0 = 0; h->G = 1; h->p = 0;
+        h->max_nf = cfg->max_frames ? cfg->max_frames : 4096;
+        h->max_nx = (uint64_t)h->max_nf * h->M;
+        if (h->max_nx > 0xffffffffull) { set_error("chain: max_frames*channels exceeds 2^32-1 samples"); delete h; return CSDR_ERR_INVALID; }
+        h->agc = make_agc(cfg->agc_threshold_db);
+        if (cfg->demod == CSDR_DEMOD_FM) h->fm_ref = fm_ref_of(cfg->kf);
+        auto failt = [&](int code) { csdr_chain_destroy(h); return code; };
+        if ((r = dev_alloc(&h->d_dcstate, 1))) return failt(r);
+        if ((r = dev_alloc(&h->d_agc, h->C))) return failt(r);
+        if (cfg->demod == CSDR_DEMOD_FM && ((r = dev_alloc(&h->d_rp[0], h->C)) || (r = dev_alloc(&h->d_rp[1], h->C)))) return failt(r);
+        if (cfg->mix && h->C > 1 && (r = dev_alloc(&h->d_B, (size_t)h->C * h->max_nf))) return failt(r);
+        if (!(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL)) { if ((r = agc_tail_create(h->C, h->max_nf, &h->agc_tail))) return failt(r); }
+        else if ((r = dev_alloc(&h->d_A, (size_t)h->C * h->max_nf))) return failt(r);        // the one-lane-per-channel kernel works in place
+        h->path = std::string("tail-only+agc") + (h->agc_tail ? "-spec" : "");
+        h->timed_kernel = "k_agc_spec";
+        if ((r = chain_init_state(h, nullptr))) return failt(r);
+        CSDR_HIP_CLEAN(hipDeviceSynchronize(), csdr_chain_destroy(h));
+        if (!(cfg->flags & CSDR_FLAG_QUIET)) {
+            printf("csdr chain [%s] on HIP device %d: %u channel rows, agc=%g dB demod=%s kf=%g mix=%u\n", h->path.c_str(), dev, h->C,
+                   cfg->agc_threshold_db, cfg->demod == CSDR_DEMOD_FM ? "FM" : "none", cfg->kf, cfg->mix);
+            fflush(stdout);
+        }
+        *out = h;
+        return CSDR_OK;
+    }
     if (cfg->demod == CSDR_DEMOD_FM && !(cfg->kf > 0.f)) { set_error("chain: FM needs kf > 0"); return CSDR_ERR_INVALID; }
     if (cfg->dc_block && !(cfg->dc_alpha > 0.f && cfg->dc_alpha < 1.f)) { set_error("chain: dc_alpha out of (0,1)"); return CSDR_ERR_INVALID; }
     const uint32_t M = cfg->channels;
@@ -1050,6 +1087,24 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
     hipStream_t s = (hipStream_t)stream;
     const uint32_t nf = n_in / h->M;
     int r;
+    if (h->tail_only) {
+        const bool fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix && h->M > 1;
+        if (h->agc_tail) {
+            if ((r = chain_agc_tail(h, (const float2 *)d_in, nf, d_out, s))) return r;
+        } else {
+            CSDR_HIP(hipMemcpyAsync(h->d_A, d_in, sizeof(float2) * (size_t)n_in, hipMemcpyDeviceToDevice, s));
+            if ((r = launch_agc(h->d_A, h->C, nf, h->d_agc, h->agc, s))) return r;
+            if (fm) {
+                float *F = mixo ? (float *)h->d_B : (float *)d_out;
+                if ((r = launch_fm(h->d_A, F, h->C, nf, h->fm_ref, h->d_rp[h->rp_cur], h->d_rp[h->rp_cur ^ 1], s))) return r;
+                h->rp_cur ^= 1;
+                if (mixo && (r = launch_mix(F, (float *)d_out, h->C, nf, s))) return r;
+            } else if (mixo) { if ((r = launch_mix((const float *)h->d_A, (float *)d_out, h->C, 2 * nf, s))) return r; }
+            else CSDR_HIP(hipMemcpyAsync(d_out, h->d_A, sizeof(float2) * (size_t)n_in, hipMemcpyDeviceToDevice, s));
+        }
+        if (n_out) *n_out = mixo ? nf : h->C * nf;
+        return CSDR_OK;
+    }
     if (h->use_fused) {
         const bool agc_on = h->d_agc != nullptr, fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix != 0;
         float2 *Z = (agc_on && (fm || mixo || h->agc_tail)) ? h->d_A + h->a_guard : (float2 *)d_out;

@@ -248,6 +248,7 @@ class ChainConfig:
     flags: int = _lib.FLAG_QUIET
     pfb_m: int = 7
     pfb_as: float = 80.0
+    tail_only: bool = False     # CSDR_FLAG_TAIL_ONLY: the per-channel tail alone on a channel-major CF32 plane [channels][nf]
 
 
 class Chain:
@@ -266,7 +267,7 @@ class Chain:
         c.kf, c.mix = cfg.kf, int(cfg.mix)
         c.chan_first, c.chan_count = cfg.chan_first, cfg.chan_count
         c.chan_stride = cfg.chan_stride
-        c.device, c.max_frames, c.flags = cfg.device, cfg.max_frames, cfg.flags
+        c.device, c.max_frames, c.flags = cfg.device, cfg.max_frames, cfg.flags | (_lib.FLAG_TAIL_ONLY if cfg.tail_only else 0)
         c.pfb_m, c.pfb_as = cfg.pfb_m, cfg.pfb_as
         h = C.c_void_p()
         check(lib().csdr_chain_create(C.byref(c), C.byref(h)))

@@ -21,6 +21,15 @@ Two partitions of the reference's `-c M` channelizer:
                   With GPU-resident buffers the all-reduce runs on the output tensor itself
                   (process_device_mix: RCCL, no host hop).
 
+  mode="hybrid"   SURVEY 8e(B), for the configurations the two above cannot scale: per-channel AGC / squelch tails (state
+                  depends on unbounded history: no time stripes) behind a front end that channel sharding cannot divide (DC
+                  blocker, pre-mix and FIR see every branch).  Every rank runs the LINEAR front end (DC blocker -> pre-mix ->
+                  firpfbch, DeNo) on its own time stripe behind the warm-up prefix of mode="time", ONE all-to-all turns the
+                  [M][stripe] planes into [M / G][whole span] planes (rank g receives its channel block [g M / G, (g + 1) M / G) of
+                  every stripe: 7/8 of 8 bytes per sample cross xGMI at G = 8), and the rank's tail handle (CSDR_FLAG_TAIL_ONLY:
+                  automaticGainControl [-> fmDemodulator] on M / G rows) walks the whole time span.  Every stage divides by G.
+                  Front end to the stripe tolerance of mode="time"; the tail is exact given its input.
+
 Outputs stay on the rank that made them (per-channel files are written per rank); gather()
 collects them on rank 0 for tests.
 """
@@ -54,7 +63,8 @@ def channel_bounds(M, world, rank):
 
 
 class ShardedChain:
-    def __init__(self, cfg: ChainConfig, mode="time", rank=None, world=None, group=None, chain_factory=Chain, interleave=False):
+    def __init__(self, cfg: ChainConfig, mode="time", rank=None, world=None, group=None, chain_factory=Chain, interleave=False,
+                 tail_factory=None):
         import torch.distributed as dist
         self.dist = dist if dist.is_available() and dist.is_initialized() else None
         self.rank = rank if rank is not None else (self.dist.get_rank(group) if self.dist else 0)
@@ -80,13 +90,130 @@ class ShardedChain:
                 self.c0, self.cn = c0, cn
                 # the rank's partial mix is reduced across ranks afterwards
                 self.chain = chain_factory(replace(cfg, chan_first=c0, chan_count=cn)) if cn else None
+        elif mode == "hybrid":
+            if cfg.channels % self.world:
+                raise ValueError("hybrid sharding needs world | channels")
+            if cfg.agc == 0.0:
+                raise ValueError("hybrid sharding is for the AGC configurations; without the AGC use mode='time'")
+            if cfg.demod not in ("none", "fm"):
+                raise ValueError("hybrid sharding: demod none / fm")
+            self.interleave = False
+            self.cn = cfg.channels // self.world
+            self.c0 = self.rank * self.cn                     # contiguous channel blocks: the front end's plane is already grouped by destination rank
+            # linear front end on the time stripe (all channels, DeNo, no AGC); per-channel tail on the owned rows
+            self.chain = chain_factory(replace(cfg, agc=0.0, demod="none", mix=False, chan_first=0, chan_count=0, chan_stride=0))
+            self.tail = (tail_factory or chain_factory)(replace(cfg, channels=self.cn, chan_first=0, chan_count=0, chan_stride=0, tail_only=True,
+                                                                dc_block=False))
         else:
             raise ValueError(mode)
+
+    # ------------------------------------------------------------------ hybrid: time-sharded front end, all-to-all, channel-sharded tail
+    def hybrid_front(self, x):
+        """x: the WHOLE stream (host array).  This rank's front-end output on its stripe: ([M][t1 - t0] complex64, stripe bounds of every rank)."""
+        M = self.cfg.channels
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        nf = x.size // M
+        bounds = [stripe_bounds(nf, self.world, r) for r in range(self.world)]
+        t0, t1 = bounds[self.rank]
+        w0 = max(0, t0 - warmup_frames(M))
+        w0 -= w0 & 1                                  # even start: same pre-mix sign as the full stream
+        if hasattr(self.chain, "seek_frames"):
+            self.chain.seek_frames(w0)
+        front = self._run(self.chain, x, w0, t1)[:, t0 - w0:] if t1 > t0 else np.empty((M, 0), dtype=np.complex64)
+        return np.ascontiguousarray(front), bounds
+
+    def hybrid_exchange(self, plane, bounds):
+        """plane: this rank's front-end output [M][n][2] (torch, CF32 as float32 pairs).  Rank p owns the channel block
+        [p M / G, (p + 1) M / G), so the plane IS [G][M / G][n][2] grouped by destination: one all-to-all (equal stripes:
+        all_to_all_single; else send / receive pairs) returns the list of this rank's rows of every stripe, in time order."""
+        import torch
+        G, g = self.world, self.rank
+        mine = [plane[p * self.cn:(p + 1) * self.cn] for p in range(G)]
+        if self.dist is None or G == 1:
+            return [mine[g]]
+        if all(b1 - b0 == bounds[0][1] - bounds[0][0] for (b0, b1) in bounds):
+            out = torch.empty_like(plane)
+            self.dist.all_to_all_single(out, plane.contiguous(), group=self.group)
+            return list(out.view(G, self.cn, -1, 2))
+        recv = [torch.empty((self.cn, b1 - b0, 2), dtype=plane.dtype, device=plane.device) for (b0, b1) in bounds]
+        recv[g] = mine[g]
+        ops = []
+        for p in range(G):
+            if p == g:
+                continue
+            if mine[p].numel():
+                ops.append(self.dist.P2POp(self.dist.isend, mine[p].contiguous(), p, self.group))
+            if recv[p].numel():
+                ops.append(self.dist.P2POp(self.dist.irecv, recv[p], p, self.group))
+        for w in (self.dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return recv
+
+    def hybrid_tail(self, pieces):
+        """pieces: this rank's rows [M / G][n_k] (complex64) of consecutive stretches of the stream, in time order.  The tail handle
+        is streaming-stateful, so the stretches go through it one after the other; returns [M / G][sum n_k] (or [sum n_k] mixed)."""
+        step = self.cfg.max_frames
+        parts = []
+        for rows in pieces:
+            n = rows.shape[1]
+            for a in range(0, n, step):
+                parts.append(self.tail.process(np.ascontiguousarray(rows[:, a:min(n, a + step)]).reshape(-1)))
+        if not parts:
+            return self.tail.process(np.empty(0, dtype=np.complex64))
+        return np.concatenate(parts, axis=-1)
+
+    def process_stream_hybrid(self, x):
+        """x: the WHOLE stream (host array).  Returns this rank's output [M / G][nf]: the channel block [rank M / G, (rank + 1) M / G)."""
+        import torch
+        M = self.cfg.channels
+        front, bounds = self.hybrid_front(x)
+        plane = torch.from_numpy(front.view(np.float32).reshape(M, front.shape[1], 2))
+        if self.dist is not None and self.world > 1 and self.dist.get_backend(self.group) == "nccl":
+            plane = plane.to(torch.device("cuda", torch.cuda.current_device()))
+        pieces = [np.ascontiguousarray(t.cpu().numpy()).view(np.complex64).reshape(self.cn, -1) for t in self.hybrid_exchange(plane, bounds)]
+        return self.hybrid_tail(pieces)
+
+    def process_device_hybrid(self, x_dev, plane_dev, recv_dev, out_dev, stream=0):
+        """GPU-resident hybrid step (bench): x_dev = this rank's stripe (interleaved CF32 as float32, nf frames, state carried from the
+        rank's previous stripe), plane_dev / recv_dev = [M][nf][2] float32 scratch, out_dev = [G][M / G][nf] output elements (the G
+        stretches of the whole span, in time order).  Front end -> ONE all_to_all_single on the plane (RCCL over xGMI) -> the tail on
+        each stretch.  Equal stripes."""
+        import torch
+        G, M = self.world, self.cfg.channels
+        nf = x_dev.numel() // 2 // M
+        self.chain.process_device(x_dev.data_ptr(), M * nf, plane_dev.data_ptr(), stream)
+        if self.dist is not None and G > 1:
+            cur = torch.cuda.current_stream(plane_dev.device) if plane_dev.is_cuda else None
+            if cur is not None and int(stream or 0) != int(cur.cuda_stream):
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.ExternalStream(int(stream or 0), device=plane_dev.device))
+                cur.wait_event(ev)
+            if plane_dev.is_cuda and self.dist.get_backend(self.group) != "nccl":
+                # (test harness: several ranks on one GPU over gloo -- the exchange goes through host memory)
+                cur.synchronize()
+                hp = plane_dev.cpu(); hr = torch.empty_like(hp)
+                self.dist.all_to_all_single(hr, hp, group=self.group)
+                recv_dev.copy_(hr)
+            else:
+                self.dist.all_to_all_single(recv_dev, plane_dev, group=self.group)
+            if cur is not None and int(stream or 0) != int(cur.cuda_stream):
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                torch.cuda.ExternalStream(int(stream or 0), device=plane_dev.device).wait_event(ev)
+        else:
+            recv_dev = plane_dev
+        per = self.cn * nf * 2                                         # float32 elements of one stretch
+        w = 1 if self.cfg.demod == "fm" else 2
+        for k in range(G):
+            self.tail.process_device(recv_dev.data_ptr() + 4 * per * k, self.cn * nf, out_dev.data_ptr() + 4 * self.cn * nf * w * k, stream)
+        return G * self.cn * nf
 
     # ------------------------------------------------------------------ time stripes
     def process_stream(self, x):
         """x: the WHOLE stream (host array of nf*M CF32).  Returns this rank's output:
         time mode -> [C][t1-t0] (or [t1-t0] mixed) for its stripe; channel mode -> [cn][nf]."""
+        if self.mode == "hybrid":
+            return self.process_stream_hybrid(x)
         M = self.cfg.channels
         x = np.ascontiguousarray(x, dtype=np.complex64)
         nf = x.size // M

@@ -73,6 +73,14 @@ extern "C" {
                                      * between two timed launches, so it is a per-kernel figure only for one-kernel steps.  Per-launch
                                      * event pairs (CSDR_FLAG_TIME_KERNELS alone) cost the stream 10-20 us per launch.           */
 
+#define CSDR_FLAG_TAIL_ONLY 64u     /* the handle is the per-channel TAIL of the chain alone: `automaticGainControl` (with the mute
+                                     * rule) [-> `fmDemodulator kf`] [-> `mix`] on `channels` independent rows (Trans.hs:124-129 `mux`,
+                                     * SoapySDR.hs:249).  process(): in = a channel-major CF32 plane [channels][nf] (n_in = channels *
+                                     * nf samples: what a DeNo chain writes), out = [channels][nf] CF32 / F32 ([nf] with mix).  For the
+                                     * hybrid multi-GPU partition: DC blocker, pre-mix, FIR and DFT run time-sharded, one
+                                     * all-to-all turns time stripes into channel shards, every rank runs this tail on its channels for
+                                     * the whole time span.  Needs agc_threshold_db != 0; dc_block, chan_*, pfb_* are ignored.         */
+
 const char *csdr_last_error(void);
 int  csdr_device_count(void);
 /* library / build identification: "csdr-hip gfx950 <version>" */

@@ -36,6 +36,71 @@ class OracleChain:
         return y
 
 
+class OracleTail:
+    """the CSDR_FLAG_TAIL_ONLY handle's process() surface on top of oracle_lib: one Agc [+ FreqDem] per row, streaming-stateful"""
+
+    def __init__(self, cfg):
+        import oracle_lib as O
+        assert cfg.tail_only and cfg.agc != 0.0
+        self.C, self.fm = cfg.channels, cfg.demod == "fm"
+        self.agc = [O.Agc(cfg.agc) for _ in range(self.C)]
+        self.dem = [O.FreqDem(cfg.kf) for _ in range(self.C)] if self.fm else None
+
+    def process(self, plane):
+        z = np.ascontiguousarray(plane, dtype=np.complex64).reshape(self.C, -1)
+        y = [self.agc[k].execute_block(z[k]) for k in range(self.C)]
+        if self.fm:
+            y = [self.dem[k].demodulate_block(y[k]) for k in range(self.C)]
+        return np.stack(y) if z.shape[1] else np.empty((self.C, 0), dtype=np.float32 if self.fm else np.complex64)
+
+
+def _worker_hybrid(rank, world, port, q, demod, nf):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle_lib as O
+        from composable_sdr_amd.pipes import ChainConfig
+        from composable_sdr_amd.sharded import ShardedChain
+        from synth import synth_cf32
+        M = 16
+        x = synth_cf32(M * nf, M, seed=43)
+        cfg = ChainConfig(channels=M, demod=demod, kf=0.3, agc=3.0, max_frames=1024)
+        sc = ShardedChain(cfg, mode="hybrid", chain_factory=OracleChain, tail_factory=OracleTail)
+        full = sc.gather(sc.process_stream(x))
+        if rank == 0:
+            q.put((full, O.Chain(M, demod=demod, kf=0.3, agc_db=3.0).process(x)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("demod,nf", [("fm", 6000), ("none", 6016)])
+def test_hybrid_time_front_alltoall_channel_tail_world2(demod, nf):
+    """linear front end on time stripes, one all-to-all (unequal stripes: send / receive pairs; equal: all_to_all_single),
+    AGC + squelch [+ freqdem] tail on channel blocks over the whole span -- against the single-stream oracle: same mute decisions
+    (the threshold sits >= 3 dB from every channel level), open samples to the stripe tolerance of the time partition."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hybrid, args=(r, 2, port, q, demod, nf)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full, want = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert full.shape == want.shape
+    mism = int(np.sum((full == 0) != (want == 0)))
+    op = want != 0
+    assert mism == 0 and 0.05 < op.mean() < 0.95, (mism, op.mean())
+    if demod == "fm":
+        d = np.abs((full.astype(np.float64) - want + 0.5 / 0.3) % (1 / 0.3) - 0.5 / 0.3)
+        assert np.median(d[op]) < 1e-5 and np.quantile(d, 0.999) < 5e-4
+    else:
+        assert np.max(np.abs(full - want)) < 1e-4 * np.abs(want).max()
+    # rank 0's stripe is the head of the stream and the tail is exact given its input: bit-identical there
+    assert np.array_equal(full[:, :3008], want[:, :3008])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
