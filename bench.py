@@ -478,14 +478,19 @@ def main():
         v2 = nx * reps / d2 / 1e6
         res["agc_variant"] = {"value": round(v2, 1), "unit": "MS/s", "agc_db": 10.0, "ms_per_step": round(d2 / reps * 1e3, 4),
                               "path": ch2.path, "frames_per_step": nf, "steps": reps,
-                              "strategy": "time-parallel AGC+squelch+freqdem tail: one lane per (channel, segment) with a warm-up, "
-                                          "segment boundaries verified bitwise, failing segments recomputed in parallel rounds until all hold (exact)",
+                              "strategy": "time-parallel AGC+squelch+freqdem tail on a tile-major CF32 plane: one lane per (channel, segment) with a warm-up, "
+                                          "segment boundaries verified bitwise, failing segments recomputed (up to the checkpoint where they meet the "
+                                          "speculative trajectory) in parallel rounds until all hold (exact)",
+                              "tile_major_calls": ch2.agc_tile_major_calls(),
                               "segments_checked": c1 - c0, "segments_recomputed": r1 - r0,
                               "hbm_roofline_frac_whole_step": round(v2 * 1e6 * alg_bytes_per_sample / 1e9 / HBM_PEAK_GBS, 4)}
         # the AGC step is two kernels (channelizer to channel-major CF32 scratch, then the AGC + freqdem tail): achieved
         # = algorithmic bytes of the STEP over the step time; traffic = counter bytes of both launches
-        ta, tb = traffic_of("k_run256v2<CF32>") or traffic_of("k_run256<CF32>"), traffic_of("k_agc_spec")
-        res["agc_variant"]["roofline"] = {"bound": "hbm", "kernel": "k_run256v2<CF32> + k_agc_spec (+ k_agc_fix)",
+        def traffic_tm(kernel):
+            return tj.get(f"{kernel}|M={M}|nf={nf}|tm", {}).get("hbm_bytes_per_launch")
+        ta = traffic_tm("k_run256v2<CF32>") or traffic_of("k_run256v2<CF32>") or traffic_of("k_run256<CF32>")
+        tb = traffic_of("k_agc_spec_tm") or traffic_of("k_agc_spec")
+        res["agc_variant"]["roofline"] = {"bound": "hbm", "kernel": "k_run256v2<CF32> (tile-major plane) + k_agc_spec_tm (+ k_agc_fix)",
                                           "achieved": round(nx * alg_bytes_per_sample / (d2 / reps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": round(nx * alg_bytes_per_sample / (d2 / reps) / 1e9 / HBM_PEAK_GBS, 4),
                                           "traffic": (ta + tb) if (ta and tb) else None}

@@ -89,6 +89,7 @@ SIGNATURES = {
     "csdr_chain_get_taps": (_i32, [_vp, _vp, _u32]),
     "csdr_chain_get_nco": (_i32, [_vp, _pu32, _pu32]),
     "csdr_chain_path": (C.c_char_p, [_vp]),
+    "csdr_route_table": (C.c_char_p, []),
     "csdr_chain_debug_trace": (_i32, [_vp, _vp, _u32]),
     "csdr_chain_debug_agc": (_i32, [_vp, _vp, _vp]),
     "csdr_chain_debug_agc_tile_major_calls": (_u32, [_vp]),

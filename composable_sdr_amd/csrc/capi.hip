@@ -607,6 +607,78 @@ int csdr_ampdem_destroy(csdr_ampdem *h)
 // ---------------------------------------------------------------------------
 // fused chain
 // ---------------------------------------------------------------------------
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Route table: which plan and which kernels a chain configuration gets.  csdr_chain_create selects a row through
+// route_select() and nothing else; csdr_route_table() prints the rows (README).  Per call the plan then picks
+// between its run-sized and its chunk-sized kernel by the call's frame count (the thresholds are part of the row's text).
+// ---------------------------------------------------------------------------
+namespace {
+enum RoutePlan { PLAN_FUSED256, PLAN_SMALL64, PLAN_BIG1024, PLAN_GENERIC };
+constexpr uint32_t ST1 = 1u << 1, ST2 = 1u << 2, ST4 = 1u << 4, ST8 = 1u << 8, ST_ANY = ~0u;
+struct RouteRow {
+    uint32_t M;                 // channels the row is for; 0: any count
+    uint32_t strides;           // bit g: chan_stride g accepted (bit 1: whole band or a contiguous shard)
+    RoutePlan plan;
+    const char *name, *run_sized, *other, *agc_tail;
+};
+const RouteRow ROUTES[] = {
+    {256, ST1 | ST2 | ST4 | ST8, PLAN_FUSED256, "fused-k_run256",
+     "k_run256v2<FM | CF32[, G]> (whole band: calls of >= 2048 whole tiles of 16 frames; interleaved shards G = 2, 4, 8: every whole tile); "
+     "k_run256v3 with CSDR_RUN_V3=1 (experiment, not faster); k_run256 v1 with CSDR_RUN_V1=1 or outputs >= 4 GiB",
+     "k_tile256<FM | CF32> (look-back tile kernel: chunk-sized calls and ragged ends) [+ k_shard_gather]",
+     "channelizer -> CF32 plane (tile-major for run-sized calls of whole tiles) -> k_agc_spec_tm | k_agc_spec -> k_agc_fix [-> k_mix]"},
+    {64, ST1, PLAN_SMALL64, "fused-k_run64",
+     "k_run64v2 (CF32 output, whole band, nf % 64 == 0, >= 8 tiles of 64 frames per run)", "k_run64<FM | CF32> (FM output, shards, ragged calls)",
+     "k_run64<CF32> -> k_agc_spec -> k_agc_fix [-> k_mix]"},
+    {1024, ST1 | ST2 | ST4 | ST8, PLAN_BIG1024, "fused-k_run1024",
+     "k_run1024v2<FM[, G]> (FM output, whole 4-frame tiles, run-sized); k_run1024<CF32> (CF32 output, AGC, AM)",
+     "k_run1024<FM | CF32> (short and ragged calls) [+ k_pfb1024_fixup, k_shard_gather1024]", "k_run1024<CF32> -> k_agc_spec -> k_agc_fix [-> k_mix]"},
+    {0, ST_ANY, PLAN_GENERIC, "generic",
+     "k_dc_tile -> k_pfb_fir (M = 1024, forced generic: k_pfb1024) -> k_fft_r16 | k_fft_pow2 | k_dft_direct [interleaved shard: k_fold + (M / G)-point DFT] "
+     "-> k_transpose_fm | k_mix_frames | k_transpose;  DeNo --mix over all channels: k_dc_fold + k_mixid_finish (M % 4096 == 0) | k_dc_tile + k_branch0_fir "
+     "(the sum of all bins of a frame is M x branch 0)",
+     "the same kernels (any call size)", "... -> k_transpose -> k_agc_spec -> k_agc_fix [-> k_fm] [-> k_mix]"},
+};
+const RouteRow *route_select(uint32_t M, uint32_t p, uint32_t G, uint32_t flags)
+{
+    const RouteRow *generic = &ROUTES[sizeof(ROUTES) / sizeof(ROUTES[0]) - 1];
+    if (M <= 1 || (flags & CSDR_FLAG_FORCE_GENERIC)) return generic;
+    if (G > 1 && getenv("CSDR_SHARD_GENERIC")) return generic;
+    for (const RouteRow &r : ROUTES) {
+        if (r.M != M || !(G < 32 && (r.strides >> G) & 1u)) continue;
+        const bool ok = r.plan == PLAN_FUSED256 ? fused_supported(M, p) : r.plan == PLAN_SMALL64 ? small_supported(M, p)
+                      : r.plan == PLAN_BIG1024 ? (big_supported(M, p) && !getenv("CSDR_NO_RUN1024")) : true;
+        if (ok) return &r;
+    }
+    return generic;
+}
+std::string route_table_text()
+{
+    std::string t;
+    char buf[256];
+    for (const RouteRow &r : ROUTES) {
+        std::string st;
+        if (r.strides == ST_ANY) st = "any";
+        else for (uint32_t g : {1u, 2u, 4u, 8u}) if ((r.strides >> g) & 1u) st += (st.empty() ? "" : ", ") + std::to_string(g);
+        snprintf(buf, sizeof buf, "[%s] channels = %s, chan_stride in {%s}\n", r.name, r.M ? std::to_string(r.M).c_str() : "any", st.c_str());
+        t += buf;
+        t += std::string("    run-sized calls : ") + r.run_sized + "\n    other calls     : " + r.other + "\n    AGC on          : " + r.agc_tail + "\n";
+    }
+    t += "[tail-only] CSDR_FLAG_TAIL_ONLY: channel-major CF32 plane -> k_agc_spec -> k_agc_fix [-> k_mix] (hybrid multi-GPU partition)\n";
+    return t;
+}
+}  // namespace
+
+extern "C" {
+
+const char *csdr_route_table(void)
+{
+    static const std::string text = route_table_text();
+    return text.c_str();
+}
+
 void csdr_chain_cfg_default(csdr_chain_cfg *cfg, uint32_t channels)
 {
     if (!cfg) return;
@@ -771,8 +843,8 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     // With the AGC on, the fused kernel stops at the channel-major CF32 samples and the
     // exactly-sequential per-channel AGC tail (one lane per channel) + freqdem + mix follow.
     // interleaved shards: the fused M = 256 chain takes strides 2, 4, 8 (k_run256v2<.., G>); every other shape the any-M route with a pruned DFT
-    const bool want_fused = M > 1 && !(cfg->flags & CSDR_FLAG_FORCE_GENERIC) && (G == 1 || ((fused_supported(M, h->p) || big_supported(M, h->p)) && (G == 2 || G == 4 || G == 8) && !getenv("CSDR_SHARD_GENERIC")));
-    h->use_fused = want_fused && (fused_supported(M, h->p) || small_supported(M, h->p) || (big_supported(M, h->p) && !getenv("CSDR_NO_RUN1024")));
+    const RouteRow *route = route_select(M, h->p, G, cfg->flags);          // the one place a configuration is mapped to a plan (table above)
+    h->use_fused = route->plan != PLAN_GENERIC;
     if (h->use_fused) {
         const bool agc_on = cfg->agc_threshold_db != 0.0f;
         FusedConfig fc{};
@@ -780,11 +852,11 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         fc.dc_block = cfg->dc_block != 0; fc.dc = h->dc;
         fc.fm = cfg->demod == CSDR_DEMOD_FM && !agc_on; fc.fm_ref = h->fm_ref;
         fc.mix = cfg->mix != 0 && !agc_on; fc.taps = h->taps.data(); fc.d_theta = h->d_theta;
-        if (small_supported(M, h->p)) {
+        if (route->plan == PLAN_SMALL64) {
             if ((r = small_create(fc, &h->small))) return fail(r);
             h->path = std::string("fused-") + small_name(h->small) + (agc_on ? "+agc" : "");
             h->timed_kernel = small_name(h->small);
-        } else if (big_supported(M, h->p)) {
+        } else if (route->plan == PLAN_BIG1024) {
             if ((r = big_create(fc, &h->big))) return fail(r);
             h->path = std::string("fused-") + big_name(h->big) + (G > 1 ? "+interleaved-shard" : "") + (agc_on ? "+agc" : "");
             h->timed_kernel = big_name(h->big);

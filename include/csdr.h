@@ -292,6 +292,9 @@ uint32_t csdr_chain_out_elem_size(const csdr_chain *h);            /* 8 or 4 byt
 int  csdr_chain_get_taps(const csdr_chain *h, float *taps, uint32_t n); /* first M*2m taps */
 int  csdr_chain_get_nco(const csdr_chain *h, uint32_t *theta, uint32_t *d_theta);
 const char *csdr_chain_path(const csdr_chain *h);                  /* "fused-..." | "generic" */
+/* The library's route table as text: which plan and which kernels a configuration (channels x chan_stride x output x AGC) gets,
+ * per call shape.  csdr_chain_create selects from exactly this table. */
+const char *csdr_route_table(void);
 /* CSDR_FLAG_TIME_KERNELS: accumulated duration of the dominant kernel's launches
  * since the last call (synchronises the stream).  Returns the kernel's name. */
 const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *launches);

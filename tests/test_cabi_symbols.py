@@ -60,3 +60,12 @@ def test_product_package_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle_lib" not in txt and "csdr_oracle" not in txt and "libcsdr_oracle" not in txt, (dp, f)
+
+
+def test_route_table_names_every_product_kernel_family():
+    """csdr_route_table() is what csdr_chain_create selects from: it must name the plans and the kernels DESIGN.md quotes."""
+    from composable_sdr_amd import _lib
+    t = _lib.lib().csdr_route_table().decode()
+    for name in ("fused-k_run256", "k_run256v2", "k_tile256", "fused-k_run64", "k_run64v2", "fused-k_run1024", "k_run1024v2", "generic",
+                 "k_dc_fold", "k_agc_spec_tm", "k_agc_fix", "tail-only"):
+        assert name in t, name

@@ -69,7 +69,9 @@ for k, c in vals.items():
         rd, wr = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024
         if rd + wr < (1 << 20):
             continue                                    # fix-up / init kernels
-        tj[f"{short_name(k)}|M={M}|nf={nf}"] = {
+        # the AGC configuration's channelizer launch writes its CF32 plane TILE-MAJOR (round 4): its own key
+        key = f"{short_name(k)}|M={M}|nf={nf}" + ("|tm" if ("agc" in tag and short_name(k) == "k_run256v2<CF32>") else "")
+        tj[key] = {
             "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
             "fetch_size_kib_raw": c["FETCH_SIZE"], "write_size_kib_raw": c["WRITE_SIZE"],
             "note": "median over the launches of one run; FETCH_SIZE x2 (gfx950 wide-load under-count), WRITE_SIZE as reported", "source": f"profiles/{tag}_rocprofv3_summary.txt"}

@@ -9,7 +9,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 # keep only what tools/collect_profile.py reads (gpurun copies back at most 64 MiB)
 prune() { find $OUT -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" ! -name "args.txt" -delete; find $OUT -name "*.log" -size +200k -delete; }
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-agc-variant $*"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-agc-variant --preheat-ms 100 $*"
 KRE='k_'
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
