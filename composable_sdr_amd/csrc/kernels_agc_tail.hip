@@ -682,13 +682,29 @@ __device__ __forceinline__ bool repair_segment(const TailArgs &A, uint32_t c, ui
     uint32_t t = t0;
     if (A.tm) {                                                 // tile-major: t0, t1 are multiples of 16, a block is one 128-byte line
         AgcSeg *ck = A.ckpt + ((size_t)c * A.nseg + s) * A.nck;
+        const FmRnK fk = fm_rn_consts(A.ref);
         for (; t + 16 <= t1; t += 16) {
+            // a block at a time with the speculation's own quad routines (same arithmetic, bit for bit): a repair lane is alone on
+            // its dependent chain, so what it does NOT issue (scalar freqdem, VCC selects, 4-byte stores) is what shortens it
             const float4 *src = reinterpret_cast<const float4 *>(A.Z + z_index(A, c, t));
             float4 v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = src[i];
 #pragma unroll
-            for (int i = 0; i < 8; i++) { one(make_float2(v[i].x, v[i].y), t + 2 * i); one(make_float2(v[i].z, v[i].w), t + 2 * i + 1); }
+            for (int h = 0; h < 4; h++) {
+                float2 y[4];
+                agc_gain_quad<true>(v[2 * h], v[2 * h + 1], cur, A.p, y);
+                if (FM) {
+                    const float2 rq[4] = {make_float2(cur.rx, cur.ry), y[0], y[1], y[2]};
+                    float m[4];
+                    fm_quad_rn(rq, y, fk, m);
+                    *reinterpret_cast<float4 *>((float *)A.out + rowo + t + 4 * h) = make_float4(m[0], m[1], m[2], m[3]);
+                    cur.rx = y[3].x; cur.ry = y[3].y;
+                } else {
+                    float4 *o = reinterpret_cast<float4 *>((float2 *)A.out + rowo + t + 4 * h);
+                    o[0] = make_float4(y[0].x, y[0].y, y[1].x, y[1].y); o[1] = make_float4(y[2].x, y[2].y, y[3].x, y[3].y);
+                }
+            }
             const uint32_t done = t + 16 - t0;
             if (done % TM_CK == 0u && done < A.L && t + 16 < t1) {
                 AgcSeg &rec = ck[done / TM_CK - 1u];
@@ -890,6 +906,7 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
         if (L < p->Lmin) L = p->Lmin;
         if (L > 8160u) L = 8160u;
     }
+    if (tm && L < p->Lmin) L = p->Lmin;                          // (CSDR_AGC_L_TM below the plan's bounds: the checkpoint table is sized for L >= Lmin)
     if (tm && (L % 32u)) L = (L + 31u) / 32u * 32u;
     if (!L) {
         const uint32_t gmax = p->wg_slots / p->C ? p->wg_slots / p->C : 1u;
