@@ -55,3 +55,20 @@ def test_run256v3_has_no_register_spills_and_fits_one_workgroup_per_cu(tmp_path)
     for b in blocks:
         assert int(re.search(r"SGPRs Spill: (\d+)", b).group(1)) == 0 and int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, b[:400]
         assert int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)) <= 160 * 1024
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_agc_spec_tm_keeps_its_block_registers_out_of_scratch(tmp_path):
+    """k_agc_spec_tm's gain wave holds two blocks of 16 samples in registers (software pipeline).  As reference parameters of a
+    lambda hipcc put those arrays into scratch memory (found in round 4: 256 bytes of private segment, a scratch round trip per
+    sample): the kernel must have no private segment and no spills."""
+    src = os.path.join(ROOT, "composable_sdr_amd", "csrc")
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", os.path.join(src, "kernels_agc_tail.hip"),
+                          "-o", str(tmp_path / "agc.o"), "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = [b for b in re.split(r"remark: Function Name: ", out.stderr)[1:] if "k_agc_spec_tm" in b.splitlines()[0]]
+    assert len(blocks) == 2
+    for b in blocks:
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, b[:600]
+        assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0
