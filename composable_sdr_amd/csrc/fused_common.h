@@ -376,8 +376,6 @@ struct RunArgs {
     TileArgs t;
     RunSplit split;
     PhaseK pk;                  // ref-scaled atan polynomial: uniform, so it lives in SGPRs
-    float2 *yfirst;             // [nruns][256] first Y frame of every run
-    uint32_t S;                 // nominal tiles per run (fix-up indexing uses run_first)
     uint32_t nruns;             // runs are balanced: run w covers tiles [w*nb/nruns, (w+1)*nb/nruns)
     float l2beta;               // log2(beta)
     uint32_t prio_div;          // > 0: rotate the wave priority per tile; CU slot of a run = blockIdx / prio_div

@@ -31,20 +31,12 @@
 // firpfbch_crcf_analyzer_execute + the Haskell transpose (Liquid.chs:575-589, 828-862) and
 // M x freqdem_demodulate_block (Liquid.chs:324-328).
 #include "fused_common.h"
-#ifndef CSDR_ABLATE
-#define CSDR_ABLATE 0
-#endif
-#ifndef CSDR_COLSCAN
-#define CSDR_COLSCAN 1      // k_run256: DC blocker on the column-layout registers (DPP row scans) instead of the LDS-staged run scan
-#endif
 #include <cstring>
 
 namespace csdr {
 
 namespace {
 
-#define RSTAMP(i) do { if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define LSTAMP(i) do { if (A.trace && tid == 0) A.trace[(size_t)first * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define STAMP(i) do { if (A.trace && tid == 0) A.trace[(size_t)b * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 template <bool FM>
@@ -324,343 +316,6 @@ __global__ __launch_bounds__(256) void k_tile256(TileArgs A)
 }
 
 
-// ---------------------------------------------------------------------------------------------
-// Run kernel (large chunks): one workgroup walks a RUN of consecutive tiles.  The FIR window, the
-// DC-blocker state and the freqdem r' stay in registers from tile to tile, so there is no halo
-// re-staging, no look-back and no inter-workgroup hand-off at all; the price is a read-only
-// warm-up: the DC state at the run start is the decayed sum of the WU tiles before the run's
-// halo tile (beta^(4096*6) = 4.6e-6 of |v| ~ 40 is 9e-8 of the signal after the alpha factor).
-// The first freqdem output of every run but the first is finished by k_run_fixup.
-// ---------------------------------------------------------------------------------------------
-template <bool FM>
-__global__ __launch_bounds__(256, 3) void k_run256(RunArgs RA)   // <= 168 VGPRs: 3 workgroups per CU
-{
-    const TileArgs &A = RA.t;
-    __shared__ __attribute__((aligned(16))) float2 R[LDS_F2];
-    __shared__ float2 tw_s[M256];
-    __shared__ float2 Tt[16];
-    __shared__ float2 red[4];
-    __shared__ float taps_s[P * M256];      // taps_s[n][j] = h[(255 - j) + 256 n]: 14 ds_reads off one base per tile
-
-    const int tid = threadIdx.x, j = tid;
-    const unsigned w = blockIdx.x;
-    unsigned first, last;                                                            // tiles [first, last)
-    run_range(RA.split, w, first, last);
-    tw_s[tid] = A.tw[tid];
-#pragma unroll
-    for (int n = 0; n < P; n++) taps_s[n * M256 + tid] = A.taps[(M256 - 1 - tid) + n * M256];
-    LSTAMP(11);
-    const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
-    float2 *E = R + E_OFF;
-    const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
-
-    float2 old[NB], nw[NB];
-#pragma unroll
-    for (int f = 0; f < NB; f++) old[f] = make_float2(0.f, 0.f);
-    float2 c;                                   // DC state v before the next tile (same in every lane)
-    float4 raw[8];
-
-    if (w == 0) {
-        c = A.vend_in[0];
-#pragma unroll
-        for (int f = 3; f < NB; f++) old[f] = A.yhist_in[(f - 3) * M256 + j];
-        __syncthreads();
-    } else {
-        // ---- warm-up: DC state before the halo tile (first-1) from the tiles before it ----
-        const unsigned halo = first - 1;
-        const unsigned h0 = halo > (unsigned)WU ? halo - WU : 0u;
-        float w0[8], w1[8];
-        {
-            const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
-                const int i = (slot & 7) ^ ((q >> 1) & 7);
-                const int n = 16 * q + 2 * i;                       // sample index inside the tile
-                w0[it] = exp2f((float)(4095 - n) * RA.l2beta);
-                w1[it] = exp2f((float)(4094 - n) * RA.l2beta);
-            }
-        }
-        float2 acc = make_float2(0.f, 0.f);
-        auto fold = [&](const float4 (&r)[8]) {
-            float2 p = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                p = cfma(make_float2(r[it].x, r[it].y), w0[it], p);
-                p = cfma(make_float2(r[it].z, r[it].w), w1[it], p);
-            }
-            acc = cfma(acc, A.b256[16], p);
-        };
-        unsigned t = h0;
-        if (halo - h0 == (unsigned)WU) {
-            // the usual case: two batches of three tiles, so that only two load latencies are exposed instead of six
-            float4 rb[8], rc[8];
-#pragma unroll 1
-            for (int half = 0; half < 2; half++, t += 3) {
-                tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
-                tile_load(x4 + (size_t)(t + 1) * 2048, 256, rb, tid);
-                tile_load(x4 + (size_t)(t + 2) * 2048, 256, rc, tid);
-                fold(raw); fold(rb); fold(rc);
-            }
-        }
-        for (; t < halo; t++) {
-            tile_load(x4 + (size_t)t * 2048, 256, raw, tid);
-            fold(raw);
-        }
-        float2 ch = wg_sum(acc, red, tid);                          // also orders tw_s
-        LSTAMP(12);
-        if (h0 == 0) ch = cfma(A.vend_in[0], exp2f((float)(4096u * halo) * RA.l2beta), ch);
-        // ---- halo tile: stage, scan, finish -> old[3..15]; its end state starts the run ----
-        tile_load(x4 + (size_t)halo * 2048, 256, raw, tid);
-        stage_and_scan(raw, R, E, Tt, A, tid);
-#pragma unroll
-        for (int f = 3; f < NB; f++) old[f] = R[256 * f + col_off];
-        const float kj = -A.alpha * A.bj[j & 15];
-        const float br = A.b16[tid & 15], bf = A.b256[tid >> 4];
-        float2 vb, ve;
-        frame_carries(Tt, A, tid, vb, ve);
-        E[tid] = cfma(cfma(ch, bf, vb), br, E[tid]);
-        c = cfma(ch, A.b256[16], ve);
-        __syncthreads();
-#pragma unroll
-        for (int f = 3; f < NB; f++) old[f] = cfma(E[16 * f + (j >> 4)], kj, old[f]);
-        __syncthreads();
-    }
-
-    {   // the window holds pre-mixed samples u = y * conj(nco): frame f of the previous tile has f's parity
-        const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j];
-#pragma unroll
-        for (int f = 3; f < NB; f++) old[f] = cmul(old[f], (f & 1) ? Wb : Wa);
-    }
-    LSTAMP(13);
-    const bool owned = (uint32_t)tid >= A.c0 && (uint32_t)tid < A.c0 + A.C;
-    float2 prev = (w == 0 && owned) ? A.rp_in[tid - A.c0] : make_float2(0.f, 0.f);
-    const bool vec_out = ((A.out_stride | A.out_t0) % 4u) == 0;
-    const bool st_ok = !(CSDR_ABLATE & 2) || A.nb == 0xffffffffu;   // timing experiments: no output stores
-    // line-coalesced stores: item = tid + 256 it covers piece (item & 3 | 7) of row item >> 2 (F32) / >> 3 (CF32); the
-    // element offsets of my items inside the output, and whether the row is in my channel shard
-    size_t st_off[FM ? 4 : 8];
-    unsigned st_mask = 0;
-#pragma unroll
-    for (int it = 0; it < (FM ? 4 : 8); it++) {
-        const int item = tid + 256 * it, rowk = FM ? item >> 2 : item >> 3, piece = FM ? item & 3 : item & 7;
-        const bool in = st_ok && (uint32_t)rowk >= A.c0 && (uint32_t)rowk < A.c0 + A.C;
-        st_off[it] = in ? (size_t)(rowk - A.c0) * A.out_stride + A.out_t0 + (FM ? 4 : 2) * piece : 0;
-        st_mask |= in ? 1u << it : 0u;
-    }
-    const PhaseK &pk = RA.pk;
-
-#if CSDR_COLSCAN
-    col_load(A.x + (size_t)first * 4096, nw, tid);
-#else
-    tile_load(x4 + (size_t)first * 2048, 256, raw, tid);
-#endif
-    for (unsigned b = first; b < last; b++) {
-        // every tile of a run is a full tile (the host hands ragged tails to k_tile256).
-        // keep the per-phase LDS address arithmetic inside the iteration: hoisted out of the tile
-        // loop it would pin >100 VGPRs and halve the occupancy
-        if (RA.prio_div) {
-            // the CU issues oldest-wave-first, so the 3 co-resident runs would finish 45 us apart and leave the
-            // CU under-filled at the end; rotating s_setprio per tile shares the issue slots evenly
-            const unsigned pr = (b - first + w / RA.prio_div) % 3u;
-            if (pr == 0) __builtin_amdgcn_s_setprio(0);
-            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(2);
-        }
-        int tid_i = tid;
-        asm volatile("" : "+v"(tid_i));
-        const int j_i = tid_i;
-        const int col_off_i = 16 * (j_i >> 4) + 2 * (((j_i & 15) >> 1) ^ (j_i >> 5)) + (j_i & 1);
-        if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b * 16 + 9] = __builtin_amdgcn_s_memrealtime();
-        RSTAMP(0);
-#if CSDR_COLSCAN
-        // ---- DC blocker, zero-state part, straight on the column-layout registers (no LDS staging): in-run scans by
-        // DPP, run totals through 2 KiB of LDS, then the same run / frame carries as the staged version ----
-        (void)col_off_i;
-        col_run_scan(nw, R, A, tid_i);
-        __syncthreads();
-        col_run_carries(R, E, Tt, A, tid_i);
-        __syncthreads();
-        RSTAMP(1);
-#else
-        // ---- stage + scan this tile, prefetch the next one ----
-        stage_and_scan(raw, R, E, Tt, A, tid_i);
-#if !(CSDR_ABLATE & 1) && defined(CSDR_EARLY_LOAD)
-        if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, 256, raw, tid_i);
-#endif
-        RSTAMP(1);
-#pragma unroll
-        for (int f = 0; f < NB; f++) nw[f] = R[256 * f + col_off_i];
-#endif
-        const float kj = -A.alpha * A.bj[j_i & 15];
-        const float br = A.b16[tid_i & 15], bf = A.b256[tid_i >> 4];
-        float2 vb, ve;
-        frame_carries(Tt, A, tid_i, vb, ve);
-        E[tid_i] = cfma(cfma(c, bf, vb), br, E[tid_i]);
-        c = cfma(c, A.b256[16], ve);
-        __syncthreads();
-        RSTAMP(2);
-        // ---- finish the DC blocker and apply the NCO pre-mix (nco_crcf_mix_block_down) ----
-        {
-            const float2 Wa = A.wpre[(A.parity0 & 1) * M256 + j_i], Wb = A.wpre[((A.parity0 & 1) ^ 1) * M256 + j_i];
-#pragma unroll
-            for (int f = 0; f < NB; f++) nw[f] = cfma(E[16 * f + (j_i >> 4)], kj, nw[f]);
-            if (b + 1 == A.nb) {                                    // the stream's last 13 frames of y
-#pragma unroll
-                for (int f = 3; f < NB; f++) A.yhist_out[(f - 3) * M256 + j_i] = nw[f];
-            }
-            const v2f Wav = to_v(Wa), Wbv = to_v(Wb);
-#pragma unroll
-            for (int f = 0; f < NB; f += 2) {
-                v2f a0 = to_v(nw[f]), a1 = to_v(nw[f + 1]);
-                cmul2_v(a0, Wav, a1, Wbv);
-                nw[f] = to_f2(a0); nw[f + 1] = to_f2(a1);
-            }
-        }
-        __syncthreads();                                            // P consumed, R free
-        RSTAMP(3);
-
-        // ---- polyphase FIR on the pre-mixed window, oldest tap first ----
-        {
-            float h[P];
-#pragma unroll
-            for (int n = 0; n < P; n++) h[n] = taps_s[n * M256 + j_i];
-#pragma unroll
-            for (int f0 = 0; f0 < NB; f0 += 4) {
-                // four frames at a time: consecutive FMAs are independent (a dependent packed chain costs a
-                // wait state per tap)
-                v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-                for (int n = ((CSDR_ABLATE & 4) ? 0 : P - 1); n >= 0; n--) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int i = f0 + q - n;
-                        const float2 s2 = (i >= 0) ? nw[i] : old[NB + i];
-                        const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
-                        acc[q] = __builtin_elementwise_fma(sv, hv, acc[q]);
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) R[(f0 + q) * FS_X + j_i] = make_float2(acc[q].x, acc[q].y);
-            }
-        }
-#pragma unroll
-        for (int f = 3; f < NB; f++) old[f] = nw[f];                // next tile's window
-        __syncthreads();                                            // X complete
-        RSTAMP(4);
-#if CSDR_COLSCAN
-#if !(CSDR_ABLATE & 1)
-        if (b + 1 < last) col_load(A.x + (size_t)(b + 1) * 4096, nw, tid_i);      // straight into the (dead) window registers
-#endif
-#elif !(CSDR_ABLATE & 1) && !defined(CSDR_EARLY_LOAD)
-        if (b + 1 < last) tile_load(x4 + (size_t)(b + 1) * 2048, 256, raw, tid_i);
-#endif
-
-        v2f vv[16];
-        {
-            const int f = tid_i >> 4, b1 = tid_i & 15;
-#pragma unroll
-            for (int a = 0; a < 16; a++) vv[a] = to_v(R[f * FS_X + 16 * a + b1]);
-            fft16_v(vv);
-#pragma unroll
-            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw_s[16 * XIDX(i) + b1]));
-#if !(CSDR_ABLATE & 8)
-            __syncthreads();                                        // everyone has read X
-#pragma unroll
-            for (int i = 0; i < 16; i++) R[f * FS_Z + XIDX(i) * RS_Z + b1] = to_f2(vv[i]);
-#endif
-        }
-#if !(CSDR_ABLATE & 8)
-        __syncthreads();                                            // Z complete
-#endif
-        RSTAMP(5);
-        {
-            const int f = tid_i >> 4, k1 = tid_i & 15;
-#if !(CSDR_ABLATE & 8)
-#pragma unroll
-            for (int b1 = 0; b1 < 16; b1++) vv[b1] = to_v(R[f * FS_Z + k1 * RS_Z + b1]);
-#endif
-            fft16_v(vv);
-            __syncthreads();                                        // everyone has read Z
-#pragma unroll
-            for (int i = 0; i < 16; i++) R[(k1 + 16 * XIDX(i)) * RS_Y + f] = to_f2(vv[i]);
-        }
-        __syncthreads();                                            // Y complete
-        RSTAMP(6);
-
-        // ---- tail: thread k owns channel k ----
-        float2 v[16];
-#pragma unroll
-        for (int f = 0; f < NB; f++) v[f] = R[tid_i * RS_Y + f];
-        const size_t row = (size_t)(owned ? tid_i - A.c0 : 0) * A.out_stride + A.out_t0 + (size_t)16 * b;
-        if (FM) {
-            if (b == first && w > 0) RA.yfirst[(size_t)w * M256 + tid_i] = v[0];
-            float m[NB];
-            freqdem16(v, prev, pk, m);
-            prev = v[NB - 1];
-            if (vec_out) {
-                // transpose the 16 demodulated samples per channel through LDS so that 4 consecutive lanes
-                // write the 4 x 16-byte pieces of one channel row (a wave instruction = 16 x 64 B segments)
-                __syncthreads();                                    // Y consumed by everyone
-                float4 *M4 = reinterpret_cast<float4 *>(R);
-#pragma unroll
-                for (int q = 0; q < 4; q++) M4[tid_i * 5 + q] = make_float4(m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
-                __syncthreads();
-                float *obase = (float *)A.out + (size_t)16 * b;
-#pragma unroll
-                for (int it = 0; it < 4; it++) {
-                    const int item = tid_i + 256 * it, rowk = item >> 2, piece = item & 3;
-                    if (st_mask & (1u << it)) *reinterpret_cast<float4 *>(obase + st_off[it]) = M4[rowk * 5 + piece];
-                }
-            } else if (owned) {
-                float *o = (float *)A.out + row;
-#pragma unroll
-                for (int f = 0; f < NB; f++) o[f] = m[f];
-            }
-        } else if (vec_out) {
-            // CF32 rows leave as whole 128-byte lines: 8 consecutive lanes write the 8 x 16-byte pieces of
-            // one channel row (a wave instruction = 8 full lines), instead of 64 lanes x 16 B of 64 rows
-            float2 *obase = (float2 *)A.out + (size_t)16 * b;
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                const int item = tid_i + 256 * it, rowk = item >> 3, piece = item & 7;
-                const float2 a0 = R[rowk * RS_Y + 2 * piece], a1 = R[rowk * RS_Y + 2 * piece + 1];
-                if (st_mask & (1u << it)) *reinterpret_cast<float4 *>(obase + st_off[it]) = make_float4(a0.x, a0.y, a1.x, a1.y);
-            }
-        } else if (owned) {
-            float2 *o = (float2 *)A.out + row;
-#pragma unroll
-            for (int f = 0; f < NB; f++) o[f] = v[f];
-        }
-        RSTAMP(7);
-        __syncthreads();                                            // Y consumed, R free
-        RSTAMP(8);
-        if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b * 16 + 10] = __builtin_amdgcn_s_memrealtime();
-    }
-    LSTAMP(14);
-    // ---- stream state after the run that ends the launch ----
-    if (FM) reinterpret_cast<float2 *>(A.ylast)[(size_t)w * M256 + tid] = prev;
-    if (last == A.nb) {
-        if (tid == 0) A.vend_out[0] = c;
-        if (FM && owned) A.rp_out[tid - A.c0] = prev;
-    }
-}
-
-// first freqdem sample of every run w >= 1: needs the last frame of run w-1
-__global__ __launch_bounds__(256) void k_run_fixup(const float2 *__restrict__ yfirst, const float2 *__restrict__ ylast,
-                                                   float *__restrict__ out, uint32_t nf, RunSplit split, uint32_t c0,
-                                                   uint32_t C, float ref)
-{
-    const uint32_t k = threadIdx.x, w = blockIdx.x + 1;
-    if (k < c0 || k >= c0 + C) return;
-    const float2 r = yfirst[(size_t)w * M256 + k], rp = ylast[(size_t)(w - 1) * M256 + k];
-    const float re = __fadd_rn(__fmul_rn(rp.x, r.x), __fmul_rn(rp.y, r.y));
-    const float im = __fsub_rn(__fmul_rn(rp.x, r.y), __fmul_rn(rp.y, r.x));
-    uint32_t first, last;
-    run_range(split, w, first, last);
-    out[(size_t)(k - c0) * nf + (size_t)16 * first] = fast_atan2f(im, re) * ref;
-}
-
 }  // namespace
 
 // Split nb tiles into nruns runs.  With one run per resident workgroup slot (nruns = slots x cus) slot k's runs
@@ -720,13 +375,10 @@ struct FusedPlan {
     u64 *d_agg = nullptr, *d_ylast = nullptr;
     void *d_premix = nullptr;    // per-channel output before mixing
     u64 *d_trace = nullptr;
-    float2 *d_yfirst = nullptr;
     uint32_t run_min_tiles = 2048;   // chunks with at least this many tiles use the run kernel (measured crossover)
     uint32_t cus = 256;
     float slot_weight[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // tile share of the k-th co-resident run of a CU
-    uint32_t resident_wgs = 512;     // workgroups of k_run256 the device holds at once
     uint32_t resident_wgs_v2 = 512;  // workgroups of k_run256v2 the device holds at once
-    bool use_v2 = true;              // CSDR_RUN_V1=1: first-generation run kernel (A/B)
     bool use_v3 = false;             // CSDR_RUN_V3=1: k_run256v3 (one 512-thread workgroup per CU, front / back wave roles) for whole-band calls
     // independent launches (csdr_chain_submit_device): the last WU + 1 raw tiles of the previous chunk, three slots (the launch
     // two calls back may still be reading its slot when this call's copy is queued on the other stream)
@@ -763,7 +415,6 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     ALLOC(p->d_yflag, sizeof(unsigned) * p->max_nb);
     ALLOC(p->d_agg, sizeof(u64) * 2 * p->max_nb);
     ALLOC(p->d_ylast, sizeof(u64) * (size_t)cfg.M * p->max_nb);
-    ALLOC(p->d_yfirst, sizeof(float2) * (size_t)cfg.M * (p->max_nb / 8 + 2));   // S >= 8 tiles per run
     if (const char *e = getenv("CSDR_RUN_MIN_TILES")) p->run_min_tiles = (uint32_t)atol(e);
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
     if (getenv("CSDR_TRACE")) { ALLOC(p->d_trace, sizeof(u64) * 16 * p->max_nb); CSDR_HIP(hipMemset(p->d_trace, 0, sizeof(u64) * 16 * p->max_nb)); }
@@ -801,17 +452,12 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     for (int k = 0; k < 17; k++) A.b256[k] = (float)std::pow(beta, 256.0 * k);
     for (int k = 0; k < 16; k++) A.bj[k] = (float)std::pow(beta, (double)k);
     {
-        int dev = 0, cus = 256, occ = 2;
+        int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (cfg.fm) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run256<true>, 256, 0);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_run256<false>, 256, 0);
-        if (occ < 1) occ = 1;
-        p->resident_wgs = (uint32_t)(cus * occ);
         p->cus = (uint32_t)cus;
         p->resident_wgs_v2 = (uint32_t)(cus * run256_v2_blocks_per_cu(cfg.fm));
-        if (const char *e = getenv("CSDR_RESIDENT_WGS")) p->resident_wgs = p->resident_wgs_v2 = (uint32_t)atol(e);
-        if (const char *e = getenv("CSDR_RUN_V1")) p->use_v2 = atoi(e) == 0;
+        if (const char *e = getenv("CSDR_RESIDENT_WGS")) p->resident_wgs_v2 = (uint32_t)atol(e);
         if (const char *e = getenv("CSDR_RUN_V3")) p->use_v3 = atoi(e) != 0;
         if (const char *e = getenv("CSDR_RUN_WEIGHTS")) {
             int k = 0;
@@ -841,7 +487,7 @@ bool fused_tail_recorded(const FusedPlan *p) { return p->keep_tail && p->tail_va
 static bool fused_v2_call(const FusedPlan *p, uint32_t nf)
 {
     const FusedConfig &c = p->cfg;
-    return p->use_v2 && c.G == 1 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32) && nf / NB >= p->run_min_tiles;
+    return c.G == 1 && c.c0 == 0 && c.C == c.M && nf / NB >= p->run_min_tiles;
 }
 
 bool fused_tile_major_ok(const FusedPlan *p, uint32_t nf)
@@ -850,9 +496,8 @@ bool fused_tile_major_ok(const FusedPlan *p, uint32_t nf)
     const FusedConfig &c = p->cfg;
     const bool shard = c.G > 1;
     if (c.fm || c.mix || nf % NB || !nf) return false;
-    if ((uint64_t)c.C * nf * 8u >= (1ull << 32)) return false;
-    if (shard) return true;
-    return p->use_v2 && c.c0 == 0 && c.C == c.M && nf / NB >= p->run_min_tiles;
+    if (shard) return (uint64_t)c.C * nf * 8u < (1ull << 32);
+    return c.c0 == 0 && c.C == c.M && nf / NB >= p->run_min_tiles;
 }
 
 bool fused_can_overlap(const FusedPlan *p, uint32_t nf)
@@ -881,25 +526,26 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     const uint32_t nb_full = nf / NB;
     const bool shard = c.G > 1;      // interleaved shard: every whole tile goes through k_run256v2<.., G> (the tile kernel only knows whole bands)
     if (shard && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) >= (1ull << 32)) { set_error("fused: interleaved shard output of %u frames exceeds 4 GiB", nf); return -1; }
-    if (nb_full >= p->run_min_tiles || shard) {
-        // large chunk: dependency-free runs of S full tiles; a ragged tail (< 16 frames) follows as
-        // a second launch of the tile kernel on the state the run kernel leaves behind
-        // whole-band calls whose output fits 32-bit byte offsets take the second-generation kernel
-        const bool v2 = shard || (p->use_v2 && c.c0 == 0 && c.C == c.M && (uint64_t)c.C * nf * (c.fm ? 4u : 8u) < (1ull << 32));
+    const bool whole_band = c.G == 1 && c.c0 == 0 && c.C == c.M;      // (a contiguous channel shard takes the tile kernel, which masks its stores, at every size)
+    if ((nb_full >= p->run_min_tiles && whole_band) || shard) {
+        // large chunk: dependency-free runs of full tiles (k_run256v2; its lane offsets are 32-bit over 16 rows and the row groups
+        // go through a 64-bit base, so the output may exceed 4 GiB); a ragged tail (< 16 frames) follows as a second launch of the
+        // tile kernel on the state the run kernel leaves behind
+        const bool v2 = true;
         // third generation: one 512-thread workgroup per CU (half the cold starts), whole band
-        const bool v3 = v2 && !shard && p->use_v3;
-        p->name = v3 ? (c.fm ? "k_run256v3<FM>" : "k_run256v3<CF32>") : (v2 ? (c.fm ? "k_run256v2<FM>" : "k_run256v2<CF32>") : (c.fm ? "k_run256<FM>" : "k_run256<CF32>"));
+        const bool v3 = !shard && p->use_v3;
+        p->name = v3 ? (c.fm ? "k_run256v3<FM>" : "k_run256v3<CF32>") : (c.fm ? "k_run256v2<FM>" : "k_run256v2<CF32>");
         if (shard) p->name += "/G" + std::to_string(c.G);
         RunArgs RA{};
         A.nf = nb_full * NB; A.nb = nb_full;
-        RA.t = A; RA.yfirst = p->d_yfirst; RA.pk = phase_consts(c.fm_ref);
+        RA.t = A; RA.pk = phase_consts(c.fm_ref);
         // one run per resident workgroup slot (a single round), runs balanced to within one tile,
         // at least 8 tiles per run so that the warm-up reads stay below 7/8 of a run
-        uint32_t nruns = v3 ? p->cus : (v2 ? p->resident_wgs_v2 : p->resident_wgs);
+        uint32_t nruns = v3 ? p->cus : p->resident_wgs_v2;
         if (v3) { if (const char *e = getenv("CSDR_V3_RUNS")) nruns = (uint32_t)atol(e); }
         if (nruns > A.nb / 8) nruns = A.nb / 8;
         if (nruns < 1) nruns = 1;
-        RA.nruns = nruns; RA.S = (A.nb + nruns - 1) / nruns;
+        RA.nruns = nruns;
         // k_run256v2: the older of a CU's two workgroups wins the issue arbitration and runs ~1.4x faster than the younger
         // one, so it gets the larger share of the tiles (measured: both end together at about 1.2 : 0.8); rotating the
         // priority per tile instead was no better
@@ -931,16 +577,10 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
             p->tail_w = nxt; p->tail_valid = true;
         } else p->tail_valid = false;
         if (timer && (r = timer->begin(s))) return r;
-        static const size_t extra_lds = getenv("CSDR_EXTRA_LDS") ? (size_t)atol(getenv("CSDR_EXTRA_LDS")) : 0;   // occupancy experiments
         if (nb_full == 0) { /* shard, fewer than 16 frames: the tile kernel below does the whole call */ }
         else if (v3) { if ((r = run256_v3_launch(&RA, c.fm, nruns, s))) return r; }
-        else if (v2) { if ((r = run256_v2_launch(&RA, c.fm, c.G, nruns, s))) return r; }
-        else if (c.fm) hipLaunchKernelGGL(k_run256<true>, dim3(nruns), dim3(256), extra_lds, s, RA);
-        else hipLaunchKernelGGL(k_run256<false>, dim3(nruns), dim3(256), extra_lds, s, RA);
+        else if ((r = run256_v2_launch(&RA, c.fm, c.G, nruns, s))) return r;
         if (timer && (r = timer->end(s))) return r;
-        if (c.fm && nruns > 1 && !v2)                            // k_run256v2 computes the frame in front of a run itself
-            hipLaunchKernelGGL(k_run_fixup, dim3(nruns - 1), dim3(256), 0, s, p->d_yfirst, (const float2 *)p->d_ylast,
-                               (float *)A.out, nf, RA.split, c.c0, c.C, c.fm_ref);
         const uint32_t rem = nf - nb_full * NB;
         if (rem) {
             if (nb_full) p->cur ^= 1;                            // the tail starts from the run kernel's state
@@ -1003,7 +643,7 @@ void fused_destroy(FusedPlan *p)
 {
     if (!p) return;
     void *ptrs[] = {p->d_shard_tail, p->d_tail[0], p->d_tail[1], p->d_tail[2], p->d_taps, p->d_tw, p->d_wpre, p->d_yhist[0], p->d_yhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0],
-                    p->d_rp[1], p->d_ticket, p->d_yflag, p->d_status, p->d_agg, p->d_ylast, p->d_premix, p->d_trace, p->d_yfirst};
+                    p->d_rp[1], p->d_ticket, p->d_yflag, p->d_status, p->d_agg, p->d_ylast, p->d_premix, p->d_trace};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }

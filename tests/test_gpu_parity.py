@@ -460,6 +460,58 @@ def test_fused256_no_dc_block_and_shard():
     assert np.array_equal(part, full[100:156])
 
 
+def test_fused256_output_beyond_4gib_and_contiguous_shard_at_run_size():
+    """(1) k_run256v2 addresses its output with 32-bit lane offsets over 16 rows and a 64-bit base per row group, so a call whose
+    [256][nf] CF32 output exceeds 4 GiB (nf > 2 097 152) stays on the run kernel: one 2 101 248-frame call against the same stream in
+    two calls (state carried), rows compared at the far end of the buffer too.  (2) a contiguous channel shard (chan_first /
+    chan_count) takes the look-back tile kernel at every size: run-sized call against the rows of the whole band."""
+    import torch
+    from composable_sdr_amd import _lib
+    from synth import synth_cf32_torch
+    M = 256
+    dev = torch.device("cuda", 0)
+    nf = 2097152 + 4096
+    half = 1048576
+    parts = [synth_cf32_torch(M * half, M, dev, seed=900 + i) for i in range(2)] + [synth_cf32_torch(M * 4096, M, dev, seed=902)]
+    x = torch.cat([p.view(-1) for p in parts]); del parts
+    assert x.numel() == 2 * M * nf
+    out1 = torch.empty(M * nf * 2, dtype=torch.float32, device=dev)           # 4.3 GB
+    a = cs.Chain(channels=M, max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
+    a.process_device(x.data_ptr(), M * nf, out1.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert a.kernel_time()[0] == "k_run256v2<CF32>"
+    a.close()
+    b = cs.Chain(channels=M, max_frames=half + 4096)
+    o2a = torch.empty(M * half * 2, dtype=torch.float32, device=dev)
+    o2b = torch.empty(M * (nf - half) * 2, dtype=torch.float32, device=dev)
+    b.process_device(x.data_ptr(), M * half, o2a.data_ptr(), 0)
+    b.process_device(x.data_ptr() + M * half * 8, M * (nf - half), o2b.data_ptr(), 0)
+    torch.cuda.synchronize()
+    b.close()
+    v1 = out1.view(M, nf, 2)
+    for rows in (slice(0, 4), slice(126, 130), slice(252, 256)):
+        ref = torch.cat([o2a.view(M, half, 2)[rows], o2b.view(M, nf - half, 2)[rows]], dim=1)
+        got = v1[rows]
+        e = float((got - ref).pow(2).sum().sqrt() / ref.pow(2).sum().sqrt())
+        print(f"> 4 GiB output, rows {rows.start}..{rows.stop - 1}: one call vs two calls rel-rms {e:.2e}")
+        assert e < 2e-6
+    del out1, o2a, o2b, v1
+    torch.cuda.empty_cache()
+    # (2)
+    nf2 = 40000
+    xs = x[: 2 * M * nf2].view(torch.float32).cpu().numpy().view(np.complex64).reshape(-1)
+    del x
+    torch.cuda.empty_cache()
+    full = cs.Chain(channels=M, demod="fm", max_frames=nf2).process(xs)
+    sh = cs.Chain(channels=M, demod="fm", chan_first=64, chan_count=96, max_frames=nf2, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
+    part = sh.process(xs)
+    assert sh.kernel_time()[0] == "k_tile256<FM>" and part.shape == (96, nf2)
+    sh.close()
+    d = np.abs(wrap_pm(part.astype(np.float64) - full[64:160], 1.0 / 0.3))
+    print(f"contiguous shard at run size (tile kernel) vs whole band (run kernel): FM median {np.median(d):.2e}, tone-channel max {d[1::4].max():.2e}")
+    assert np.median(d) < 5e-6 and d[1::4].max() < 5e-6
+
+
 def test_fused256_dc_state_matches_long_stream():
     """A strong DC offset makes the carried DC-blocker state matter: 64 chunks of 16 frames
     must equal one chunk of 1024 frames (look-back across tiles == carry across calls)."""
@@ -832,7 +884,7 @@ def test_run64_v2_matches_first_generation_kernel_and_oracle(monkeypatch):
     (64, "none", "CSDR_RUN64_V1", [8192, 2048], {}),
     (64, "none", "CSDR_RUN64_V1", [8192], {"mix": True}),
     (1024, "fm", "CSDR_RUN1024_V1", [4096], {}),
-    (256, "fm", "CSDR_RUN_V1", [40000], {}),
+    (256, "fm", "CSDR_RUN_MIN_TILES", [40000], {}),
 ])
 def test_second_generation_run_kernels_without_dc_blocker(M, demod, env, frames, extra, monkeypatch):
     """dc_block = False (alpha = 0, beta = 0 inside the kernels) and DeNo --mix through k_run64v2 / k_run1024v2 / k_run256v2
@@ -841,7 +893,7 @@ def test_second_generation_run_kernels_without_dc_blocker(M, demod, env, frames,
     x = synth_cf32(M * sum(frames), M, seed=3)
     kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames), dc_block=False, **extra)
     a = cs.Chain(**kw)
-    monkeypatch.setenv(env, "1")
+    monkeypatch.setenv(env, "1000000" if env == "CSDR_RUN_MIN_TILES" else "1")     # M = 256: the look-back tile kernel is the other implementation
     b = cs.Chain(**kw)
     monkeypatch.delenv(env)
     pos = 0
