@@ -488,7 +488,7 @@ def main():
         # = algorithmic bytes of the STEP over the step time; traffic = counter bytes of both launches
         def traffic_tm(kernel):
             return tj.get(f"{kernel}|M={M}|nf={nf}|tm", {}).get("hbm_bytes_per_launch")
-        ta = traffic_tm("k_run256v2<CF32>") or traffic_of("k_run256v2<CF32>") or traffic_of("k_run256<CF32>")
+        ta = traffic_tm("k_run256v2<CF32>") or traffic_of("k_run256v2<CF32>")
         tb = traffic_of("k_agc_spec_tm") or traffic_of("k_agc_spec")
         res["agc_variant"]["roofline"] = {"bound": "hbm", "kernel": "k_run256v2<CF32> (tile-major plane) + k_agc_spec_tm (+ k_agc_fix)",
                                           "achieved": round(nx * alg_bytes_per_sample / (d2 / reps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -624,7 +624,7 @@ struct RouteRow {
     const char *name, *run_sized, *other, *agc_tail;
 };
 const RouteRow ROUTES[] = {
-    {256, ST1 | ST2 | ST4 | ST8, PLAN_FUSED256, "fused-k_run256",
+    {256, ST1 | ST2 | ST4 | ST8, PLAN_FUSED256, "fused-256",
      "k_run256v2<FM | CF32[, G]> (whole band: calls of >= 2048 whole tiles of 16 frames; interleaved shards G = 2, 4, 8: every whole tile); "
      "k_run256v3 with CSDR_RUN_V3=1 (experiment, not faster)",
      "k_tile256<FM | CF32> (look-back tile kernel: chunk-sized calls, ragged ends, and contiguous channel shards at every size) [+ k_shard_gather]",
@@ -862,7 +862,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             h->timed_kernel = big_name(h->big);
         } else {
             if ((r = fused_create(fc, &h->fused))) return fail(r);
-            h->path = std::string("fused-k_run256|") + fused_name(h->fused) + (G > 1 ? "+interleaved-shard" : "") + (agc_on ? "+agc" : "");
+            h->path = std::string("fused-256|") + fused_name(h->fused) + (G > 1 ? "+interleaved-shard" : "") + (agc_on ? "+agc" : "");
             h->timed_kernel = fused_name(h->fused);
         }
         if (agc_on) {

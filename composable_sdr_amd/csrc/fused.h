@@ -46,7 +46,7 @@ int  fused_status(FusedPlan *plan, unsigned *status);
 int  fused_trace(FusedPlan *plan, unsigned long long *out, uint32_t ntiles);
 void fused_destroy(FusedPlan *plan);
 // second-generation run kernel of the M = 256 chain (kernels_fused_v2.hip): whole-band calls of >= run_min_tiles tiles.
-// run_args points at the RunArgs the first-generation k_run256 would have been launched with.
+// run_args points at a RunArgs (fused_common.h) the plan fills.
 int  run256_v2_launch(const void *run_args, bool fm, unsigned G, unsigned nruns, hipStream_t s);
 int  run256_v2_blocks_per_cu(bool fm);
 // third-generation run kernel (kernels_run256_v3.hip): one 512-thread workgroup per CU, front / back wave roles; whole band
