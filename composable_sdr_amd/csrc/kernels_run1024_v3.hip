@@ -1,0 +1,451 @@
+// Third-generation run kernel of the fused M = 1024 FM chain (BASELINE configs[3] shape): ONE 512-thread workgroup per compute
+// unit, split by wave role, the output staged in REGISTERS until a row's whole 128-byte line is complete.
+//
+//   raw CF32 x --DC blocker--> y --NCO pre-mix, 14-tap polyphase FIR--> X_t[j] --1024-point forward DFT (16 x 16 x 4)--> Y_t[k]
+//              --per-channel freqdem--> out[1024][nf] F32           (8 B read + 4 B written per sample, Liquid.chs:575-589,
+//                                                                     828-862, 324-328)
+//
+// Why (verdict r03 #4).  A 4-frame tile holds 16 bytes of each of the 1024 F32 rows; a whole 128-byte line of every row is 8
+// tiles = 128 KiB.  k_run1024v2 (two 256-thread workgroups per CU, 256 VGPRs each, 2 x 80 KiB of LDS: nothing left on chip)
+// parks those 128 KiB per workgroup in a global staging block and reads them back transposed: + 8 B per sample through the
+// L2 -> fabric counters, 1.89x the algorithmic bytes with the run-start re-reads.  Here a CU runs ONE workgroup whose waves are
+// a two-stage pipeline (the structure of k_run256v3):
+//   FRONT waves 0-3 (thread j = branches j + 256 q): tile DMA, DC blocker, pre-mix, FIR of tile t     -> X(t) in the tile's buffer
+//   BACK  waves 4-7 (wave f = frame f; thread kk):   DFT passes 1 + 2 of tile t-1, pass 3 + freqdem of tile t-2
+// The front waves carry the 13-frame window (104 VGPRs) and, now that the DFT is not theirs, the 56 taps + phasors of their four
+// branches (v2 re-reads them per tile); the back waves have no window, so the 8 tiles x 4 channels x 4 frames a thread produces
+// per block wait in 128 VGPRs.  When the block is complete a wave turns its 64 rows x 128 bytes through its own 8 KiB of the
+// tile buffer it has just consumed (its pass-3 reads cover exactly 2 KiB of each frame block: no barrier) and stores whole
+// lines, eight lanes per row.  No staging block, no read-back; runs are twice as long (one per CU), so the read-only run-start
+// tiles halve as well.  Runs start and end on 8-tile blocks (the launcher takes calls of nf = 0 mod 32 frames).
+//
+// A step has two workgroup barriers:        front                                back
+//   bar X  --------------------------------------------------------------------------------------------------
+//          DC scan of tile s (raw image -> y', group totals)               pass 3 + freqdem of tile s-2 [+ block flush]
+//   bar Y  --------------------------------------------------------------------------------------------------
+//          DMA of tile s+2; column layout, pre-mix, FIR -> X(s); window    passes 1 + 2 of tile s-1 (wave-private frame block)
+// Tile i lives in buffer i % 4 from its DMA to the back waves' pass 3.  Arithmetic: k_run1024v2's, instruction for instruction.
+#include "fused_v2_common.h"
+
+#ifndef B3_ABLATE
+#define B3_ABLATE 0      // timing experiments only: 2 no output stores, 4 no freqdem, 8 no flush transposition (stores of registers)
+#endif
+
+namespace csdr {
+namespace {
+
+constexpr int B3_M = 1024, B3_T4 = 4, B3_NBUF = 4, B3_TB = 8;
+constexpr int B3_BUF = 4096;                       // float2 per tile buffer (32 KiB)
+constexpr int B3_TW1 = B3_NBUF * B3_BUF;           // twiddles W1024^(k1 b) at [k1 - 1][b], k1 = 1..15: 960
+constexpr int B3_ST = B3_TW1 + 960;                // last Y frame of channel kk + 256 k3 at [kk][k3]: 1024 (the prologue's reduction scratch before that)
+constexpr int B3_TT = B3_ST + 1024;                // 16 group totals
+constexpr int B3_F2 = B3_TT + 16;                  // 18 384 float2 = 147 072 B: one workgroup per CU
+constexpr int B3_WU = 6, B3_HALO = 4;              // read-only warm-up tiles (DC state); 3 window-refill tiles + the muted tile in front of a run
+
+struct Run1024v3Args {
+    const float2 *x;            // raw input of this call
+    float *out;                 // [1024][nf] F32
+    const float4 *taps_q;       // k_run1024v2's table: [4 q][4 pieces][256 j] taps + even-frame phasor; behind the 64 KiB: [4 q][256 j] odd-frame phasor
+    const float2 *tw;           // e^{-j 2 pi i / 1024}
+    const float2 *uhist_in; float2 *uhist_out;    // [13][1024] pre-mixed, DC-blocked window before / after the call
+    const float2 *vend_in; float2 *vend_out;      // DC blocker state v1
+    const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r'
+    uint32_t nf, nb, nruns, parity0;
+    float alpha, beta, l2beta, fm_ref, tiny;
+    float b16[16];              // beta^(16 r)
+    float b256[17];             // beta^(256 g)
+    PhaseK pk;
+};
+
+// run w: blocks of 8 tiles, evenly
+__host__ __device__ __forceinline__ void run3_bounds(uint32_t nb, uint32_t nruns, unsigned w, unsigned &first, unsigned &last)
+{
+    const unsigned nblk = nb / B3_TB;
+    first = B3_TB * (unsigned)((unsigned long long)w * nblk / nruns);
+    last = B3_TB * (unsigned)((unsigned long long)(w + 1) * nblk / nruns);
+}
+
+__global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
+{
+    __shared__ __attribute__((aligned(16))) float2 L[B3_F2];
+    float2 *tw1 = L + B3_TW1, *ST = L + B3_ST, *Tt = L + B3_TT, *red = ST;
+    const int tid = threadIdx.x;
+    const bool back = tid >= 256;                       // wave-uniform role
+    const int lt = tid & 255, j = lt;                   // thread index inside the role; front: polyphase branches j + 256 q
+    const unsigned w = blockIdx.x;
+    unsigned first, last;
+    run3_bounds(A.nb, A.nruns, w, first, last);
+    const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
+    const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
+    const unsigned goff = dma_offset(lt);
+    const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(lt >> 6);      // wave index inside the role
+    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)L + 1024u * wave_u;
+
+    for (int e = tid; e < 960; e += 512) tw1[e] = A.tw[(((e >> 6) + 1) * (e & 63)) & 1023];
+
+    // ------------------------------------------------------------------ run start
+    // items of the run: tile tile_begin + i, i = 0 .. n_items - 1; the first nwarm only refill the window (front waves), the next
+    // one (tile first - 1) is muted: FIR and DFT for its last frame, the freqdem history of the run's first sample
+    const unsigned tile_begin = w == 0 ? first : first - B3_HALO;
+    const unsigned nwarm = w == 0 ? 0u : (unsigned)(B3_HALO - 1);
+    const unsigned n_items = last - tile_begin;
+    if (!back) {                                        // the first two tile images: requested before anything else
+        dma_tile(x4 + (size_t)tile_begin * 2048, goff, lds_wave);
+        if (n_items > 1) dma_tile(x4 + (size_t)(tile_begin + 1) * 2048, goff, lds_wave + (unsigned)(B3_BUF * 8u));
+    }
+    float2 c = make_float2(0.f, 0.f);                   // DC state v before the next tile (same in every lane)
+    {
+        float2 acc = make_float2(0.f, 0.f);
+        if (w > 0 && !back) {
+            // read-only warm-up (as k_run1024v2): the DC state before tile_begin from the six tiles in front of it, one batch of loads
+            const unsigned h0 = tile_begin - B3_WU;
+            float4 raw[8], rb[8], rc[8], rd[8], re[8], rf[8];
+            float wt0, wt1;
+            {
+                const int wave = lt >> 6, lane = lt & 63;
+                const int slot = 64 * wave + lane, q = slot >> 3;
+                const int i = (slot & 7) ^ ((q >> 1) & 7);
+                const int n = 16 * q + 2 * i;
+                wt0 = exp2f((float)(4095 - n) * A.l2beta);
+                wt1 = exp2f((float)(4094 - n) * A.l2beta);
+            }
+            const float wstep = A.l2beta < -100.0f ? 0.0f : exp2f(-512.0f * A.l2beta);
+            auto fold = [&](const float4 (&r)[8]) {
+                float2 p = make_float2(0.f, 0.f);
+                float a0 = wt0, a1 = wt1;
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    p = cfma(make_float2(r[it].x, r[it].y), a0, p);
+                    p = cfma(make_float2(r[it].z, r[it].w), a1, p);
+                    a0 *= wstep; a1 *= wstep;
+                }
+                acc = cfma(acc, A.b256[16], p);
+            };
+            static_assert(B3_WU == 6, "one batch of six warm-up tiles");
+            tile_load(x4 + (size_t)h0 * 2048, 256, raw, lt); tile_load(x4 + (size_t)(h0 + 1) * 2048, 256, rb, lt);
+            tile_load(x4 + (size_t)(h0 + 2) * 2048, 256, rc, lt); tile_load(x4 + (size_t)(h0 + 3) * 2048, 256, rd, lt);
+            tile_load(x4 + (size_t)(h0 + 4) * 2048, 256, re, lt); tile_load(x4 + (size_t)(h0 + 5) * 2048, 256, rf, lt);
+            fold(raw); fold(rb); fold(rc); fold(rd); fold(re); fold(rf);
+        }
+        const float2 sum = wg_sum(acc, red, tid);       // red[0..3]: the front waves (the back waves park zeros in red[4..7])
+        if (w == 0) c = A.vend_in[0];
+        else {
+            c = sum;
+            if (tile_begin - B3_WU == 0) c = cfma(A.vend_in[0], exp2f((float)(4096 * B3_WU) * A.l2beta), c);
+        }
+    }
+    if (back) {                                         // freqdem history (after the reduction scratch is done with)
+#pragma unroll
+        for (int k3 = 0; k3 < 4; k3++) ST[4 * lt + k3] = (w == 0) ? A.rp_in[lt + 256 * k3] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();                                    // twiddle tables, stash
+
+    if (!back) {
+        // ================================================================== FRONT
+        float2 hist[52];                                // window: frames -13 .. -1 of my four branches, [13][4]
+        if (w == 0) {
+#pragma unroll
+            for (int i = 0; i < 52; i++) hist[i] = A.uhist_in[(i >> 2) * B3_M + 256 * (i & 3) + j];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 52; i++) hist[i] = make_float2(0.f, 0.f);
+        }
+        // taps (14) and even / odd frame pre-mix phasors of a branch: four 16-byte loads + one 8-byte load per tile out of the L2-resident
+        // table, as in k_run1024v2 (the window leaves no room for all 72 registers): branches 0 and 1 are requested at the top of the step
+        // and fly during the DC scan, 2 and 3 between the FIR passes; the DMA of tile s + 2 is issued after the last of them has been
+        // used (the waits the compiler places count vmcnt in order and would otherwise wait for the DMA as well)
+        const unsigned joff = 16u * (unsigned)j;
+        const __amdgpu_buffer_rsrc_t taps_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(A.taps_q), 0, 65536 + 8192, 0x00020000);
+        auto load_taps = [&](v4f (&t)[4], v2f &wodd, const int qq) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+                const v4u_ v = __builtin_amdgcn_raw_buffer_load_b128(taps_rsrc, (int)joff, (qq * 4 + p) * 4096, 0);
+                t[p] = __builtin_bit_cast(v4f, v);
+            }
+            typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+            const v2u_ v = __builtin_amdgcn_raw_buffer_load_b64(taps_rsrc, (int)(joff >> 1), 65536 + qq * 2048, 0);
+            wodd = __builtin_bit_cast(v2f, v);
+        };
+        const float kJ = -A.alpha * exp2f((float)j * A.l2beta);                  // -alpha beta^j: group state into column j
+        const float b256 = A.b256[1];
+        const bool odd0 = (A.parity0 & 1) != 0;
+        const int q = lt, sw = (q >> 1) & 7;
+        const unsigned raw_a = (unsigned)q * 128u + ((unsigned)sw << 4);         // slot i of my run: raw_a ^ (i << 4)
+
+        for (unsigned s = 0; s < n_items + 2; s++) {
+            const bool have = s < n_items;
+            const bool warm = s < nwarm;
+            char *B = reinterpret_cast<char *>(L) + (s & 3u) * (B3_BUF * 8u);    // item s's buffer
+            float2 *Bf = reinterpret_cast<float2 *>(B);
+            if (have) {                                 // my pieces of image s have landed (image s + 1 may still be in flight)
+                if (s + 1 < n_items) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            v4f tq0[4], tq1[4], tq2[4], tq3[4];
+            v2f wo0, wo1, wo2, wo3;
+            if (have) { load_taps(tq0, wo0, 0); load_taps(tq1, wo1, 1); }
+            bar();                                      // X
+            if (have) {
+                // ---- DC blocker inside a 256-sample group: thread q owns the run of 16 consecutive samples q (as k_run256v2)
+                const float na = opaque_v(-A.alpha), be = opaque_v(A.beta);
+                v4f xr[8];
+                float2 sc = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    xr[i] = *reinterpret_cast<const v4f *>(B + (raw_a ^ (unsigned)(i << 4)));
+                    sc = make_float2(fmaf(sc.x, be, xr[i].x), fmaf(sc.y, be, xr[i].y));
+                    sc = make_float2(fmaf(sc.x, be, xr[i].z), fmaf(sc.y, be, xr[i].w));
+                }
+                {
+                    float2 t;
+                    t = dpp2<0x111>(sc); sc = cfma(t, A.b16[1], sc);
+                    t = dpp2<0x112>(sc); sc = cfma(t, A.b16[2], sc);
+                    t = dpp2<0x114>(sc); sc = cfma(t, A.b16[4], sc);
+                    t = dpp2<0x118>(sc); sc = cfma(t, A.b16[8], sc);
+                }
+                if ((q & 15) == 15) Tt[q >> 4] = sc;
+                sc = dpp2<0x111>(sc);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    v4f y;
+                    y.x = fmaf(sc.x, na, xr[i].x); y.y = fmaf(sc.y, na, xr[i].y);
+                    sc = make_float2(fmaf(sc.x, be, xr[i].x), fmaf(sc.y, be, xr[i].y));
+                    y.z = fmaf(sc.x, na, xr[i].z); y.w = fmaf(sc.y, na, xr[i].w);
+                    sc = make_float2(fmaf(sc.x, be, xr[i].z), fmaf(sc.y, be, xr[i].w));
+                    *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = y;
+                }
+            }
+            bar();                                      // Y: y' (group carry still missing) and the group totals are visible; buffer (s + 2) % 4 is free
+            if (!have) continue;
+            // ---- column layout: nw[4 f + qq] = sample of frame f, branch j + 256 qq; group state chain V[g] (uniform)
+            float2 nw[16];
+            {
+                v2f V = {c.x, c.y};
+                const v2f kJv = {kJ, kJ}, bv = {b256, b256};
+#pragma unroll
+                for (int f = 0; f < 4; f++) {
+                    const v4f t01 = *reinterpret_cast<const v4f *>(Tt + 4 * f), t23 = *reinterpret_cast<const v4f *>(Tt + 4 * f + 2);
+                    const v2f tg[4] = {{t01.x, t01.y}, {t01.z, t01.w}, {t23.x, t23.y}, {t23.z, t23.w}};
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        const int g = 4 * f + qq;
+                        nw[g] = to_f2(__builtin_elementwise_fma(V, kJv, to_v(Bf[256 * g + col_off])));
+                        V = __builtin_elementwise_fma(V, bv, tg[qq]);
+                    }
+                }
+                c = make_float2(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(V.x))), __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(V.y))));
+            }
+            // pre-mix, then the polyphase FIR on the pre-mixed window: one branch at a time, four accumulators = its four frames
+            auto branch = [&](const v4f (&t)[4], const v2f wodd, const int qq) {
+                const v2f we = {t[3].z, t[3].w};
+                const v2f Wa = odd0 ? wodd : we, Wb = odd0 ? we : wodd;
+#pragma unroll
+                for (int f = 0; f < 4; f += 2) {
+                    v2f a0 = to_v(nw[4 * f + qq]), a1 = to_v(nw[4 * (f + 1) + qq]);
+                    cmul2_v(a0, Wa, a1, Wb);
+                    nw[4 * f + qq] = to_f2(a0); nw[4 * (f + 1) + qq] = to_f2(a1);
+                }
+                if (warm) return;
+                const float h[16] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w, t[2].x, t[2].y, t[2].z, t[2].w, t[3].x, t[3].y, 0.f, 0.f};
+                v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+                for (int n = P - 1; n >= 0; n--) {
+#pragma unroll
+                    for (int f = 0; f < 4; f++) {
+                        const int i = f - n;
+                        const float2 s2 = (i >= 0) ? nw[4 * i + qq] : hist[4 * (13 + i) + qq];
+                        const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
+                        acc[f] = __builtin_elementwise_fma(sv, hv, acc[f]);
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < 4; f++) Bf[256 * (4 * f + qq) + col_off] = to_f2(acc[f]);
+            };
+            branch(tq0, wo0, 0);
+            asm volatile("" ::: "memory");
+            load_taps(tq2, wo2, 2);
+            asm volatile("" ::: "memory");
+            branch(tq1, wo1, 1);
+            asm volatile("" ::: "memory");
+            load_taps(tq3, wo3, 3);
+            asm volatile("" ::: "memory");
+            branch(tq2, wo2, 2);
+            branch(tq3, wo3, 3);
+            asm volatile("" ::: "memory");
+            if (s + 2 < n_items) dma_tile(x4 + (size_t)(tile_begin + s + 2) * 2048, goff, lds_wave + ((s + 2u) & 3u) * (B3_BUF * 8u));
+            // the window moves on by four frames
+#pragma unroll
+            for (int i = 0; i < 36; i++) hist[i] = hist[i + 16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) hist[36 + i] = nw[i];
+        }
+        if (last == A.nb) {
+            if (lt == 0) A.vend_out[0] = c;
+#pragma unroll
+            for (int i = 0; i < 52; i++) A.uhist_out[(i >> 2) * B3_M + 256 * (i & 3) + j] = hist[i];
+        }
+        return;
+    }
+
+    // ====================================================================== BACK
+    const FmK2 fk = {{A.pk.c[0], A.pk.c[1], A.pk.c[2], A.pk.c[3], A.pk.c[4], A.pk.c[5], A.pk.c[6], A.pk.c[7]}, A.tiny, A.fm_ref, A.pk.hp, A.pk.pi};
+    const unsigned fb = 8192u * wave_u;                                         // passes 1-2: my wave's frame block
+    const int b1 = lt & 63;                                                     // pass 1: n = 64 a + b1
+    // X[f][64 a + b1] sits at fb + 512 a + (x_a ^ ((a & 3) << 5))  (column layout of the raw image, see col_off)
+    const unsigned x_a = 8u * (unsigned)((16 * (b1 >> 4)) | (b1 & 1) | (2 * ((((b1 & 15) >> 1) ^ (b1 >> 5)) & 7)));
+    // Z1[k1][b = 4 c + d]: reader lane l2 = 4 k1 + d sees its 16 values as eight swizzled 16-byte pairs; writer (k1, b1): fb + 512 k1 + (z1w ^ (((2 k1) & 6) << 4))
+    const unsigned z1w = 128u * (unsigned)(b1 & 3) + 8u * (unsigned)((b1 >> 2) & 1) + 16u * (unsigned)(((b1 >> 3) ^ ((b1 & 3) >> 1)) & 7);
+    const int l2 = lt & 63, d2 = l2 & 3;                                        // pass 2: k1 = l2 >> 2, d = l2 & 3
+    const unsigned z1r = fb + (unsigned)l2 * 128u + ((unsigned)((l2 >> 1) & 7) << 4);    // pair i: z1r ^ (i << 4)
+    const unsigned z2w = fb + 8u * (unsigned)l2;                                // Z2[k1][k2][d] at 4 (k1 + 16 k2) + d: + 512 k2
+    const unsigned z2r = 32u * (unsigned)lt;                                    // pass 3: thread kk reads 4 d's of frame f at 8192 f + 32 kk
+    // block flush: my wave's 8 KiB of a consumed tile buffer = 2 KiB of each frame block (exactly what its pass-3 reads covered), as
+    // 512 16-byte slots: writer lane l, piece p -> slot 8 l + (p ^ ((l >> 1) & 7)); reader instruction m, lane l -> row r = 8 m + (l >> 3),
+    // piece l & 7.  Slot sigma lies at 8192 (sigma >> 7) + 2048 wave + 16 (sigma & 127).
+    const unsigned row_b = A.nf * 4u;                                           // bytes per output row
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)(1024u * row_b), 0x00020000);
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+    v4f stg[B3_TB][4];                                  // my four channels' results of the block's tiles: 128 VGPRs
+#pragma unroll
+    for (int t = 0; t < B3_TB; t++)
+#pragma unroll
+        for (int k3 = 0; k3 < 4; k3++) stg[t][k3] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    for (unsigned s = 0; s < n_items + 2; s++) {
+        bar();                                          // X: Z2 of item s - 2 is complete
+        if (s >= 2 + nwarm) {
+            // ---- DFT pass 3 + tail of item s - 2: thread kk = k1 + 16 k2, all four frames; Y[f][k3] = channel kk + 256 k3
+            const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)(tile_begin + s - 2));
+            const char *B = reinterpret_cast<const char *>(L) + ((s - 2u) & 3u) * (B3_BUF * 8u);
+            v2f y[4][4];
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                const v4f v0 = *reinterpret_cast<const v4f *>(B + 8192 * f + z2r);
+                const v4f v1 = *reinterpret_cast<const v4f *>(B + 8192 * f + z2r + 16);
+                y[f][0] = (v2f){v0.x, v0.y}; y[f][1] = (v2f){v0.z, v0.w}; y[f][2] = (v2f){v1.x, v1.y}; y[f][3] = (v2f){v1.z, v1.w};
+                bfly4_v(y[f][0], y[f][1], y[f][2], y[f][3]);
+            }
+            char *stp = reinterpret_cast<char *>(ST) + z2r;        // my 32 bytes of the stash: [kk][k3]
+            const v4f p01 = *reinterpret_cast<const v4f *>(stp), p23 = *reinterpret_cast<const v4f *>(stp + 16);
+            const float2 prev[4] = {make_float2(p01.x, p01.y), make_float2(p01.z, p01.w), make_float2(p23.x, p23.y), make_float2(p23.z, p23.w)};
+            *reinterpret_cast<v4f *>(stp) = (v4f){y[3][0].x, y[3][0].y, y[3][1].x, y[3][1].y};
+            *reinterpret_cast<v4f *>(stp + 16) = (v4f){y[3][2].x, y[3][2].y, y[3][3].x, y[3][3].y};
+            if (b >= first) {                           // (the muted tile in front of the run: only its last frame was wanted)
+                v4f mv[4];
+                FmK2 fkt = fk;                          // tile-local copies of the uniform scalings (SGPRs)
+                asm volatile("" : "+s"(fkt.ref), "+s"(fkt.hp), "+s"(fkt.pi), "+s"(fkt.tiny));
+#pragma unroll
+                for (int k3 = 0; k3 < 4; k3++) {
+                    const float2 rp[4] = {prev[k3], to_f2(y[0][k3]), to_f2(y[1][k3]), to_f2(y[2][k3])};
+                    const float2 rr[4] = {to_f2(y[0][k3]), to_f2(y[1][k3]), to_f2(y[2][k3]), to_f2(y[3][k3])};
+                    float mq[4];
+                    if (B3_ABLATE & 4) { mq[0] = rp[0].x + rr[0].y; mq[1] = rp[1].y + rr[1].x; mq[2] = rp[2].x + rr[2].y; mq[3] = rp[3].y + rr[3].x; }
+                    else fm_quad(rp, rr, fkt, mq);
+                    mv[k3] = (v4f){mq[0], mq[1], mq[2], mq[3]};
+                }
+                const unsigned ts = b & (B3_TB - 1u);
+#define B3_KEEP(T) case T: stg[T][0] = mv[0]; stg[T][1] = mv[1]; stg[T][2] = mv[2]; stg[T][3] = mv[3]; break;
+                switch (ts) { B3_KEEP(0) B3_KEEP(1) B3_KEEP(2) B3_KEEP(3) B3_KEEP(4) B3_KEEP(5) B3_KEEP(6) default: B3_KEEP(7) }
+#undef B3_KEEP
+                if (ts == B3_TB - 1u && !(B3_ABLATE & 2)) {
+                    // ---- the block is complete: every row's 128 bytes leave in one piece
+                    char *Bw = const_cast<char *>(B);
+                    unsigned lf = (unsigned)l2;                                  // per-lane offsets of the flush, derived here: as loop invariants they would pin five more VGPRs
+                    asm volatile("" : "+v"(lf));
+                    const unsigned fl_w = 8192u * (unsigned)(lf >> 4) + 2048u * wave_u + 128u * (unsigned)(lf & 15) + ((unsigned)((lf >> 1) & 7) << 4);   // ^ (p << 4)
+                    const unsigned fl_r0 = 2048u * wave_u + 128u * (unsigned)(lf >> 3) + 16u * (unsigned)((lf & 7) ^ (lf >> 4));                           // m even: + 8192 (m >> 1)
+                    const unsigned fl_r1 = 2048u * wave_u + 1024u + 128u * (unsigned)(lf >> 3) + 16u * (unsigned)((lf & 7) ^ (4 + (lf >> 4)));            // m odd
+                    const unsigned st_v = (64u * wave_u + (unsigned)(lf >> 3)) * row_b + 16u * (unsigned)(lf & 7);
+                    const unsigned o0 = 16u * (b - (B3_TB - 1u));                // the block's first frame in a row, bytes
+#pragma unroll
+                    for (int k3 = 0; k3 < 4; k3++) {
+                        if (B3_ABLATE & 8) {
+#pragma unroll
+                            for (int m = 0; m < 8; m++)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, stg[m][k3]), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * row_b), 0);
+                            continue;
+                        }
+#pragma unroll
+                        for (int p = 0; p < 8; p++) *reinterpret_cast<v4f *>(Bw + (fl_w ^ (unsigned)(p << 4))) = stg[p][k3];
+#pragma unroll
+                        for (int m = 0; m < 8; m++) {
+                            const v4f v = *reinterpret_cast<const v4f *>(Bw + ((m & 1) ? fl_r1 : fl_r0) + 8192 * (m >> 1));
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * row_b), 0);
+                        }
+                    }
+                }
+            }
+        }
+        bar();                                          // Y
+        if (s >= 1 + nwarm && s - 1 < n_items) {
+            // ---- DFT pass 1 of item s - 1: wave f, lane b1: radix 16 over a (n = 64 a + b1); Z1 goes back into the frame block
+            char *B = reinterpret_cast<char *>(L) + ((s - 1u) & 3u) * (B3_BUF * 8u);
+            v2f vv[16];
+#pragma unroll
+            for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B + fb + 512 * a + (x_a ^ (unsigned)((a & 3) << 5))));
+            fft16_v(vv);
+#pragma unroll
+            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (XIDX(i) - 1) + b1]));
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                *reinterpret_cast<float2 *>(B + fb + 512 * XIDX(i) + (z1w ^ (unsigned)(((2 * XIDX(i)) & 6) << 4))) = to_f2(vv[i]);
+            // ---- DFT pass 2: same wave, lane (k1, d): radix 16 over c (b = 4 c + d)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const v4f v = *reinterpret_cast<const v4f *>(B + (z1r ^ (unsigned)(i << 4)));
+                vv[2 * i] = (v2f){v.x, v.y}; vv[2 * i + 1] = (v2f){v.z, v.w};
+            }
+            fft16_v(vv);                                // vv[i] = k2 = XIDX(i)
+            if (d2) {                                   // W64^(d k2); lanes d = 0 sit this out
+#pragma unroll
+                for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (4 * d2 - 1) + 4 * XIDX(i)]));
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) *reinterpret_cast<float2 *>(B + z2w + 512 * XIDX(i)) = to_f2(vv[i]);
+        }
+    }
+    if (last == A.nb) {                                 // a thread reads back what it wrote
+#pragma unroll
+        for (int k3 = 0; k3 < 4; k3++) A.rp_out[lt + 256 * k3] = ST[4 * lt + k3];
+    }
+}
+
+}  // namespace
+
+int run1024_v3_launch(const Run1024v2Host &h, uint32_t nruns, hipStream_t s, KernelTimer *timer)
+{
+    Run1024v3Args A{};
+    A.x = h.x; A.out = (float *)h.out; A.taps_q = h.taps_q; A.tw = h.tw;
+    A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
+    A.rp_in = h.rp_in; A.rp_out = h.rp_out;
+    A.nf = h.nf; A.nb = h.nf / B3_T4; A.nruns = nruns; A.parity0 = h.parity0;
+    const double beta = h.dc_block ? h.beta : 0.0;
+    A.alpha = h.dc_block ? (float)(1.0 - beta) : 0.0f; A.beta = (float)beta; A.l2beta = h.dc_block ? (float)std::log2(beta) : -1000.0f;
+    for (int i = 0; i < 16; i++) A.b16[i] = (float)std::pow(beta, 16.0 * i);
+    for (int i = 0; i < 17; i++) A.b256[i] = (float)std::pow(beta, 256.0 * i);
+    A.fm_ref = h.fm_ref; A.tiny = 1e-37f;
+    A.pk = phase_consts(1.0f);                          // unscaled polynomial (fm_quad scales a = min / max by ref)
+    A.pk.hp *= h.fm_ref; A.pk.pi *= h.fm_ref; A.pk.ref = h.fm_ref;
+    int r;
+    if (timer && (r = timer->begin(s))) return r;
+    hipLaunchKernelGGL(k_run1024v3, dim3(nruns), dim3(512), 0, s, A);
+    if (timer && (r = timer->end(s))) return r;
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
+uint32_t run1024_v3_runs(uint32_t nf, uint32_t cus)
+{
+    // one workgroup per CU; runs are whole 8-tile blocks (a row's 128-byte line); a run >= 1 spends 6 read-only + 4 halo tiles on its
+    // start state: at least four blocks per run
+    if (nf % (B3_T4 * B3_TB)) return 0;
+    const uint32_t nblk = nf / (B3_T4 * B3_TB);
+    uint32_t nruns = cus;
+    if (const char *e = getenv("CSDR_RUN1024_V3_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
+    if (nruns > nblk / 4) nruns = nblk / 4;
+    return nruns;                                       // 0: too short (or ragged) for this kernel
+}
+
+}  // namespace csdr

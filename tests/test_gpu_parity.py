@@ -1527,6 +1527,46 @@ def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatc
     a.close(); b.close()
 
 
+def test_run1024_v3_matches_second_generation_kernel_and_oracle(monkeypatch):
+    """k_run1024v3 (one 512-thread workgroup per CU, front / back wave roles, a row's 128-byte line staged in registers: FM, whole
+    band, calls of nf % 32 == 0) against k_run1024v2 and the oracle.  Calls: 5 frames (odd: first-generation kernel, leaves the NCO
+    parity odd and a non-trivial DC state, window and r'), 4096 (v3: 32 runs of 4 blocks with warm-up, halo and muted tile), 516
+    (nf % 32 != 0: k_run1024v2 picks up v3's state), 2048 (v3 again: 16 runs, picks up v2's state), 1200 (v2)."""
+    M = 1024
+    frames = [5, 4096, 516, 2048, 1200]
+    nf = sum(frames)
+    x = synth_cf32(M * nf, M, seed=79)
+    x = (x + np.complex64(0.01 - 0.005j)).astype(np.complex64)    # a DC offset the blocker has to remove across run starts
+    kw = dict(channels=M, demod="fm", kf=0.3, max_frames=max(frames))
+    monkeypatch.setenv("CSDR_RUN1024_V3", "1")
+    a = cs.Chain(**kw)
+    monkeypatch.setenv("CSDR_RUN1024_V3", "0")
+    b = cs.Chain(**kw)
+    monkeypatch.delenv("CSDR_RUN1024_V3")
+    orc = O.Chain(M, demod="fm", kf=0.3)
+    ga, gb, wo, pos, names = [], [], [], 0, []
+    for f in frames:
+        xa = x[pos * M:(pos + f) * M]
+        ga.append(a.process(xa)); gb.append(b.process(xa)); wo.append(orc.process(xa)); pos += f
+        names.append((a.kernel_time()[0], b.kernel_time()[0]))
+    print("kernels:", names)
+    assert [n[0] for n in names] == ["k_run1024<FM>", "k_run1024v3", "k_run1024v2<FM>", "k_run1024v3", "k_run1024v2<FM>"]
+    assert all("v3" not in n[1] for n in names)
+    ga, gb, wo = [np.concatenate(v, axis=1) for v in (ga, gb, wo)]
+    d1 = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / 0.3))
+    d2 = np.abs(wrap_pm(ga.astype(np.float64) - wo, 1.0 / 0.3))
+    print(f"run1024v3 FM: vs v2 median {np.median(d1):.2e} p99.9 {np.quantile(d1, 0.999):.2e} max {d1.max():.2e}; "
+          f"vs oracle median {np.median(d2):.2e} p99.9 {np.quantile(d2, 0.999):.2e}")
+    assert np.median(d1) < 2e-6 and np.median(d2) < 2e-5
+    assert np.quantile(d1, 0.999) < 5e-5
+    starts = d1[:, 5:5 + 4096:128]                                # 4096 frames / 32 runs: every run start of the first v3 call
+    assert np.quantile(starts, 0.999) < 5e-5
+    for lo, hi in ((5, 5 + 4096), (5 + 4096 + 516, 5 + 4096 + 516 + 2048)):      # every row block and every 32-frame line of the v3 calls
+        blk = d2[:, lo:hi].reshape(M // 64, 64, -1, 32)
+        assert np.median(blk, axis=(1, 3)).max() < 2e-5
+    a.close(); b.close()
+
+
 def test_full_size_cfg4_shape_1024ch_fm_properties(monkeypatch):
     """configs[3] shape on one GPU (1024 ch, 65 536 frames = 67 M samples per chunk, k_run1024):
     (1) one chunk == 8 chunks (DC state, FIR window, freqdem r' and the run splits carry over),
