@@ -268,7 +268,8 @@ def main():
     if a.preheat_ms > 0:
         est = max(dt_cold / a.steps, 1e-5)
         preheat_steps = max(10, int(a.preheat_ms * 1e-3 / est) + 1)
-        smi = SmiSampler(local) if rank == 0 else None
+        # (under rocprofv3 the preloaded tool has initialised the GPU in this process: the pool refuses a child that execs, which rocm-smi does)
+        smi = SmiSampler(local) if rank == 0 and "rocprof" not in os.environ.get("LD_PRELOAD", "") else None
         for attempt in range(4):                # the estimate comes from a K-step window: re-run longer until the run lasts preheat_ms
             if use_dist:                        # every rank the SAME number of steps (a step may contain a collective)
                 t = torch.tensor([preheat_steps], dtype=torch.int64, device=dev)

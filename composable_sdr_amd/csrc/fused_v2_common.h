@@ -55,6 +55,18 @@ __device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, u
     }
 }
 
+// one of the eight instructions of dma_tile (piece `it`, a compile-time constant after unrolling): for kernels that spread a tile's DMA over
+// their arithmetic instead of issuing it in one burst (the CU's address unit takes 16 cycles per 1 KiB wave instruction)
+__device__ __forceinline__ void dma_piece(const float4 *__restrict__ tile_base, unsigned goff, unsigned lds_wave, const int it)
+{
+    asm volatile("" : "+s"(lds_wave));
+    const unsigned dst = lds_wave + 4096u * (unsigned)it;
+    const float4 *src = tile_base + 256 * it;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %1, %3" V2_DMA_AUX "\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(goff), "s"(dst), "s"(src) : "memory");
+}
+
 // ref * arg(conj(rp) r): the degree-15 minimax polynomial of scaled_atan2f with literal coefficients (v_fmaak), the
 // scale applied to a = min/max before the last product; hp = ref pi/2, pi = ref pi, tiny = 1e-37 held in VGPRs
 struct FmK { float tiny, ref, hp, pi; };

@@ -26,9 +26,11 @@
 //          DMA of tile s+2; column layout, pre-mix, FIR -> X(s); window    passes 1 + 2 of tile s-1 (wave-private frame block)
 // Tile i lives in buffer i % 4 from its DMA to the back waves' pass 3.  Arithmetic: k_run1024v2's, instruction for instruction.
 #include "fused_v2_common.h"
+#include <type_traits>
 
 #ifndef B3_ABLATE
-#define B3_ABLATE 0      // timing experiments only: 2 no output stores, 4 no freqdem, 8 no flush transposition (stores of registers)
+#define B3_ABLATE 0      // timing experiments only: 2 no output stores, 4 no freqdem, 8 no flush transposition (stores of registers), 16 no DFT passes 1-2,
+                         // 32 no FIR, 64 no pass 3 / tail at all, 128 no window shift
 #endif
 
 namespace csdr {
@@ -51,6 +53,8 @@ struct Run1024v3Args {
     const float2 *vend_in; float2 *vend_out;      // DC blocker state v1
     const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r'
     uint32_t nf, nb, nruns, parity0;
+    unsigned long long *trace;  // debug (CSDR_RUN1024_V3_TRACE=file): s_memtime stamps of run 1's wave 0 (front) and wave 4 (back), [role][step][4]
+    uint32_t stagger;           // 1: run w > 0 walks (w >> 3) & 7 more window-refill tiles before its first output (see the kernel)
     float alpha, beta, l2beta, fm_ref, tiny;
     float b16[16];              // beta^(16 r)
     float b256[17];             // beta^(256 g)
@@ -68,6 +72,7 @@ __host__ __device__ __forceinline__ void run3_bounds(uint32_t nb, uint32_t nruns
 __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 {
     __shared__ __attribute__((aligned(16))) float2 L[B3_F2];
+    __shared__ unsigned long long trc[1536];            // debug stamps (8 KiB): collected in LDS, written out when the run is over (a global store per stamp would sit in the traced wave's vmcnt queue)
     float2 *tw1 = L + B3_TW1, *ST = L + B3_ST, *Tt = L + B3_TT, *red = ST;
     const int tid = threadIdx.x;
     const bool back = tid >= 256;                       // wave-uniform role
@@ -86,13 +91,18 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     // ------------------------------------------------------------------ run start
     // items of the run: tile tile_begin + i, i = 0 .. n_items - 1; the first nwarm only refill the window (front waves), the next
     // one (tile first - 1) is muted: FIR and DFT for its last frame, the freqdem history of the run's first sample
-    const unsigned tile_begin = w == 0 ? first : first - B3_HALO;
-    const unsigned nwarm = w == 0 ? 0u : (unsigned)(B3_HALO - 1);
+    // STAGGER.  All runs are equally long and start together, so without it every CU completes its blocks in the same step: 32 MiB
+    // of lines leave in one burst (the L2s hold 4 MiB each: the stores wait for HBM), then nothing for seven steps.  Run w > 0 therefore walks
+    // phi = (w >> 3) & 7 extra refill tiles first (front waves only, no FIR): the CUs of an XCD complete their blocks in eight different steps.
+    const unsigned phi = (w == 0 || !A.stagger) ? 0u : ((w >> 3) & 7u);
+    const unsigned tile_begin = w == 0 ? first : first - B3_HALO - phi;
+    const unsigned nwarm = w == 0 ? 0u : (unsigned)(B3_HALO - 1) + phi;
     const unsigned n_items = last - tile_begin;
-    if (!back) {                                        // the first two tile images: requested before anything else
-        dma_tile(x4 + (size_t)tile_begin * 2048, goff, lds_wave);
-        if (n_items > 1) dma_tile(x4 + (size_t)(tile_begin + 1) * 2048, goff, lds_wave + (unsigned)(B3_BUF * 8u));
-    }
+    // TILE DMA: by the BACK waves (image s + 1 is requested in pieces between the arithmetic of phase P of step s and waited for at the end of
+    // the step).  The front waves load their taps per step; loads return in order, so a DMA in their queue makes the first tap use wait for the
+    // whole image (hipcc's waits cannot see an asm DMA), and eighteen VMEM instructions per wave in one burst cost the front waves -- the
+    // role that paces the step -- ~850 cycles (the CU's address unit takes 16 cycles per 1 KiB instruction: CSDR_RUN1024_V3_TRACE).
+    if (back) dma_tile(x4 + (size_t)tile_begin * 2048, goff, lds_wave);         // the first image: landed at the __syncthreads below
     float2 c = make_float2(0.f, 0.f);                   // DC state v before the next tile (same in every lane)
     {
         float2 acc = make_float2(0.f, 0.f);
@@ -138,17 +148,22 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++) ST[4 * lt + k3] = (w == 0) ? A.rp_in[lt + 256 * k3] : make_float2(0.f, 0.f);
     }
-    __syncthreads();                                    // twiddle tables, stash
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the first image: hipcc's own waits do not know about an asm DMA)
+    __syncthreads();                                    // twiddle tables, stash, image 0
 
     if (!back) {
         // ================================================================== FRONT
-        float2 hist[52];                                // window: frames -13 .. -1 of my four branches, [13][4]
-        if (w == 0) {
+        // WINDOW.  A ring of 16 frames x 4 branches in registers (128 VGPRs), the step loop unrolled four times so that every slot index is a
+        // compile-time constant: in a step of phase PH = s & 3 the tile's frames f = 0, 1, 2 are written straight into slots 4 PH + f (they held
+        // frames -16, -15, -14: dead), frame 3 waits in n3 until the FIR has read frame -13 out of slot 4 PH + 3 and is moved there at the end
+        // of the step: four moves per step instead of k_run1024v2's 52 (a tenth of the front waves' time).  Frame -d of a step sits in slot
+        // (4 PH - d) & 15.  The tile buffer index is s & 3 = PH as well.
+        float2 ring[64];                                // [slot][branch]
 #pragma unroll
-            for (int i = 0; i < 52; i++) hist[i] = A.uhist_in[(i >> 2) * B3_M + 256 * (i & 3) + j];
-        } else {
+        for (int i = 0; i < 64; i++) ring[i] = make_float2(0.f, 0.f);
+        if (w == 0) {                                   // step 0 has phase 0: frame -13 + i in slot 3 + i
 #pragma unroll
-            for (int i = 0; i < 52; i++) hist[i] = make_float2(0.f, 0.f);
+            for (int i = 0; i < 52; i++) ring[4 * (3 + (i >> 2)) + (i & 3)] = A.uhist_in[(i >> 2) * B3_M + 256 * (i & 3) + j];
         }
         // taps (14) and even / odd frame pre-mix phasors of a branch: four 16-byte loads + one 8-byte load per tile out of the L2-resident
         // table, as in k_run1024v2 (the window leaves no room for all 72 registers): branches 0 and 1 are requested at the top of the step
@@ -173,20 +188,44 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
         const int q = lt, sw = (q >> 1) & 7;
         const unsigned raw_a = (unsigned)q * 128u + ((unsigned)sw << 4);         // slot i of my run: raw_a ^ (i << 4)
 
-        for (unsigned s = 0; s < n_items + 2; s++) {
+        auto fstep = [&](const unsigned s, auto phc) {
+            constexpr int PH = decltype(phc)::value;    // s & 3
             const bool have = s < n_items;
             const bool warm = s < nwarm;
-            char *B = reinterpret_cast<char *>(L) + (s & 3u) * (B3_BUF * 8u);    // item s's buffer
+            char *B = reinterpret_cast<char *>(L) + PH * (B3_BUF * 8);           // item s's buffer
             float2 *Bf = reinterpret_cast<float2 *>(B);
-            if (have) {                                 // my pieces of image s have landed (image s + 1 may still be in flight)
-                if (s + 1 < n_items) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            const bool tr = A.trace && w == 1 && tid == 0 && s < 128;
+            if (tr) trc[8 * s + 4] = __builtin_amdgcn_s_memtime();
+            if (tr) trc[8 * s + 5] = __builtin_amdgcn_s_memtime();
             v4f tq0[4], tq1[4], tq2[4], tq3[4];
             v2f wo0, wo1, wo2, wo3;
-            if (have) { load_taps(tq0, wo0, 0); load_taps(tq1, wo1, 1); }
-            bar();                                      // X
+            if (tr) trc[8 * s + 6] = __builtin_amdgcn_s_memtime();
+            bar();                                      // P
+            if (tr) trc[8 * s + 0] = __builtin_amdgcn_s_memtime();
+            if (have) load_taps(tq0, wo0, 0);           // (the taps of branches 0 and 1 fly during pass 1 and the DC scan)
+            asm volatile("" ::: "memory");
+            if (s >= 1 + nwarm && s - 1 < n_items && !(B3_ABLATE & 16)) {
+                // ---- DFT pass 1 of item s - 1 (its X is complete since the barrier): wave f = frame f, lane b1: radix 16 over a (n = 64 a + b1);
+                // Z1 goes back into the frame block, where back wave f finds it in phase Q
+                char *B1 = reinterpret_cast<char *>(L) + ((PH + 3) & 3) * (B3_BUF * 8);
+                unsigned b1 = (unsigned)lt & 63u;
+                asm volatile("" : "+v"(b1));            // (offsets derived here: as loop invariants they would pin VGPRs next to the window)
+                const unsigned fb = 8192u * wave_u;
+                const unsigned x_a = 8u * ((16u * (b1 >> 4)) | (b1 & 1u) | (2u * ((((b1 & 15u) >> 1) ^ (b1 >> 5)) & 7u)));
+                const unsigned z1w = 128u * (b1 & 3u) + 8u * ((b1 >> 2) & 1u) + 16u * (((b1 >> 3) ^ ((b1 & 3u) >> 1)) & 7u);
+                v2f vv[16];
+#pragma unroll
+                for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B1 + fb + 512 * a + (x_a ^ (unsigned)((a & 3) << 5))));
+                fft16_v(vv);
+#pragma unroll
+                for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (XIDX(i) - 1) + b1]));
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    *reinterpret_cast<float2 *>(B1 + fb + 512 * XIDX(i) + (z1w ^ (unsigned)(((2 * XIDX(i)) & 6) << 4))) = to_f2(vv[i]);
+            }
+            asm volatile("" ::: "memory");
             if (have) {
+                load_taps(tq1, wo1, 1);
                 // ---- DC blocker inside a 256-sample group: thread q owns the run of 16 consecutive samples q (as k_run256v2)
                 const float na = opaque_v(-A.alpha), be = opaque_v(A.beta);
                 v4f xr[8];
@@ -216,10 +255,13 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                     *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = y;
                 }
             }
-            bar();                                      // Y: y' (group carry still missing) and the group totals are visible; buffer (s + 2) % 4 is free
-            if (!have) continue;
-            // ---- column layout: nw[4 f + qq] = sample of frame f, branch j + 256 qq; group state chain V[g] (uniform)
-            float2 nw[16];
+            if (tr) trc[8 * s + 1] = __builtin_amdgcn_s_memtime();
+            bar();                                      // Q: y' (group carry still missing), the group totals and Z1 of item s - 1 are visible
+            if (tr) trc[8 * s + 2] = __builtin_amdgcn_s_memtime();
+            if (!have) return;
+            // ---- column layout: sample of frame f, branch j + 256 qq -> ring slot 4 PH + f (f < 3) / n3 (f = 3); group state chain V[g] (uniform)
+            float2 n3[4];
+#define NW(f, qq) (*((f) < 3 ? &ring[4 * ((4 * PH + (f)) & 15) + (qq)] : &n3[qq]))
             {
                 v2f V = {c.x, c.y};
                 const v2f kJv = {kJ, kJ}, bv = {b256, b256};
@@ -230,7 +272,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         const int g = 4 * f + qq;
-                        nw[g] = to_f2(__builtin_elementwise_fma(V, kJv, to_v(Bf[256 * g + col_off])));
+                        NW(f, qq) = to_f2(__builtin_elementwise_fma(V, kJv, to_v(Bf[256 * g + col_off])));
                         V = __builtin_elementwise_fma(V, bv, tg[qq]);
                     }
                 }
@@ -242,11 +284,11 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                 const v2f Wa = odd0 ? wodd : we, Wb = odd0 ? we : wodd;
 #pragma unroll
                 for (int f = 0; f < 4; f += 2) {
-                    v2f a0 = to_v(nw[4 * f + qq]), a1 = to_v(nw[4 * (f + 1) + qq]);
+                    v2f a0 = to_v(NW(f, qq)), a1 = to_v(NW(f + 1, qq));
                     cmul2_v(a0, Wa, a1, Wb);
-                    nw[4 * f + qq] = to_f2(a0); nw[4 * (f + 1) + qq] = to_f2(a1);
+                    NW(f, qq) = to_f2(a0); NW(f + 1, qq) = to_f2(a1);
                 }
-                if (warm) return;
+                if (warm || (B3_ABLATE & 32)) return;
                 const float h[16] = {t[0].x, t[0].y, t[0].z, t[0].w, t[1].x, t[1].y, t[1].z, t[1].w, t[2].x, t[2].y, t[2].z, t[2].w, t[3].x, t[3].y, 0.f, 0.f};
                 v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
@@ -254,7 +296,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 #pragma unroll
                     for (int f = 0; f < 4; f++) {
                         const int i = f - n;
-                        const float2 s2 = (i >= 0) ? nw[4 * i + qq] : hist[4 * (13 + i) + qq];
+                        const float2 s2 = (i >= 0) ? NW(i, qq) : ring[4 * ((4 * PH + i) & 15) + qq];
                         const v2f sv = {s2.x, s2.y}, hv = {h[n], h[n]};
                         acc[f] = __builtin_elementwise_fma(sv, hv, acc[f]);
                     }
@@ -262,28 +304,44 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 #pragma unroll
                 for (int f = 0; f < 4; f++) Bf[256 * (4 * f + qq) + col_off] = to_f2(acc[f]);
             };
-            branch(tq0, wo0, 0);
-            asm volatile("" ::: "memory");
+            // taps of branches 2 and 3: requested here / after branch 0 (they fly during the FIR of the branches before them)
             load_taps(tq2, wo2, 2);
             asm volatile("" ::: "memory");
-            branch(tq1, wo1, 1);
+            branch(tq0, wo0, 0);
             asm volatile("" ::: "memory");
             load_taps(tq3, wo3, 3);
             asm volatile("" ::: "memory");
+            branch(tq1, wo1, 1);
             branch(tq2, wo2, 2);
             branch(tq3, wo3, 3);
-            asm volatile("" ::: "memory");
-            if (s + 2 < n_items) dma_tile(x4 + (size_t)(tile_begin + s + 2) * 2048, goff, lds_wave + ((s + 2u) & 3u) * (B3_BUF * 8u));
-            // the window moves on by four frames
+            if (tr) trc[8 * s + 3] = __builtin_amdgcn_s_memtime();
+            // frame 3 takes the slot of frame -13
 #pragma unroll
-            for (int i = 0; i < 36; i++) hist[i] = hist[i + 16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) hist[36 + i] = nw[i];
+            for (int qq = 0; qq < 4; qq++) ring[4 * ((4 * PH + 3) & 15) + qq] = n3[qq];
+#undef NW
+        };
+        const unsigned nsteps = n_items + 2;
+        for (unsigned s0 = 0; s0 < nsteps; s0 += 4) {
+            fstep(s0, std::integral_constant<int, 0>());
+            if (s0 + 1 < nsteps) fstep(s0 + 1, std::integral_constant<int, 1>());
+            if (s0 + 2 < nsteps) fstep(s0 + 2, std::integral_constant<int, 2>());
+            if (s0 + 3 < nsteps) fstep(s0 + 3, std::integral_constant<int, 3>());
         }
+        if (A.trace && w == 1 && tid == 0) for (int i = 0; i < 1024; i++) A.trace[i] = trc[i];
         if (last == A.nb) {
             if (lt == 0) A.vend_out[0] = c;
+            // the next call's window: frame -d behind the last item (phase (n_items - 1) & 3) sits in slot (4 (n_items & 3) - d) & 15
+            auto put = [&](auto phc) {
+                constexpr int PN = decltype(phc)::value;
 #pragma unroll
-            for (int i = 0; i < 52; i++) A.uhist_out[(i >> 2) * B3_M + 256 * (i & 3) + j] = hist[i];
+                for (int i = 0; i < 52; i++) A.uhist_out[(i >> 2) * B3_M + 256 * (i & 3) + j] = ring[4 * ((4 * PN - 13 + (i >> 2)) & 15) + (i & 3)];
+            };
+            switch (n_items & 3u) {
+            case 0: put(std::integral_constant<int, 0>()); break;
+            case 1: put(std::integral_constant<int, 1>()); break;
+            case 2: put(std::integral_constant<int, 2>()); break;
+            default: put(std::integral_constant<int, 3>()); break;
+            }
         }
         return;
     }
@@ -291,11 +349,8 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     // ====================================================================== BACK
     const FmK2 fk = {{A.pk.c[0], A.pk.c[1], A.pk.c[2], A.pk.c[3], A.pk.c[4], A.pk.c[5], A.pk.c[6], A.pk.c[7]}, A.tiny, A.fm_ref, A.pk.hp, A.pk.pi};
     const unsigned fb = 8192u * wave_u;                                         // passes 1-2: my wave's frame block
-    const int b1 = lt & 63;                                                     // pass 1: n = 64 a + b1
-    // X[f][64 a + b1] sits at fb + 512 a + (x_a ^ ((a & 3) << 5))  (column layout of the raw image, see col_off)
-    const unsigned x_a = 8u * (unsigned)((16 * (b1 >> 4)) | (b1 & 1) | (2 * ((((b1 & 15) >> 1) ^ (b1 >> 5)) & 7)));
-    // Z1[k1][b = 4 c + d]: reader lane l2 = 4 k1 + d sees its 16 values as eight swizzled 16-byte pairs; writer (k1, b1): fb + 512 k1 + (z1w ^ (((2 k1) & 6) << 4))
-    const unsigned z1w = 128u * (unsigned)(b1 & 3) + 8u * (unsigned)((b1 >> 2) & 1) + 16u * (unsigned)(((b1 >> 3) ^ ((b1 & 3) >> 1)) & 7);
+    // (pass 1, front waves: X[f][64 a + b1] sits at fb + 512 a + (x_a ^ ((a & 3) << 5)), the column layout of the raw image; Z1[k1][b = 4 c + d] is
+    // written to fb + 512 k1 + (z1w ^ (((2 k1) & 6) << 4)) so that reader lane l2 = 4 k1 + d sees its 16 values as eight swizzled 16-byte pairs)
     const int l2 = lt & 63, d2 = l2 & 3;                                        // pass 2: k1 = l2 >> 2, d = l2 & 3
     const unsigned z1r = fb + (unsigned)l2 * 128u + ((unsigned)((l2 >> 1) & 7) << 4);    // pair i: z1r ^ (i << 4)
     const unsigned z2w = fb + 8u * (unsigned)l2;                                // Z2[k1][k2][d] at 4 (k1 + 16 k2) + d: + 512 k2
@@ -314,8 +369,15 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
         for (int k3 = 0; k3 < 4; k3++) stg[t][k3] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     for (unsigned s = 0; s < n_items + 2; s++) {
-        bar();                                          // X: Z2 of item s - 2 is complete
-        if (s >= 2 + nwarm) {
+        bar();                                          // P: Z2 of item s - 2 is complete
+        const bool tr = A.trace && w == 1 && tid == 256 && s < 128;
+        if (tr) trc[1024 + 4 * s + 0] = __builtin_amdgcn_s_memtime();
+        // image s + 1 into the buffer item s - 3 left in phase P of the previous step: four pieces here, four behind pass 3's arithmetic
+        const bool dma = s + 1 < n_items;
+        const float4 *dsrc = x4 + (size_t)(tile_begin + s + 1) * 2048;
+        const unsigned ddst = lds_wave + ((s + 1u) & 3u) * (B3_BUF * 8u);
+        if (dma) { dma_piece(dsrc, goff, ddst, 0); dma_piece(dsrc, goff, ddst, 1); dma_piece(dsrc, goff, ddst, 2); dma_piece(dsrc, goff, ddst, 3); }
+        if (s >= 2 + nwarm && !(B3_ABLATE & 64)) {
             // ---- DFT pass 3 + tail of item s - 2: thread kk = k1 + 16 k2, all four frames; Y[f][k3] = channel kk + 256 k3
             const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)(tile_begin + s - 2));
             const char *B = reinterpret_cast<const char *>(L) + ((s - 2u) & 3u) * (B3_BUF * 8u);
@@ -378,20 +440,14 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                 }
             }
         }
-        bar();                                          // Y
-        if (s >= 1 + nwarm && s - 1 < n_items) {
-            // ---- DFT pass 1 of item s - 1: wave f, lane b1: radix 16 over a (n = 64 a + b1); Z1 goes back into the frame block
+        if (dma) { dma_piece(dsrc, goff, ddst, 4); dma_piece(dsrc, goff, ddst, 5); dma_piece(dsrc, goff, ddst, 6); dma_piece(dsrc, goff, ddst, 7); }
+        if (tr) trc[1024 + 4 * s + 1] = __builtin_amdgcn_s_memtime();
+        bar();                                          // Q: Z1 of item s - 1 is complete
+        if (tr) trc[1024 + 4 * s + 2] = __builtin_amdgcn_s_memtime();
+        if (s >= 1 + nwarm && s - 1 < n_items && !(B3_ABLATE & 16)) {
+            // ---- DFT pass 2 of item s - 1 (front wave f left Z1 in my frame block in phase P): lane (k1, d): radix 16 over c (b = 4 c + d)
             char *B = reinterpret_cast<char *>(L) + ((s - 1u) & 3u) * (B3_BUF * 8u);
             v2f vv[16];
-#pragma unroll
-            for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B + fb + 512 * a + (x_a ^ (unsigned)((a & 3) << 5))));
-            fft16_v(vv);
-#pragma unroll
-            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (XIDX(i) - 1) + b1]));
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                *reinterpret_cast<float2 *>(B + fb + 512 * XIDX(i) + (z1w ^ (unsigned)(((2 * XIDX(i)) & 6) << 4))) = to_f2(vv[i]);
-            // ---- DFT pass 2: same wave, lane (k1, d): radix 16 over c (b = 4 c + d)
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const v4f v = *reinterpret_cast<const v4f *>(B + (z1r ^ (unsigned)(i << 4)));
@@ -405,7 +461,10 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 #pragma unroll
             for (int i = 0; i < 16; i++) *reinterpret_cast<float2 *>(B + z2w + 512 * XIDX(i)) = to_f2(vv[i]);
         }
+        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); trc[1024 + 4 * s + 3] = __builtin_amdgcn_s_memtime(); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of image s + 1 have landed (and the block's row stores, if this step had them)
     }
+    if (A.trace && w == 1 && tid == 256) for (int i = 1024; i < 1536; i++) A.trace[i] = trc[i];
     if (last == A.nb) {                                 // a thread reads back what it wrote
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++) A.rp_out[lt + 256 * k3] = ST[4 * lt + k3];
@@ -421,6 +480,7 @@ int run1024_v3_launch(const Run1024v2Host &h, uint32_t nruns, hipStream_t s, Ker
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
     A.rp_in = h.rp_in; A.rp_out = h.rp_out;
     A.nf = h.nf; A.nb = h.nf / B3_T4; A.nruns = nruns; A.parity0 = h.parity0;
+    { static const bool st = !(getenv("CSDR_RUN1024_V3_STAGGER") && atoi(getenv("CSDR_RUN1024_V3_STAGGER")) == 0); A.stagger = st ? 1u : 0u; }
     const double beta = h.dc_block ? h.beta : 0.0;
     A.alpha = h.dc_block ? (float)(1.0 - beta) : 0.0f; A.beta = (float)beta; A.l2beta = h.dc_block ? (float)std::log2(beta) : -1000.0f;
     for (int i = 0; i < 16; i++) A.b16[i] = (float)std::pow(beta, 16.0 * i);
@@ -428,11 +488,21 @@ int run1024_v3_launch(const Run1024v2Host &h, uint32_t nruns, hipStream_t s, Ker
     A.fm_ref = h.fm_ref; A.tiny = 1e-37f;
     A.pk = phase_consts(1.0f);                          // unscaled polynomial (fm_quad scales a = min / max by ref)
     A.pk.hp *= h.fm_ref; A.pk.pi *= h.fm_ref; A.pk.ref = h.fm_ref;
+    static const char *trace_file = getenv("CSDR_RUN1024_V3_TRACE");
+    static unsigned long long *d_trace = nullptr;
+    if (trace_file && !d_trace) CSDR_HIP(hipMalloc(&d_trace, 1536 * sizeof(unsigned long long)));
+    if (trace_file) { CSDR_HIP(hipMemsetAsync(d_trace, 0, 1536 * sizeof(unsigned long long), s)); A.trace = d_trace; }
     int r;
     if (timer && (r = timer->begin(s))) return r;
     hipLaunchKernelGGL(k_run1024v3, dim3(nruns), dim3(512), 0, s, A);
     if (timer && (r = timer->end(s))) return r;
     CSDR_HIP(hipGetLastError());
+    if (trace_file) {                                   // debug: the last launch's stamps, raw uint64: front [128][8], back [128][4]
+        std::vector<unsigned long long> hbuf(1536);
+        CSDR_HIP(hipStreamSynchronize(s));
+        CSDR_HIP(hipMemcpy(hbuf.data(), d_trace, 1536 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(trace_file, "wb")) { fwrite(hbuf.data(), sizeof(unsigned long long), 1536, f); fclose(f); }
+    }
     return 0;
 }
 

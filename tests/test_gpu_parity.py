@@ -887,7 +887,7 @@ def test_run64_v2_matches_first_generation_kernel_and_oracle(monkeypatch):
     (256, "fm", "CSDR_RUN_MIN_TILES", [40000], {}),
 ])
 def test_second_generation_run_kernels_without_dc_blocker(M, demod, env, frames, extra, monkeypatch):
-    """dc_block = False (alpha = 0, beta = 0 inside the kernels) and DeNo --mix through k_run64v2 / k_run1024v2 / k_run256v2
+    """dc_block = False (alpha = 0, beta = 0 inside the kernels) and DeNo --mix through k_run64v2 / k_run1024v3 / k_run256v2
     against the first-generation kernels: without the DC scan's approximated run-start state the CF32 results are bitwise
     those of k_run64 (same FIR order, same DFT butterflies)."""
     x = synth_cf32(M * sum(frames), M, seed=3)
@@ -900,7 +900,8 @@ def test_second_generation_run_kernels_without_dc_blocker(M, demod, env, frames,
     for f in frames:
         xa = x[pos * M:(pos + f) * M]; pos += f
         ga, gb = a.process(xa), b.process(xa)
-        assert "v2" in a.kernel_time()[0] and "v2" not in b.kernel_time()[0]
+        ka, kb = a.kernel_time()[0], b.kernel_time()[0]
+        assert ("v2" in ka or "v3" in ka) and "v2" not in kb and "v3" not in kb, (ka, kb)      # (M = 1024 FM: k_run1024v3)
         if demod == "fm":
             d = np.abs(ga.astype(np.float64) - gb); d = np.minimum(d, np.abs(d - 1 / 0.3))
             assert np.median(d) < 1e-6 and np.quantile(d, 0.999) < 5e-5
@@ -1496,8 +1497,9 @@ def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatc
     x = (x + np.complex64(0.01 - 0.005j)).astype(np.complex64)    # a DC offset the blocker has to remove across run starts
     kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames))
     monkeypatch.setenv("CSDR_RUN1024_V2_ALL", "1")               # the CF32 variant is not the default (k_run1024 is faster there)
+    monkeypatch.setenv("CSDR_RUN1024_V3", "0")                   # (FM calls of whole 32-frame blocks would go to k_run1024v3)
     a = cs.Chain(**kw)
-    monkeypatch.delenv("CSDR_RUN1024_V2_ALL")
+    monkeypatch.delenv("CSDR_RUN1024_V2_ALL"); monkeypatch.delenv("CSDR_RUN1024_V3")
     monkeypatch.setenv("CSDR_RUN1024_V1", "1")
     b = cs.Chain(**kw)
     monkeypatch.delenv("CSDR_RUN1024_V1")
@@ -1538,8 +1540,7 @@ def test_run1024_v3_matches_second_generation_kernel_and_oracle(monkeypatch):
     x = synth_cf32(M * nf, M, seed=79)
     x = (x + np.complex64(0.01 - 0.005j)).astype(np.complex64)    # a DC offset the blocker has to remove across run starts
     kw = dict(channels=M, demod="fm", kf=0.3, max_frames=max(frames))
-    monkeypatch.setenv("CSDR_RUN1024_V3", "1")
-    a = cs.Chain(**kw)
+    a = cs.Chain(**kw)                                            # default: k_run1024v3 where it applies
     monkeypatch.setenv("CSDR_RUN1024_V3", "0")
     b = cs.Chain(**kw)
     monkeypatch.delenv("CSDR_RUN1024_V3")
@@ -1748,10 +1749,10 @@ def test_bench_layout_cfg2_64ch_deno_whole_chunk_matches_oracle():
 
 
 def test_bench_layout_cfg4_shape_1024ch_fm_whole_chunk_matches_oracle():
-    """k_run1024v2<FM> at 1024 x 65 536 (BASELINE configs[3] shape on one GPU) against O.Chain, every sample."""
+    """k_run1024v3 at 1024 x 65 536 (BASELINE configs[3] shape on one GPU) against O.Chain, every sample."""
     M, nf, kf = 1024, 65536, 0.3
     got, xh, kname, path = _bench_layout(M, nf, 33, demod="fm", kf=kf)
-    assert kname == "k_run1024v2<FM>", (kname, path)
+    assert kname == "k_run1024v3", (kname, path)
     r = np.abs(_bench_layout(M, nf, 33)[0])
     _fm_against_oracle(got, xh, M, kf, f"cfg4 shape {kname}", r)
 
