@@ -550,9 +550,12 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         // CF32 output (DeNo, AGC / AM tails) stays with k_run1024: staged through HBM twice, k_run1024v2<CF32> moves 2.3 GB per
         // 67 M samples and takes 405-415 us against 384 us (FM: 366 against 454); CSDR_RUN1024_V2_ALL=1 selects it anyway
         p->v2_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && !getenv("CSDR_RUN1024_V1") && (cfg.fm || getenv("CSDR_RUN1024_V2_ALL"));
-        // FM, whole band, calls of whole 32-frame blocks: k_run1024v3 (294 us against k_run1024v2's 352; CSDR_RUN1024_V3=0 for the comparison)
+        // FM, whole band, calls of whole 32-frame blocks: k_run1024v3 (282 us against k_run1024v2's 352, no staging block; CSDR_RUN1024_V3=0 for the comparison)
         p->v3_ok = p->v2_ok && cfg.fm && cfg.G == 1 && !(getenv("CSDR_RUN1024_V3") && atoi(getenv("CSDR_RUN1024_V3")) == 0);
         if (cfg.G > 1) p->v2_ok = cfg.fm && !getenv("CSDR_RUN1024_V1");       // k_run1024v2<FM, G>; CF32 shards: whole band + row gather (below)
+        // until the first call: the kernel a call of max_nf frames would take (csdr_chain_path names it)
+        p->v2_last = p->v2_ok && (cfg.max_nf & 3u) == 0 && run1024_v2_runs(cfg.max_nf, p->cus) != 0;
+        p->v3_last = p->v2_last && p->v3_ok && run1024_v3_runs(cfg.max_nf, p->cus) != 0;
     }
     *out = p;
     return 0;

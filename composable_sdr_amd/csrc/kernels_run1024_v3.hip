@@ -9,25 +9,35 @@
 // tiles = 128 KiB.  k_run1024v2 (two 256-thread workgroups per CU, 256 VGPRs each, 2 x 80 KiB of LDS: nothing left on chip)
 // parks those 128 KiB per workgroup in a global staging block and reads them back transposed: + 8 B per sample through the
 // L2 -> fabric counters, 1.89x the algorithmic bytes with the run-start re-reads.  Here a CU runs ONE workgroup whose waves are
-// a two-stage pipeline (the structure of k_run256v3):
-//   FRONT waves 0-3 (thread j = branches j + 256 q): tile DMA, DC blocker, pre-mix, FIR of tile t     -> X(t) in the tile's buffer
-//   BACK  waves 4-7 (wave f = frame f; thread kk):   DFT passes 1 + 2 of tile t-1, pass 3 + freqdem of tile t-2
-// The front waves carry the 13-frame window (104 VGPRs) and, now that the DFT is not theirs, the 56 taps + phasors of their four
-// branches (v2 re-reads them per tile); the back waves have no window, so the 8 tiles x 4 channels x 4 frames a thread produces
-// per block wait in 128 VGPRs.  When the block is complete a wave turns its 64 rows x 128 bytes through its own 8 KiB of the
-// tile buffer it has just consumed (its pass-3 reads cover exactly 2 KiB of each frame block: no barrier) and stores whole
-// lines, eight lanes per row.  No staging block, no read-back; runs are twice as long (one per CU), so the read-only run-start
-// tiles halve as well.  Runs start and end on 8-tile blocks (the launcher takes calls of nf = 0 mod 32 frames).
+// a two-stage pipeline (the structure of k_run256v3), three tiles deep:
+//   FRONT waves 0-3 (thread j = branches j + 256 q; wave f = frame f in pass 1): DC blocker, pre-mix, FIR of tile s -> X(s) in the
+//                   tile's buffer; DFT pass 1 of tile s-1
+//   BACK  waves 4-7 (wave f = frame f; thread kk): tile DMA; DFT pass 2 of tile s-1; pass 3 + freqdem of tile s-2; row stores
+// The front waves carry the window -- a ring of 16 frames x 4 branches in registers, the step unrolled four times, so the window never
+// moves (k_run1024v2: 52 v_mov per tile) -- and re-read their taps per step as v2 does; the back waves have no window, so the 8 tiles x 4
+// channels x 4 frames a thread produces per block wait in 128 VGPRs.  When the block is complete a wave turns its 64 rows x 128 bytes
+// through its own 8 KiB of the tile buffer it has just consumed (its pass-3 reads cover exactly 2 KiB of each frame block: no barrier)
+// and stores whole lines, eight lanes per row.  No staging block, no read-back; runs are twice as long (one per CU), so the read-only
+// run-start tiles halve as well.  Runs start and end on 8-tile blocks (the launcher takes calls of nf = 0 mod 32 frames).
 //
-// A step has two workgroup barriers:        front                                back
-//   bar X  --------------------------------------------------------------------------------------------------
-//          DC scan of tile s (raw image -> y', group totals)               pass 3 + freqdem of tile s-2 [+ block flush]
-//   bar Y  --------------------------------------------------------------------------------------------------
-//          DMA of tile s+2; column layout, pre-mix, FIR -> X(s); window    passes 1 + 2 of tile s-1 (wave-private frame block)
+// A step has two workgroup barriers:        front                                      back
+//   bar P  ----------------------------------------------------------------------------------------------------------------
+//          taps of branch 0; pass 1 of tile s-1; taps of branch 1;               DMA of image s+1 (pieces 0-3); pass 3 + freqdem of
+//          DC scan of tile s (raw image -> y', group totals)                     tile s-2 [+ block flush]; DMA pieces 4-7
+//   bar Q  ----------------------------------------------------------------------------------------------------------------
+//          column layout, pre-mix, FIR -> X(s) (taps of branches 2, 3 on the way)   pass 2 of tile s-1; wait for image s+1
 // Tile i lives in buffer i % 4 from its DMA to the back waves' pass 3.  Arithmetic: k_run1024v2's, instruction for instruction.
+// Measured (CSDR_RUN1024_V3_TRACE on a -DB3_TRACE=1 build, tools/trace_run1024v3.py): a step is ~7000 cycles, the two roles within 5 %
+// of each other in both phases, i.e. each SIMD's two waves issue back to back (~1550 VALU instructions per step and SIMD); the step of
+// a completed block takes ~4000 more (128 KiB of row stores = 2048 cycles of the CU's address unit, behind the LDS turn).
+// What did not help: starting the runs of a CU group in different steps so that the blocks do not complete together (+3 %: the burst is
+// not an HBM problem), the tile DMA in the front waves' queue (in-order vmcnt: the first tap use then waits for the image).
 #include "fused_v2_common.h"
 #include <type_traits>
 
+#ifndef B3_TRACE
+#define B3_TRACE 0       // 1: s_memtime stamps of run 1's wave 0 / wave 4 per phase (12 KiB of LDS), written to Run1024v3Args::trace
+#endif
 #ifndef B3_ABLATE
 #define B3_ABLATE 0      // timing experiments only: 2 no output stores, 4 no freqdem, 8 no flush transposition (stores of registers), 16 no DFT passes 1-2,
                          // 32 no FIR, 64 no pass 3 / tail at all, 128 no window shift
@@ -54,7 +64,6 @@ struct Run1024v3Args {
     const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r'
     uint32_t nf, nb, nruns, parity0;
     unsigned long long *trace;  // debug (CSDR_RUN1024_V3_TRACE=file): s_memtime stamps of run 1's wave 0 (front) and wave 4 (back), [role][step][4]
-    uint32_t stagger;           // 1: run w > 0 walks (w >> 3) & 7 more window-refill tiles before its first output (see the kernel)
     float alpha, beta, l2beta, fm_ref, tiny;
     float b16[16];              // beta^(16 r)
     float b256[17];             // beta^(256 g)
@@ -72,7 +81,7 @@ __host__ __device__ __forceinline__ void run3_bounds(uint32_t nb, uint32_t nruns
 __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 {
     __shared__ __attribute__((aligned(16))) float2 L[B3_F2];
-    __shared__ unsigned long long trc[1536];            // debug stamps (8 KiB): collected in LDS, written out when the run is over (a global store per stamp would sit in the traced wave's vmcnt queue)
+    __shared__ unsigned long long trc[B3_TRACE ? 1536 : 1];            // debug stamps (8 KiB): collected in LDS, written out when the run is over (a global store per stamp would sit in the traced wave's vmcnt queue)
     float2 *tw1 = L + B3_TW1, *ST = L + B3_ST, *Tt = L + B3_TT, *red = ST;
     const int tid = threadIdx.x;
     const bool back = tid >= 256;                       // wave-uniform role
@@ -91,12 +100,8 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     // ------------------------------------------------------------------ run start
     // items of the run: tile tile_begin + i, i = 0 .. n_items - 1; the first nwarm only refill the window (front waves), the next
     // one (tile first - 1) is muted: FIR and DFT for its last frame, the freqdem history of the run's first sample
-    // STAGGER.  All runs are equally long and start together, so without it every CU completes its blocks in the same step: 32 MiB
-    // of lines leave in one burst (the L2s hold 4 MiB each: the stores wait for HBM), then nothing for seven steps.  Run w > 0 therefore walks
-    // phi = (w >> 3) & 7 extra refill tiles first (front waves only, no FIR): the CUs of an XCD complete their blocks in eight different steps.
-    const unsigned phi = (w == 0 || !A.stagger) ? 0u : ((w >> 3) & 7u);
-    const unsigned tile_begin = w == 0 ? first : first - B3_HALO - phi;
-    const unsigned nwarm = w == 0 ? 0u : (unsigned)(B3_HALO - 1) + phi;
+    const unsigned tile_begin = w == 0 ? first : first - B3_HALO;
+    const unsigned nwarm = w == 0 ? 0u : (unsigned)(B3_HALO - 1);
     const unsigned n_items = last - tile_begin;
     // TILE DMA: by the BACK waves (image s + 1 is requested in pieces between the arithmetic of phase P of step s and waited for at the end of
     // the step).  The front waves load their taps per step; loads return in order, so a DMA in their queue makes the first tap use wait for the
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
             const bool warm = s < nwarm;
             char *B = reinterpret_cast<char *>(L) + PH * (B3_BUF * 8);           // item s's buffer
             float2 *Bf = reinterpret_cast<float2 *>(B);
-            const bool tr = A.trace && w == 1 && tid == 0 && s < 128;
+            const bool tr = B3_TRACE && A.trace && w == 1 && tid == 0 && s < 128;
             if (tr) trc[8 * s + 4] = __builtin_amdgcn_s_memtime();
             if (tr) trc[8 * s + 5] = __builtin_amdgcn_s_memtime();
             v4f tq0[4], tq1[4], tq2[4], tq3[4];
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
             if (s0 + 2 < nsteps) fstep(s0 + 2, std::integral_constant<int, 2>());
             if (s0 + 3 < nsteps) fstep(s0 + 3, std::integral_constant<int, 3>());
         }
-        if (A.trace && w == 1 && tid == 0) for (int i = 0; i < 1024; i++) A.trace[i] = trc[i];
+        if (B3_TRACE && A.trace && w == 1 && tid == 0) for (int i = 0; i < 1024; i++) A.trace[i] = trc[i];
         if (last == A.nb) {
             if (lt == 0) A.vend_out[0] = c;
             // the next call's window: frame -d behind the last item (phase (n_items - 1) & 3) sits in slot (4 (n_items & 3) - d) & 15
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 
     for (unsigned s = 0; s < n_items + 2; s++) {
         bar();                                          // P: Z2 of item s - 2 is complete
-        const bool tr = A.trace && w == 1 && tid == 256 && s < 128;
+        const bool tr = B3_TRACE && A.trace && w == 1 && tid == 256 && s < 128;
         if (tr) trc[1024 + 4 * s + 0] = __builtin_amdgcn_s_memtime();
         // image s + 1 into the buffer item s - 3 left in phase P of the previous step: four pieces here, four behind pass 3's arithmetic
         const bool dma = s + 1 < n_items;
@@ -464,7 +469,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
         if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); trc[1024 + 4 * s + 3] = __builtin_amdgcn_s_memtime(); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of image s + 1 have landed (and the block's row stores, if this step had them)
     }
-    if (A.trace && w == 1 && tid == 256) for (int i = 1024; i < 1536; i++) A.trace[i] = trc[i];
+    if (B3_TRACE && A.trace && w == 1 && tid == 256) for (int i = 1024; i < 1536; i++) A.trace[i] = trc[i];
     if (last == A.nb) {                                 // a thread reads back what it wrote
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++) A.rp_out[lt + 256 * k3] = ST[4 * lt + k3];
@@ -480,7 +485,6 @@ int run1024_v3_launch(const Run1024v2Host &h, uint32_t nruns, hipStream_t s, Ker
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
     A.rp_in = h.rp_in; A.rp_out = h.rp_out;
     A.nf = h.nf; A.nb = h.nf / B3_T4; A.nruns = nruns; A.parity0 = h.parity0;
-    { static const bool st = !(getenv("CSDR_RUN1024_V3_STAGGER") && atoi(getenv("CSDR_RUN1024_V3_STAGGER")) == 0); A.stagger = st ? 1u : 0u; }
     const double beta = h.dc_block ? h.beta : 0.0;
     A.alpha = h.dc_block ? (float)(1.0 - beta) : 0.0f; A.beta = (float)beta; A.l2beta = h.dc_block ? (float)std::log2(beta) : -1000.0f;
     for (int i = 0; i < 16; i++) A.b16[i] = (float)std::pow(beta, 16.0 * i);

@@ -58,6 +58,25 @@ def test_run256v3_has_no_register_spills_and_fits_one_workgroup_per_cu(tmp_path)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_run1024v3_has_no_register_spills_and_fits_one_workgroup_per_cu(tmp_path):
+    """k_run1024v3 (512 threads, front / back wave roles, 128 VGPRs of staged output lines in the back waves, a 128-register window ring
+    in the front waves): two waves per SIMD means 256 VGPRs, and anything hipcc spills lands in the tile loop -- a scratch load in the
+    front waves' queue would wait for nothing they own, one in the back waves' queue for the tile DMA.  Its asm DMA reads scalar bases:
+    no SGPR spills either (v_readlane -> VMEM hazard, fused_v2_common.h).  Static LDS: four tile buffers within a CU's 160 KiB."""
+    src = os.path.join(ROOT, "composable_sdr_amd", "csrc")
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", os.path.join(src, "kernels_run1024_v3.hip"),
+                          "-o", str(tmp_path / "b3.o"), "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = [b for b in re.split(r"remark: Function Name: ", out.stderr)[1:] if "k_run1024v3" in b.splitlines()[0]]
+    assert len(blocks) == 1
+    b = blocks[0]
+    assert int(re.search(r"SGPRs Spill: (\d+)", b).group(1)) == 0 and int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, b[:600]
+    assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0
+    assert int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)) <= 160 * 1024
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_agc_spec_tm_keeps_its_block_registers_out_of_scratch(tmp_path):
     """k_agc_spec_tm's gain wave holds two blocks of 16 samples in registers (software pipeline).  As reference parameters of a
     lambda hipcc put those arrays into scratch memory (found in round 4: 256 bytes of private segment, a scratch round trip per

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Phase times of k_run1024v3 (s_memtime stamps of run 1: front wave 0, back wave 4; CSDR_RUN1024_V3_TRACE): per step, the cycles
-between bar X and the end of phase 1, the wait at bar Y, phase 2 and the wait at the next bar X, for both roles."""
+of phase P's work, the wait at bar Q, phase Q's work and what lies between it and bar P, for both roles.  Needs a library whose
+kernels_run1024_v3.hip was built with -DB3_TRACE=1: tools/build_variant.sh b3trace kernels_run1024_v3.hip -DB3_TRACE=1, then
+CSDR_LIB=$PWD/composable_sdr_amd/variants/libcsdr_b3trace.so python tools/trace_run1024v3.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
