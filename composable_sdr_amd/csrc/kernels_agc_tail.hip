@@ -831,6 +831,7 @@ int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (const char *e = getenv("CSDR_CUS")) { if (atoi(e) > 0 && atoi(e) < cus) cus = atoi(e); }      // experiments: a plan sized for a CU-masked stream
         // k_agc_spec: two waves per workgroup at <= 256 VGPRs -> two waves per SIMD -> four workgroups per CU
         p->wg_slots = (uint32_t)cus * 4u;
         if (const char *e = getenv("CSDR_AGC_WGS")) p->wg_slots = (uint32_t)cus * (uint32_t)(atol(e) > 0 ? atol(e) : 1);

@@ -455,6 +455,7 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (const char *e = getenv("CSDR_CUS")) { if (atoi(e) > 0 && atoi(e) < cus) cus = atoi(e); }      // experiments: a plan sized for a CU-masked stream
         p->cus = (uint32_t)cus;
         p->resident_wgs_v2 = (uint32_t)(cus * run256_v2_blocks_per_cu(cfg.fm));
         if (const char *e = getenv("CSDR_RESIDENT_WGS")) p->resident_wgs_v2 = (uint32_t)atol(e);

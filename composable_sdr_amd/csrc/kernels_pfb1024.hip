@@ -550,12 +550,13 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         // CF32 output (DeNo, AGC / AM tails) stays with k_run1024: staged through HBM twice, k_run1024v2<CF32> moves 2.3 GB per
         // 67 M samples and takes 405-415 us against 384 us (FM: 366 against 454); CSDR_RUN1024_V2_ALL=1 selects it anyway
         p->v2_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && !getenv("CSDR_RUN1024_V1") && (cfg.fm || getenv("CSDR_RUN1024_V2_ALL"));
-        // FM, whole band, calls of whole 32-frame blocks: k_run1024v3 (282 us against k_run1024v2's 352, no staging block; CSDR_RUN1024_V3=0 for the comparison)
-        p->v3_ok = p->v2_ok && cfg.fm && cfg.G == 1 && !(getenv("CSDR_RUN1024_V3") && atoi(getenv("CSDR_RUN1024_V3")) == 0);
+        // whole band, calls of whole output lines: k_run1024v3 (FM: 282 us against k_run1024v2's 352, no staging block; CSDR_RUN1024_V3=0 for the comparison)
+        p->v3_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && cfg.G == 1 && !getenv("CSDR_RUN1024_V1") && !(getenv("CSDR_RUN1024_V3") && atoi(getenv("CSDR_RUN1024_V3")) == 0);
         if (cfg.G > 1) p->v2_ok = cfg.fm && !getenv("CSDR_RUN1024_V1");       // k_run1024v2<FM, G>; CF32 shards: whole band + row gather (below)
         // until the first call: the kernel a call of max_nf frames would take (csdr_chain_path names it)
         p->v2_last = p->v2_ok && (cfg.max_nf & 3u) == 0 && run1024_v2_runs(cfg.max_nf, p->cus) != 0;
-        p->v3_last = p->v2_last && p->v3_ok && run1024_v3_runs(cfg.max_nf, p->cus) != 0;
+        p->v3_last = p->v3_ok && run1024_v3_runs(cfg.max_nf, cfg.fm, p->cus) != 0;
+        if (p->v3_last) p->v2_last = false;
     }
     *out = p;
     return 0;
@@ -575,7 +576,7 @@ int big_reset(BigPlan *p, hipStream_t s)
 void big_seek(BigPlan *p, uint64_t frames) { p->frames_done = frames; }
 const char *big_name(const BigPlan *p)
 {
-    if (p->v3_last) return "k_run1024v3";
+    if (p->v3_last) return p->cfg.fm ? "k_run1024v3<FM>" : "k_run1024v3<CF32>";
     if (p->v2_last) return p->cfg.fm ? "k_run1024v2<FM>" : "k_run1024v2<CF32>";
     return p->cfg.fm ? "k_run1024<FM>" : "k_run1024<CF32>";
 }
@@ -588,9 +589,10 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     int r;
     const uint32_t v2runs = (p->v2_ok && (nf & 3u) == 0 && (uint64_t)nf * 8192u < (1ull << 31)) ? run1024_v2_runs(nf, p->cus) : 0;
     p->v2_last = v2runs != 0;
-    const uint32_t v3runs = (v2runs && p->v3_ok && c.fm && c.G == 1) ? run1024_v3_runs(nf, p->cus) : 0;
+    const uint32_t v3runs = (p->v3_ok && (uint64_t)nf * 8192u < (1ull << 31)) ? run1024_v3_runs(nf, c.fm, p->cus) : 0;
     p->v3_last = v3runs != 0;
-    if (v2runs) {
+    if (v3runs) p->v2_last = false;
+    if (v2runs || v3runs) {
         Run1024v2Host H{};
         H.x = call.d_in; H.out = c.mix ? p->d_premix : call.d_out; H.taps_q = p->d_taps_q; H.tw = p->d_tw;
         H.uhist_in = p->d_uhist[p->cur]; H.uhist_out = p->d_uhist[p->cur ^ 1];
@@ -600,7 +602,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
         H.G = c.G; H.g = c.G > 1 ? c.c0 : 0u;
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
-        if (v3runs) { if ((r = run1024_v3_launch(H, v3runs, s, timer))) return r; }
+        if (v3runs) { if ((r = run1024_v3_launch(H, c.fm, v3runs, s, timer))) return r; }
         else if ((r = run1024_v2_launch(H, c.fm, s, timer))) return r;
         p->cur ^= 1;
         p->frames_done += nf;

@@ -46,7 +46,8 @@
 namespace csdr {
 namespace {
 
-constexpr int B3_M = 1024, B3_T4 = 4, B3_NBUF = 4, B3_TB = 8;
+constexpr int B3_M = 1024, B3_T4 = 4, B3_NBUF = 4;
+constexpr int B3_TBF = 8, B3_TBC = 4;            // tiles per block = a row's 128-byte line: 32 F32 / 16 CF32 frames
 constexpr int B3_BUF = 4096;                       // float2 per tile buffer (32 KiB)
 constexpr int B3_TW1 = B3_NBUF * B3_BUF;           // twiddles W1024^(k1 b) at [k1 - 1][b], k1 = 1..15: 960
 constexpr int B3_ST = B3_TW1 + 960;                // last Y frame of channel kk + 256 k3 at [kk][k3]: 1024 (the prologue's reduction scratch before that)
@@ -56,7 +57,7 @@ constexpr int B3_WU = 6, B3_HALO = 4;              // read-only warm-up tiles (D
 
 struct Run1024v3Args {
     const float2 *x;            // raw input of this call
-    float *out;                 // [1024][nf] F32
+    void *out;                  // [1024][nf] F32 (FM) / CF32
     const float4 *taps_q;       // k_run1024v2's table: [4 q][4 pieces][256 j] taps + even-frame phasor; behind the 64 KiB: [4 q][256 j] odd-frame phasor
     const float2 *tw;           // e^{-j 2 pi i / 1024}
     const float2 *uhist_in; float2 *uhist_out;    // [13][1024] pre-mixed, DC-blocked window before / after the call
@@ -70,16 +71,18 @@ struct Run1024v3Args {
     PhaseK pk;
 };
 
-// run w: blocks of 8 tiles, evenly
-__host__ __device__ __forceinline__ void run3_bounds(uint32_t nb, uint32_t nruns, unsigned w, unsigned &first, unsigned &last)
+// run w: blocks of TB tiles, evenly
+__host__ __device__ __forceinline__ void run3_bounds(uint32_t nb, uint32_t nruns, unsigned w, unsigned TB, unsigned &first, unsigned &last)
 {
-    const unsigned nblk = nb / B3_TB;
-    first = B3_TB * (unsigned)((unsigned long long)w * nblk / nruns);
-    last = B3_TB * (unsigned)((unsigned long long)(w + 1) * nblk / nruns);
+    const unsigned nblk = nb / TB;
+    first = TB * (unsigned)((unsigned long long)w * nblk / nruns);
+    last = TB * (unsigned)((unsigned long long)(w + 1) * nblk / nruns);
 }
 
+template <bool FM>
 __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 {
+    constexpr unsigned B3_TB = FM ? B3_TBF : B3_TBC;
     __shared__ __attribute__((aligned(16))) float2 L[B3_F2];
     __shared__ unsigned long long trc[B3_TRACE ? 1536 : 1];            // debug stamps (8 KiB): collected in LDS, written out when the run is over (a global store per stamp would sit in the traced wave's vmcnt queue)
     float2 *tw1 = L + B3_TW1, *ST = L + B3_ST, *Tt = L + B3_TT, *red = ST;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     const int lt = tid & 255, j = lt;                   // thread index inside the role; front: polyphase branches j + 256 q
     const unsigned w = blockIdx.x;
     unsigned first, last;
-    run3_bounds(A.nb, A.nruns, w, first, last);
+    run3_bounds(A.nb, A.nruns, w, B3_TB, first, last);
     const float4 *x4 = reinterpret_cast<const float4 *>(A.x);
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
     const unsigned goff = dma_offset(lt);
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     // items of the run: tile tile_begin + i, i = 0 .. n_items - 1; the first nwarm only refill the window (front waves), the next
     // one (tile first - 1) is muted: FIR and DFT for its last frame, the freqdem history of the run's first sample
     const unsigned tile_begin = w == 0 ? first : first - B3_HALO;
-    const unsigned nwarm = w == 0 ? 0u : (unsigned)(B3_HALO - 1);
+    const unsigned nwarm = w == 0 ? 0u : (unsigned)(FM ? B3_HALO - 1 : B3_HALO);      // (CF32 output has no freqdem history: the tile in front of the run only refills the window)
     const unsigned n_items = last - tile_begin;
     // TILE DMA: by the BACK waves (image s + 1 is requested in pieces between the arithmetic of phase P of step s and waited for at the end of
     // the step).  The front waves load their taps per step; loads return in order, so a DMA in their queue makes the first tap use wait for the
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     }
     if (back) {                                         // freqdem history (after the reduction scratch is done with)
 #pragma unroll
-        for (int k3 = 0; k3 < 4; k3++) ST[4 * lt + k3] = (w == 0) ? A.rp_in[lt + 256 * k3] : make_float2(0.f, 0.f);
+        for (int k3 = 0; k3 < 4; k3++) ST[4 * lt + k3] = (FM && w == 0) ? A.rp_in[lt + 256 * k3] : make_float2(0.f, 0.f);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the first image: hipcc's own waits do not know about an asm DMA)
     __syncthreads();                                    // twiddle tables, stash, image 0
@@ -363,15 +366,18 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     // block flush: my wave's 8 KiB of a consumed tile buffer = 2 KiB of each frame block (exactly what its pass-3 reads covered), as
     // 512 16-byte slots: writer lane l, piece p -> slot 8 l + (p ^ ((l >> 1) & 7)); reader instruction m, lane l -> row r = 8 m + (l >> 3),
     // piece l & 7.  Slot sigma lies at 8192 (sigma >> 7) + 2048 wave + 16 (sigma & 127).
-    const unsigned row_b = A.nf * 4u;                                           // bytes per output row
+    const unsigned row_b = A.nf * (FM ? 4u : 8u);                               // bytes per output row
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)(1024u * row_b), 0x00020000);
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-    v4f stg[B3_TB][4];                                  // my four channels' results of the block's tiles: 128 VGPRs
+    // my four channels' results of the block's tiles: per k3 a 32-float register tuple [16-byte piece of the line][4] (128 VGPRs), written at a
+    // uniform runtime index (v_movreld: the tile's position in the block lives in an SGPR) and read at constant indices by the flush
+    typedef float v32f __attribute__((ext_vector_type(32)));
+    v32f stg[4];
 #pragma unroll
-    for (int t = 0; t < B3_TB; t++)
+    for (int k3 = 0; k3 < 4; k3++)
 #pragma unroll
-        for (int k3 = 0; k3 < 4; k3++) stg[t][k3] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 32; i++) stg[k3][i] = 0.f;
 
     for (unsigned s = 0; s < n_items + 2; s++) {
         bar();                                          // P: Z2 of item s - 2 is complete
@@ -394,28 +400,42 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                 y[f][0] = (v2f){v0.x, v0.y}; y[f][1] = (v2f){v0.z, v0.w}; y[f][2] = (v2f){v1.x, v1.y}; y[f][3] = (v2f){v1.z, v1.w};
                 bfly4_v(y[f][0], y[f][1], y[f][2], y[f][3]);
             }
-            char *stp = reinterpret_cast<char *>(ST) + z2r;        // my 32 bytes of the stash: [kk][k3]
-            const v4f p01 = *reinterpret_cast<const v4f *>(stp), p23 = *reinterpret_cast<const v4f *>(stp + 16);
-            const float2 prev[4] = {make_float2(p01.x, p01.y), make_float2(p01.z, p01.w), make_float2(p23.x, p23.y), make_float2(p23.z, p23.w)};
-            *reinterpret_cast<v4f *>(stp) = (v4f){y[3][0].x, y[3][0].y, y[3][1].x, y[3][1].y};
-            *reinterpret_cast<v4f *>(stp + 16) = (v4f){y[3][2].x, y[3][2].y, y[3][3].x, y[3][3].y};
-            if (b >= first) {                           // (the muted tile in front of the run: only its last frame was wanted)
-                v4f mv[4];
-                FmK2 fkt = fk;                          // tile-local copies of the uniform scalings (SGPRs)
-                asm volatile("" : "+s"(fkt.ref), "+s"(fkt.hp), "+s"(fkt.pi), "+s"(fkt.tiny));
+            const unsigned ts = b & (B3_TB - 1u);
+            bool keep = true;
+            if (FM) {
+                char *stp = reinterpret_cast<char *>(ST) + z2r;    // my 32 bytes of the stash: [kk][k3]
+                const v4f p01 = *reinterpret_cast<const v4f *>(stp), p23 = *reinterpret_cast<const v4f *>(stp + 16);
+                const float2 prev[4] = {make_float2(p01.x, p01.y), make_float2(p01.z, p01.w), make_float2(p23.x, p23.y), make_float2(p23.z, p23.w)};
+                *reinterpret_cast<v4f *>(stp) = (v4f){y[3][0].x, y[3][0].y, y[3][1].x, y[3][1].y};
+                *reinterpret_cast<v4f *>(stp + 16) = (v4f){y[3][2].x, y[3][2].y, y[3][3].x, y[3][3].y};
+                keep = b >= first;                      // (the muted tile in front of the run: only its last frame was wanted)
+                if (keep) {
+                    v4f mv[4];
+                    FmK2 fkt = fk;                      // tile-local copies of the uniform scalings (SGPRs)
+                    asm volatile("" : "+s"(fkt.ref), "+s"(fkt.hp), "+s"(fkt.pi), "+s"(fkt.tiny));
+#pragma unroll
+                    for (int k3 = 0; k3 < 4; k3++) {
+                        const float2 rp[4] = {prev[k3], to_f2(y[0][k3]), to_f2(y[1][k3]), to_f2(y[2][k3])};
+                        const float2 rr[4] = {to_f2(y[0][k3]), to_f2(y[1][k3]), to_f2(y[2][k3]), to_f2(y[3][k3])};
+                        float mq[4];
+                        if (B3_ABLATE & 4) { mq[0] = rp[0].x + rr[0].y; mq[1] = rp[1].y + rr[1].x; mq[2] = rp[2].x + rr[2].y; mq[3] = rp[3].y + rr[3].x; }
+                        else fm_quad(rp, rr, fkt, mq);
+                        mv[k3] = (v4f){mq[0], mq[1], mq[2], mq[3]};
+                    }
+#pragma unroll
+                    for (int k3 = 0; k3 < 4; k3++) {
+                        stg[k3][4 * ts + 0] = mv[k3].x; stg[k3][4 * ts + 1] = mv[k3].y; stg[k3][4 * ts + 2] = mv[k3].z; stg[k3][4 * ts + 3] = mv[k3].w;
+                    }
+                }
+            } else {
+                // CF32: a tile is 32 bytes of a row = pieces 2 ts and 2 ts + 1 of its line
 #pragma unroll
                 for (int k3 = 0; k3 < 4; k3++) {
-                    const float2 rp[4] = {prev[k3], to_f2(y[0][k3]), to_f2(y[1][k3]), to_f2(y[2][k3])};
-                    const float2 rr[4] = {to_f2(y[0][k3]), to_f2(y[1][k3]), to_f2(y[2][k3]), to_f2(y[3][k3])};
-                    float mq[4];
-                    if (B3_ABLATE & 4) { mq[0] = rp[0].x + rr[0].y; mq[1] = rp[1].y + rr[1].x; mq[2] = rp[2].x + rr[2].y; mq[3] = rp[3].y + rr[3].x; }
-                    else fm_quad(rp, rr, fkt, mq);
-                    mv[k3] = (v4f){mq[0], mq[1], mq[2], mq[3]};
+#pragma unroll
+                    for (int f = 0; f < 4; f++) { stg[k3][8 * ts + 2 * f] = y[f][k3].x; stg[k3][8 * ts + 2 * f + 1] = y[f][k3].y; }
                 }
-                const unsigned ts = b & (B3_TB - 1u);
-#define B3_KEEP(T) case T: stg[T][0] = mv[0]; stg[T][1] = mv[1]; stg[T][2] = mv[2]; stg[T][3] = mv[3]; break;
-                switch (ts) { B3_KEEP(0) B3_KEEP(1) B3_KEEP(2) B3_KEEP(3) B3_KEEP(4) B3_KEEP(5) B3_KEEP(6) default: B3_KEEP(7) }
-#undef B3_KEEP
+            }
+            if (keep) {
                 if (ts == B3_TB - 1u && !(B3_ABLATE & 2)) {
                     // ---- the block is complete: every row's 128 bytes leave in one piece
                     char *Bw = const_cast<char *>(B);
@@ -425,17 +445,17 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                     const unsigned fl_r0 = 2048u * wave_u + 128u * (unsigned)(lf >> 3) + 16u * (unsigned)((lf & 7) ^ (lf >> 4));                           // m even: + 8192 (m >> 1)
                     const unsigned fl_r1 = 2048u * wave_u + 1024u + 128u * (unsigned)(lf >> 3) + 16u * (unsigned)((lf & 7) ^ (4 + (lf >> 4)));            // m odd
                     const unsigned st_v = (64u * wave_u + (unsigned)(lf >> 3)) * row_b + 16u * (unsigned)(lf & 7);
-                    const unsigned o0 = 16u * (b - (B3_TB - 1u));                // the block's first frame in a row, bytes
+                    const unsigned o0 = (FM ? 16u : 32u) * (b - (B3_TB - 1u));   // the block's first frame in a row, bytes
 #pragma unroll
                     for (int k3 = 0; k3 < 4; k3++) {
                         if (B3_ABLATE & 8) {
 #pragma unroll
                             for (int m = 0; m < 8; m++)
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, stg[m][k3]), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * row_b), 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){stg[k3][4 * m], stg[k3][4 * m + 1], stg[k3][4 * m + 2], stg[k3][4 * m + 3]}), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * row_b), 0);
                             continue;
                         }
 #pragma unroll
-                        for (int p = 0; p < 8; p++) *reinterpret_cast<v4f *>(Bw + (fl_w ^ (unsigned)(p << 4))) = stg[p][k3];
+                        for (int p = 0; p < 8; p++) *reinterpret_cast<v4f *>(Bw + (fl_w ^ (unsigned)(p << 4))) = (v4f){stg[k3][4 * p], stg[k3][4 * p + 1], stg[k3][4 * p + 2], stg[k3][4 * p + 3]};
 #pragma unroll
                         for (int m = 0; m < 8; m++) {
                             const v4f v = *reinterpret_cast<const v4f *>(Bw + ((m & 1) ? fl_r1 : fl_r0) + 8192 * (m >> 1));
@@ -470,7 +490,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // my pieces of image s + 1 have landed (and the block's row stores, if this step had them)
     }
     if (B3_TRACE && A.trace && w == 1 && tid == 256) for (int i = 1024; i < 1536; i++) A.trace[i] = trc[i];
-    if (last == A.nb) {                                 // a thread reads back what it wrote
+    if (FM && last == A.nb) {                           // a thread reads back what it wrote
 #pragma unroll
         for (int k3 = 0; k3 < 4; k3++) A.rp_out[lt + 256 * k3] = ST[4 * lt + k3];
     }
@@ -478,10 +498,10 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 
 }  // namespace
 
-int run1024_v3_launch(const Run1024v2Host &h, uint32_t nruns, hipStream_t s, KernelTimer *timer)
+int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_t s, KernelTimer *timer)
 {
     Run1024v3Args A{};
-    A.x = h.x; A.out = (float *)h.out; A.taps_q = h.taps_q; A.tw = h.tw;
+    A.x = h.x; A.out = h.out; A.taps_q = h.taps_q; A.tw = h.tw;
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
     A.rp_in = h.rp_in; A.rp_out = h.rp_out;
     A.nf = h.nf; A.nb = h.nf / B3_T4; A.nruns = nruns; A.parity0 = h.parity0;
@@ -498,7 +518,8 @@ int run1024_v3_launch(const Run1024v2Host &h, uint32_t nruns, hipStream_t s, Ker
     if (trace_file) { CSDR_HIP(hipMemsetAsync(d_trace, 0, 1536 * sizeof(unsigned long long), s)); A.trace = d_trace; }
     int r;
     if (timer && (r = timer->begin(s))) return r;
-    hipLaunchKernelGGL(k_run1024v3, dim3(nruns), dim3(512), 0, s, A);
+    if (fm) hipLaunchKernelGGL((k_run1024v3<true>), dim3(nruns), dim3(512), 0, s, A);
+    else hipLaunchKernelGGL((k_run1024v3<false>), dim3(nruns), dim3(512), 0, s, A);
     if (timer && (r = timer->end(s))) return r;
     CSDR_HIP(hipGetLastError());
     if (trace_file) {                                   // debug: the last launch's stamps, raw uint64: front [128][8], back [128][4]
@@ -510,9 +531,10 @@ int run1024_v3_launch(const Run1024v2Host &h, uint32_t nruns, hipStream_t s, Ker
     return 0;
 }
 
-uint32_t run1024_v3_runs(uint32_t nf, uint32_t cus)
+uint32_t run1024_v3_runs(uint32_t nf, bool fm, uint32_t cus)
 {
-    // one workgroup per CU; runs are whole 8-tile blocks (a row's 128-byte line); a run >= 1 spends 6 read-only + 4 halo tiles on its
+    const uint32_t B3_TB = fm ? B3_TBF : B3_TBC;
+    // one workgroup per CU; runs are whole blocks of 8 (F32) / 4 (CF32) tiles (a row's 128-byte line); a run >= 1 spends 6 read-only + 4 halo tiles on its
     // start state: at least four blocks per run
     if (nf % (B3_T4 * B3_TB)) return 0;
     const uint32_t nblk = nf / (B3_T4 * B3_TB);

@@ -1529,31 +1529,47 @@ def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatc
     a.close(); b.close()
 
 
-def test_run1024_v3_matches_second_generation_kernel_and_oracle(monkeypatch):
-    """k_run1024v3 (one 512-thread workgroup per CU, front / back wave roles, a row's 128-byte line staged in registers: FM, whole
-    band, calls of nf % 32 == 0) against k_run1024v2 and the oracle.  Calls: 5 frames (odd: first-generation kernel, leaves the NCO
-    parity odd and a non-trivial DC state, window and r'), 4096 (v3: 32 runs of 4 blocks with warm-up, halo and muted tile), 516
-    (nf % 32 != 0: k_run1024v2 picks up v3's state), 2048 (v3 again: 16 runs, picks up v2's state), 1200 (v2)."""
+@pytest.mark.parametrize("demod", ["fm", "none"])
+def test_run1024_v3_matches_second_generation_kernel_and_oracle(demod, monkeypatch):
+    """k_run1024v3 (one 512-thread workgroup per CU, front / back wave roles, a row's 128-byte line staged in registers: whole band,
+    calls of whole lines = nf % 32 == 0 F32 / nf % 16 == 0 CF32) against the older kernels and the oracle.  Calls: 5 frames (odd:
+    first-generation kernel, leaves the NCO parity odd and a non-trivial DC state, window and r'), 4096 (v3: 32 runs of 4 blocks with
+    warm-up, halo and muted tile), 516 (not whole lines: k_run1024v2 / k_run1024 picks up v3's state), 2048 (v3 again, picks up
+    their state), 1200 (FM: v2; CF32: 1200 % 16 == 0, v3 with 18 runs)."""
     M = 1024
     frames = [5, 4096, 516, 2048, 1200]
     nf = sum(frames)
     x = synth_cf32(M * nf, M, seed=79)
     x = (x + np.complex64(0.01 - 0.005j)).astype(np.complex64)    # a DC offset the blocker has to remove across run starts
-    kw = dict(channels=M, demod="fm", kf=0.3, max_frames=max(frames))
+    kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames))
     a = cs.Chain(**kw)                                            # default: k_run1024v3 where it applies
     monkeypatch.setenv("CSDR_RUN1024_V3", "0")
     b = cs.Chain(**kw)
     monkeypatch.delenv("CSDR_RUN1024_V3")
-    orc = O.Chain(M, demod="fm", kf=0.3)
+    orc = O.Chain(M, demod=demod, kf=0.3)
     ga, gb, wo, pos, names = [], [], [], 0, []
     for f in frames:
         xa = x[pos * M:(pos + f) * M]
         ga.append(a.process(xa)); gb.append(b.process(xa)); wo.append(orc.process(xa)); pos += f
         names.append((a.kernel_time()[0], b.kernel_time()[0]))
     print("kernels:", names)
-    assert [n[0] for n in names] == ["k_run1024<FM>", "k_run1024v3", "k_run1024v2<FM>", "k_run1024v3", "k_run1024v2<FM>"]
+    if demod == "fm":
+        assert [n[0] for n in names] == ["k_run1024<FM>", "k_run1024v3<FM>", "k_run1024v2<FM>", "k_run1024v3<FM>", "k_run1024v2<FM>"]
+    else:
+        assert [n[0] for n in names] == ["k_run1024<CF32>", "k_run1024v3<CF32>", "k_run1024<CF32>", "k_run1024v3<CF32>", "k_run1024v3<CF32>"]
     assert all("v3" not in n[1] for n in names)
     ga, gb, wo = [np.concatenate(v, axis=1) for v in (ga, gb, wo)]
+    if demod == "none":
+        print(f"run1024v3 DeNo: vs v1 {rel_rms(ga, gb):.2e}, vs oracle {rel_rms(ga, wo):.2e}")
+        assert rel_rms(ga, gb) < 2e-6 and rel_rms(ga, wo) < 1e-5
+        pos = 0
+        for f in frames:                                          # every call on its own (a wrong hand-over shows in the call behind it)
+            assert rel_rms(ga[:, pos:pos + f], wo[:, pos:pos + f]) < 1e-5, f
+            pos += f
+        blk = np.abs(ga - wo)[:, 5:5 + 4096].reshape(M // 64, 64, -1, 16)          # every row block and every 16-frame line of the first v3 call
+        assert blk.max(axis=(1, 3)).max() < 1e-4 * np.abs(wo).max()
+        a.close(); b.close()
+        return
     d1 = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / 0.3))
     d2 = np.abs(wrap_pm(ga.astype(np.float64) - wo, 1.0 / 0.3))
     print(f"run1024v3 FM: vs v2 median {np.median(d1):.2e} p99.9 {np.quantile(d1, 0.999):.2e} max {d1.max():.2e}; "
@@ -1752,7 +1768,7 @@ def test_bench_layout_cfg4_shape_1024ch_fm_whole_chunk_matches_oracle():
     """k_run1024v3 at 1024 x 65 536 (BASELINE configs[3] shape on one GPU) against O.Chain, every sample."""
     M, nf, kf = 1024, 65536, 0.3
     got, xh, kname, path = _bench_layout(M, nf, 33, demod="fm", kf=kf)
-    assert kname == "k_run1024v3", (kname, path)
+    assert kname == "k_run1024v3<FM>", (kname, path)
     r = np.abs(_bench_layout(M, nf, 33)[0])
     _fm_against_oracle(got, xh, M, kf, f"cfg4 shape {kname}", r)
 
