@@ -103,7 +103,7 @@ def cpu_baseline(M, demod, kf, agc, x_host, seconds, mix=False):
         budget = max(2.0, seconds / 3)
         worker = (
             "import sys,time,os;sys.path.insert(0,%r);sys.path.insert(0,%r);import numpy as np,oracle_lib as O;from synth import synth_cf32;"
-            "M=%d;x=synth_cf32(4096*M,M,seed=1000+int(sys.argv[1]));c=O.Chain(M,dc_block=True,agc_db=%r,demod=%r,kf=%r,mix=%r);"
+            "M=%d;Ms=min(M,256);x=np.tile(synth_cf32(4096*Ms,Ms,seed=1000+int(sys.argv[1])),M//Ms) if M%%Ms==0 else synth_cf32(4096*M,M,seed=1000+int(sys.argv[1]));c=O.Chain(M,dc_block=True,agc_db=%r,demod=%r,kf=%r,mix=%r);"
             "t_go=float(sys.argv[2]);n=0\n"
             "while time.time()<t_go: time.sleep(0.01)\n"
             "t0=time.perf_counter()\n"
