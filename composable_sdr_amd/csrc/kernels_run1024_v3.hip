@@ -52,7 +52,8 @@ constexpr int B3_BUF = 4096;                       // float2 per tile buffer (32
 constexpr int B3_TW1 = B3_NBUF * B3_BUF;           // twiddles W1024^(k1 b) at [k1 - 1][b], k1 = 1..15: 960
 constexpr int B3_ST = B3_TW1 + 960;                // last Y frame of channel kk + 256 k3 at [kk][k3]: 1024 (the prologue's reduction scratch before that)
 constexpr int B3_TT = B3_ST + 1024;                // 16 group totals
-constexpr int B3_F2 = B3_TT + 16;                  // 18 384 float2 = 147 072 B: one workgroup per CU
+constexpr int B3_TW2 = B3_TT + 16;                 // pass-2 twiddles W64^(d k2) at [k2][d]: 64 (the three d of an instruction in three banks; tw1 has them 2 KiB apart)
+constexpr int B3_F2 = B3_TW2 + 64;                 // 18 448 float2 = 147 584 B: one workgroup per CU
 constexpr int B3_WU = 6, B3_HALO = 4;              // read-only warm-up tiles (DC state); 3 window-refill tiles + the muted tile in front of a run
 
 struct Run1024v3Args {
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)L + 1024u * wave_u;
 
     for (int e = tid; e < 960; e += 512) tw1[e] = A.tw[(((e >> 6) + 1) * (e & 63)) & 1023];
+    if (tid < 64) L[B3_TW2 + tid] = A.tw[(16 * (tid & 3) * (tid >> 2)) & 1023];
 
     // ------------------------------------------------------------------ run start
     // items of the run: tile tile_begin + i, i = 0 .. n_items - 1; the first nwarm only refill the window (front waves), the next
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     }
     if (back) {                                         // freqdem history (after the reduction scratch is done with)
 #pragma unroll
-        for (int k3 = 0; k3 < 4; k3++) ST[4 * lt + k3] = (FM && w == 0) ? A.rp_in[lt + 256 * k3] : make_float2(0.f, 0.f);
+        for (int k3 = 0; k3 < 4; k3++) ST[4 * lt + (k3 ^ (2 * ((lt >> 3) & 1)))] = (FM && w == 0) ? A.rp_in[lt + 256 * k3] : make_float2(0.f, 0.f);   // (halves swapped where kk & 8: see z2r)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the first image: hipcc's own waits do not know about an asm DMA)
     __syncthreads();                                    // twiddle tables, stash, image 0
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                 asm volatile("" : "+v"(b1));            // (offsets derived here: as loop invariants they would pin VGPRs next to the window)
                 const unsigned fb = 8192u * wave_u;
                 const unsigned x_a = 8u * ((16u * (b1 >> 4)) | (b1 & 1u) | (2u * ((((b1 & 15u) >> 1) ^ (b1 >> 5)) & 7u)));
-                const unsigned z1w = 128u * (b1 & 3u) + 8u * ((b1 >> 2) & 1u) + 16u * (((b1 >> 3) ^ ((b1 & 3u) >> 1)) & 7u);
+                const unsigned z1w = 128u * (b1 & 3u) + 8u * ((b1 >> 2) & 1u) + 16u * (((b1 >> 3) ^ ((b1 & 3u) >> 1) ^ (((b1 & 3u) >> 1) << 2)) & 7u);
                 v2f vv[16];
 #pragma unroll
                 for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B1 + fb + 512 * a + (x_a ^ (unsigned)((a & 3) << 5))));
@@ -358,11 +360,15 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     const FmK2 fk = {{A.pk.c[0], A.pk.c[1], A.pk.c[2], A.pk.c[3], A.pk.c[4], A.pk.c[5], A.pk.c[6], A.pk.c[7]}, A.tiny, A.fm_ref, A.pk.hp, A.pk.pi};
     const unsigned fb = 8192u * wave_u;                                         // passes 1-2: my wave's frame block
     // (pass 1, front waves: X[f][64 a + b1] sits at fb + 512 a + (x_a ^ ((a & 3) << 5)), the column layout of the raw image; Z1[k1][b = 4 c + d] is
-    // written to fb + 512 k1 + (z1w ^ (((2 k1) & 6) << 4)) so that reader lane l2 = 4 k1 + d sees its 16 values as eight swizzled 16-byte pairs)
+    // written to fb + 512 k1 + (z1w ^ (((2 k1) & 6) << 4)) so that reader lane l2 = 4 k1 + d sees its 16 values as eight swizzled 16-byte pairs;
+    // the swizzle of a reader row, ((l2 >> 1) & 7) ^ (4 for d >= 2), keeps the b128 reads conflict-free and puts the rows d and d + 2 that a writer's
+    // 32-lane half touches into different bank quarters: tools/lds_conflicts_run1024v3.py)
     const int l2 = lt & 63, d2 = l2 & 3;                                        // pass 2: k1 = l2 >> 2, d = l2 & 3
-    const unsigned z1r = fb + (unsigned)l2 * 128u + ((unsigned)((l2 >> 1) & 7) << 4);    // pair i: z1r ^ (i << 4)
-    const unsigned z2w = fb + 8u * (unsigned)l2;                                // Z2[k1][k2][d] at 4 (k1 + 16 k2) + d: + 512 k2
-    const unsigned z2r = 32u * (unsigned)lt;                                    // pass 3: thread kk reads 4 d's of frame f at 8192 f + 32 kk
+    const unsigned z1r = fb + (unsigned)l2 * 128u + ((unsigned)(((l2 >> 1) & 7) ^ (((l2 >> 1) & 1) << 2)) << 4);    // pair i: z1r ^ (i << 4)
+    // Z2[k1][k2][d]: thread kk = k1 + 16 k2 of pass 3 owns the 32 bytes at 32 kk; its two 16-byte halves are swapped where kk & 8, so that the
+    // sixteen lanes a b128 read is served with cover all 64 banks (unswapped: 32-byte stride, two-way conflict)
+    const unsigned z2w = fb + 32u * (unsigned)(l2 >> 2) + 16u * (unsigned)(((l2 >> 1) & 1) ^ ((l2 >> 5) & 1)) + 8u * (unsigned)(l2 & 1);     // + 512 k2
+    const unsigned z2r = 32u * (unsigned)lt + 16u * (unsigned)((lt >> 3) & 1);   // pass 3: thread kk reads d = 0, 1 of frame f at 8192 f + z2r, d = 2, 3 at (8192 f + z2r) ^ 16
     // block flush: my wave's 8 KiB of a consumed tile buffer = 2 KiB of each frame block (exactly what its pass-3 reads covered), as
     // 512 16-byte slots: writer lane l, piece p -> slot 8 l + (p ^ ((l >> 1) & 7)); reader instruction m, lane l -> row r = 8 m + (l >> 3),
     // piece l & 7.  Slot sigma lies at 8192 (sigma >> 7) + 2048 wave + 16 (sigma & 127).
@@ -396,18 +402,19 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 #pragma unroll
             for (int f = 0; f < 4; f++) {
                 const v4f v0 = *reinterpret_cast<const v4f *>(B + 8192 * f + z2r);
-                const v4f v1 = *reinterpret_cast<const v4f *>(B + 8192 * f + z2r + 16);
+                const v4f v1 = *reinterpret_cast<const v4f *>(B + ((8192 * f + z2r) ^ 16u));
                 y[f][0] = (v2f){v0.x, v0.y}; y[f][1] = (v2f){v0.z, v0.w}; y[f][2] = (v2f){v1.x, v1.y}; y[f][3] = (v2f){v1.z, v1.w};
                 bfly4_v(y[f][0], y[f][1], y[f][2], y[f][3]);
             }
             const unsigned ts = b & (B3_TB - 1u);
             bool keep = true;
             if (FM) {
-                char *stp = reinterpret_cast<char *>(ST) + z2r;    // my 32 bytes of the stash: [kk][k3]
-                const v4f p01 = *reinterpret_cast<const v4f *>(stp), p23 = *reinterpret_cast<const v4f *>(stp + 16);
+                char *stp = reinterpret_cast<char *>(ST) + 32u * (unsigned)lt;    // my 32 bytes of the stash: [kk][k3], halves swapped like Z2's
+                const unsigned sth = 16u * (unsigned)((lt >> 3) & 1);
+                const v4f p01 = *reinterpret_cast<const v4f *>(stp + sth), p23 = *reinterpret_cast<const v4f *>(stp + (sth ^ 16u));
                 const float2 prev[4] = {make_float2(p01.x, p01.y), make_float2(p01.z, p01.w), make_float2(p23.x, p23.y), make_float2(p23.z, p23.w)};
-                *reinterpret_cast<v4f *>(stp) = (v4f){y[3][0].x, y[3][0].y, y[3][1].x, y[3][1].y};
-                *reinterpret_cast<v4f *>(stp + 16) = (v4f){y[3][2].x, y[3][2].y, y[3][3].x, y[3][3].y};
+                *reinterpret_cast<v4f *>(stp + sth) = (v4f){y[3][0].x, y[3][0].y, y[3][1].x, y[3][1].y};
+                *reinterpret_cast<v4f *>(stp + (sth ^ 16u)) = (v4f){y[3][2].x, y[3][2].y, y[3][3].x, y[3][3].y};
                 keep = b >= first;                      // (the muted tile in front of the run: only its last frame was wanted)
                 if (keep) {
                     v4f mv[4];
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
             fft16_v(vv);                                // vv[i] = k2 = XIDX(i)
             if (d2) {                                   // W64^(d k2); lanes d = 0 sit this out
 #pragma unroll
-                for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (4 * d2 - 1) + 4 * XIDX(i)]));
+                for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(L[B3_TW2 + 4 * XIDX(i) + d2]));
             }
 #pragma unroll
             for (int i = 0; i < 16; i++) *reinterpret_cast<float2 *>(B + z2w + 512 * XIDX(i)) = to_f2(vv[i]);
@@ -492,7 +499,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     if (B3_TRACE && A.trace && w == 1 && tid == 256) for (int i = 1024; i < 1536; i++) A.trace[i] = trc[i];
     if (FM && last == A.nb) {                           // a thread reads back what it wrote
 #pragma unroll
-        for (int k3 = 0; k3 < 4; k3++) A.rp_out[lt + 256 * k3] = ST[4 * lt + k3];
+        for (int k3 = 0; k3 < 4; k3++) A.rp_out[lt + 256 * k3] = ST[4 * lt + (k3 ^ (2 * ((lt >> 3) & 1)))];
     }
 }
 
