@@ -4,9 +4,10 @@ Model (gfx9 LDS, 64 banks x 4 B): a ds_read/write_b64 wave instruction is served
 within a group, lanes that hit the same bank at DIFFERENT addresses serialise: cost of a group = max over banks of the number of distinct
 dwords addressed in it.  Prints, per access, the cycles per wave instruction and the conflict-free minimum."""
 import sys
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 32      # LDS banks (x 4 bytes per cycle): 32 on CDNA3 / 4 (128 B per clock), the counters agree with that
 
 def cost(addrs, width):                       # addrs: byte address per lane (64), width: 8 or 16
-    per = {8: 32, 16: 16}[width]
+    per = {8: 32 * NB // 64, 16: 16 * NB // 64}[width]
     total = 0
     for g in range(0, 64, per):
         banks = {}
@@ -15,7 +16,7 @@ def cost(addrs, width):                       # addrs: byte address per lane (64
             if a is None: continue
             for w in range(width // 4):
                 dw = a // 4 + w
-                banks.setdefault(dw % 64, set()).add(dw)
+                banks.setdefault(dw % NB, set()).add(dw)
         total += max((len(v) for v in banks.values()), default=0)
     return total
 
@@ -23,7 +24,7 @@ def report(name, fn, width, count, variants):
     worst = 0; tot = 0
     for v in variants:
         c = cost([fn(l, v) for l in range(64)], width); tot += c; worst = max(worst, c)
-    ideal = 64 * width // 256
+    ideal = 64 * width // (4 * NB)
     print(f"{name:46s} b{width * 8:<3d} x{count:3d}/thread/tile: {tot / len(variants):5.2f} cycles per instruction (ideal {ideal}), worst {worst}")
     return tot / len(variants) * count, ideal * count
 

@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
 """Static LDS bank-conflict count of k_run256v2<FM>'s access patterns (whole band), same model as tools/lds_conflicts_run1024v3.py."""
+import sys
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 def cost(addrs, width):
-    per = {8: 32, 16: 16}[width]; total = 0
+    per = {8: 32 * NB // 64, 16: 16 * NB // 64}[width]; total = 0
     for g in range(0, 64, per):
         banks = {}
         for l in range(g, g + per):
             a = addrs[l]
             if a is None: continue
             for w in range(width // 4):
-                dw = a // 4 + w; banks.setdefault(dw % 64, set()).add(dw)
+                dw = a // 4 + w; banks.setdefault(dw % NB, set()).add(dw)
         total += max((len(v) for v in banks.values()), default=0)
     return total
 def report(name, fn, width, count, variants):
     tot = 0; worst = 0
     for v in variants:
         c = cost([fn(l, v) for l in range(64)], width); tot += c; worst = max(worst, c)
-    ideal = 64 * width // 256
+    ideal = 64 * width // (4 * NB)
     print(f"{name:52s} b{width * 8:<3d} x{count:3d}/thread/tile: {tot / len(variants):5.2f} cycles per instruction (ideal {ideal}), worst {worst}")
     return tot / len(variants) * count, ideal * count
 W = range(4); acc = []
