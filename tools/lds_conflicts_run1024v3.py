@@ -4,7 +4,7 @@ Model (gfx9 LDS, 64 banks x 4 B): a ds_read/write_b64 wave instruction is served
 within a group, lanes that hit the same bank at DIFFERENT addresses serialise: cost of a group = max over banks of the number of distinct
 dwords addressed in it.  Prints, per access, the cycles per wave instruction and the conflict-free minimum."""
 import sys
-NB = int(sys.argv[1]) if len(sys.argv) > 1 else 32      # LDS banks (x 4 bytes per cycle): 32 on CDNA3 / 4 (128 B per clock), the counters agree with that
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 64      # LDS banks of the model (64: the model whose four findings the SQ counters confirmed; 32: stricter, names the b128 accesses too)
 
 def cost(addrs, width):                       # addrs: byte address per lane (64), width: 8 or 16
     per = {8: 32 * NB // 64, 16: 16 * NB // 64}[width]

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static LDS bank-conflict count of k_run256v2<FM>'s access patterns (whole band), same model as tools/lds_conflicts_run1024v3.py."""
 import sys
-NB = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 def cost(addrs, width):
     per = {8: 32 * NB // 64, 16: 16 * NB // 64}[width]; total = 0
     for g in range(0, 64, per):
