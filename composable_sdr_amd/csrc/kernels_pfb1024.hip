@@ -547,9 +547,9 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
             tq[(size_t)PM * 16 + 2 * (size_t)r] = wpre[PM + r].x; tq[(size_t)PM * 16 + 2 * (size_t)r + 1] = wpre[PM + r].y;
         }
         CSDR_HIP(hipMemcpy(p->d_taps_q, tq.data(), sizeof(float) * tq.size(), hipMemcpyHostToDevice));
-        // CF32 output (DeNo, AGC / AM tails) stays with k_run1024: staged through HBM twice, k_run1024v2<CF32> moves 2.3 GB per
-        // 67 M samples and takes 405-415 us against 384 us (FM: 366 against 454); CSDR_RUN1024_V2_ALL=1 selects it anyway
-        p->v2_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && !getenv("CSDR_RUN1024_V1") && (cfg.fm || getenv("CSDR_RUN1024_V2_ALL"));
+        // k_run1024v2: FM output only (calls of whole 4-frame tiles that are not whole 32-frame lines, and the interleaved shards); its CF32
+        // variant (measured slower than k_run1024<CF32>: 405-415 us against 384) is no longer built: k_run1024v3<CF32> takes those calls
+        p->v2_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && !getenv("CSDR_RUN1024_V1") && cfg.fm;
         // whole band, calls of whole output lines: k_run1024v3 (FM: 282 us against k_run1024v2's 352, no staging block; CSDR_RUN1024_V3=0 for the comparison)
         p->v3_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && cfg.G == 1 && !getenv("CSDR_RUN1024_V1") && !(getenv("CSDR_RUN1024_V3") && atoi(getenv("CSDR_RUN1024_V3")) == 0);
         if (cfg.G > 1) p->v2_ok = cfg.fm && !getenv("CSDR_RUN1024_V1");       // k_run1024v2<FM, G>; CF32 shards: whole band + row gather (below)
@@ -577,7 +577,7 @@ void big_seek(BigPlan *p, uint64_t frames) { p->frames_done = frames; }
 const char *big_name(const BigPlan *p)
 {
     if (p->v3_last) return p->cfg.fm ? "k_run1024v3<FM>" : "k_run1024v3<CF32>";
-    if (p->v2_last) return p->cfg.fm ? "k_run1024v2<FM>" : "k_run1024v2<CF32>";
+    if (p->v2_last) return "k_run1024v2<FM>";
     return p->cfg.fm ? "k_run1024<FM>" : "k_run1024<CF32>";
 }
 

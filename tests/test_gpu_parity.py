@@ -1485,7 +1485,7 @@ def test_pfb1024_fused_kernel_matches_three_kernel_route_and_oracle(demod, agc, 
     a.close(); a2.close(); b.close()
 
 
-@pytest.mark.parametrize("demod", ["fm", "none"])
+@pytest.mark.parametrize("demod", ["fm"])
 def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatch):
     """k_run1024v2 (256 threads, 4-frame tiles, two workgroups per CU: whole-band calls with nf % 4 == 0) against k_run1024
     (CSDR_RUN1024_V1) and the oracle: a 5-frame call first (odd: first-generation kernel, leaves the NCO parity odd and a
@@ -1496,10 +1496,9 @@ def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatc
     x = synth_cf32(M * nf, M, seed=77)
     x = (x + np.complex64(0.01 - 0.005j)).astype(np.complex64)    # a DC offset the blocker has to remove across run starts
     kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames))
-    monkeypatch.setenv("CSDR_RUN1024_V2_ALL", "1")               # the CF32 variant is not the default (k_run1024 is faster there)
     monkeypatch.setenv("CSDR_RUN1024_V3", "0")                   # (FM calls of whole 32-frame blocks would go to k_run1024v3)
     a = cs.Chain(**kw)
-    monkeypatch.delenv("CSDR_RUN1024_V2_ALL"); monkeypatch.delenv("CSDR_RUN1024_V3")
+    monkeypatch.delenv("CSDR_RUN1024_V3")
     monkeypatch.setenv("CSDR_RUN1024_V1", "1")
     b = cs.Chain(**kw)
     monkeypatch.delenv("CSDR_RUN1024_V1")
