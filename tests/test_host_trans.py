@@ -147,3 +147,22 @@ def test_audio_file_sink_layouts(tmp_path):
     assert struct.unpack(">4sIHHIIHH", b[12:36]) == (b"fmt ", 16, 3, 1, 44100, 176400, 4, 32)
     assert struct.unpack(">4sII", b[36:48]) == (b"fact", 4, 1000) and struct.unpack(">4sI", b[48:56]) == (b"data", 4000)
     assert np.array_equal(np.frombuffer(b[56:], dtype=">f4").astype(np.float32), x)
+
+
+def test_wav_sink_is_read_back_by_an_independent_parser(tmp_path):
+    """audioFileSink's RIFX / IEEE-float WAV through scipy.io.wavfile (a parser that is not ours): rate, dtype, frame count and every
+    sample, mono and interleaved stereo, without a warning about the chunk structure."""
+    import warnings
+    from scipy.io import wavfile
+    from composable_sdr_amd.app import audioFileSink
+    rng = np.random.default_rng(5)
+    for nch, n in ((1, 1000), (2, 777)):
+        x = rng.standard_normal(n * nch).astype(np.float32)
+        s = audioFileSink("WAV", 48000 // nch, n, nch, str(tmp_path / f"w{nch}"))
+        s.step(x[: 100 * nch]); s.step(x[100 * nch:]); s.done()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            sr, data = wavfile.read(s.path)
+        assert sr == 48000 // nch and data.dtype.kind == "f" and data.dtype.itemsize == 4
+        assert data.shape == ((n,) if nch == 1 else (n, nch))
+        assert np.array_equal(np.asarray(data, dtype=np.float32).reshape(-1), x)
