@@ -541,13 +541,14 @@ int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream
 uint32_t run1024_v3_runs(uint32_t nf, bool fm, uint32_t cus)
 {
     const uint32_t B3_TB = fm ? B3_TBF : B3_TBC;
-    // one workgroup per CU; runs are whole blocks of 8 (F32) / 4 (CF32) tiles (a row's 128-byte line); a run >= 1 spends 6 read-only + 4 halo tiles on its
-    // start state: at least four blocks per run
+    // one workgroup per CU; runs are whole blocks of 8 (F32) / 4 (CF32) tiles (a row's 128-byte line); a run >= 1 spends 6 read-only + 4 halo
+    // tiles in front of its first tile: at least 12 tiles per run (mid-sized calls, e.g. the reference's 4096-frame chunks, then get twice
+    // the runs that four blocks per run would give them)
     if (nf % (B3_T4 * B3_TB)) return 0;
-    const uint32_t nblk = nf / (B3_T4 * B3_TB);
+    const uint32_t nblk = nf / (B3_T4 * B3_TB), minb = fm ? 2u : 3u;
     uint32_t nruns = cus;
     if (const char *e = getenv("CSDR_RUN1024_V3_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
-    if (nruns > nblk / 4) nruns = nblk / 4;
+    if (nruns > nblk / minb) nruns = nblk / minb;
     return nruns;                                       // 0: too short (or ragged) for this kernel
 }
 

@@ -1532,8 +1532,8 @@ def test_run1024_v2_matches_first_generation_kernel_and_oracle(demod, monkeypatc
 def test_run1024_v3_matches_second_generation_kernel_and_oracle(demod, monkeypatch):
     """k_run1024v3 (one 512-thread workgroup per CU, front / back wave roles, a row's 128-byte line staged in registers: whole band,
     calls of whole lines = nf % 32 == 0 F32 / nf % 16 == 0 CF32) against the older kernels and the oracle.  Calls: 5 frames (odd:
-    first-generation kernel, leaves the NCO parity odd and a non-trivial DC state, window and r'), 4096 (v3: 32 runs of 4 blocks with
-    warm-up, halo and muted tile), 516 (not whole lines: k_run1024v2 / k_run1024 picks up v3's state), 2048 (v3 again, picks up
+    first-generation kernel, leaves the NCO parity odd and a non-trivial DC state, window and r'), 4096 (v3: 64 runs of 2 blocks F32 / 85 runs of
+    3 blocks CF32, with warm-up, halo and muted tile), 516 (not whole lines: k_run1024v2 / k_run1024 picks up v3's state), 2048 (v3 again, picks up
     their state), 1200 (FM: v2; CF32: 1200 % 16 == 0, v3 with 18 runs)."""
     M = 1024
     frames = [5, 4096, 516, 2048, 1200]
@@ -1575,7 +1575,7 @@ def test_run1024_v3_matches_second_generation_kernel_and_oracle(demod, monkeypat
           f"vs oracle median {np.median(d2):.2e} p99.9 {np.quantile(d2, 0.999):.2e}")
     assert np.median(d1) < 2e-6 and np.median(d2) < 2e-5
     assert np.quantile(d1, 0.999) < 5e-5
-    starts = d1[:, 5:5 + 4096:128]                                # 4096 frames / 32 runs: every run start of the first v3 call
+    starts = d1[:, 5:5 + 4096:64]                                 # 4096 frames / 64 runs: every run start of the first v3 call
     assert np.quantile(starts, 0.999) < 5e-5
     for lo, hi in ((5, 5 + 4096), (5 + 4096 + 516, 5 + 4096 + 516 + 2048)):      # every row block and every 32-frame line of the v3 calls
         blk = d2[:, lo:hi].reshape(M // 64, 64, -1, 32)
