@@ -305,9 +305,12 @@ __global__ __launch_bounds__(256, 2) void k_run64v2(Run64v2Args A)
 
 uint32_t run64_v2_runs(uint32_t nf, uint32_t cus)
 {
-    // two workgroups per CU; a run >= 1 reads 6 warm-up tiles and walks a halo tile: at least 16 tiles per run on average
+    // two workgroups per CU; a run >= 1 reads 6 warm-up tiles and walks a halo tile: at least 16 tiles per run on average.  A call pays
+    // those ~23 tile times (~60 us) whatever its size, so k_run64 keeps the calls below 3072 tiles (196 608 frames; measured by call size:
+    // 4096 frames 17 us against 60 us, 131 072 frames 58 against 66, 262 144 frames 99 against 76)
     if (nf % 64u) return 0;
     const uint32_t nb = nf / 64u;
+    if (nb < 3072u && !getenv("CSDR_RUN64_V2_ALL")) return 0;
     uint32_t nruns = 2 * cus;
     if (nruns > nb / 16) nruns = nb / 16;
     if (nruns > 2) nruns &= ~1u;

@@ -857,6 +857,7 @@ def test_run64_v2_matches_first_generation_kernel_and_oracle(monkeypatch):
     then 8192 frames (8 runs with warm-up and halo), a ragged call (first generation again), and 2048 more."""
     M = 64
     frames = [5, 8192, 70, 2048]
+    monkeypatch.setenv("CSDR_RUN64_V2_ALL", "1")                  # (by default k_run64v2 takes calls of >= 3072 tiles only: below that k_run64 is faster)
     x = synth_cf32(M * sum(frames), M, seed=64)
     x = (x + np.complex64(0.05 - 0.02j)).astype(np.complex64)
     kw = dict(channels=M, demod="none", max_frames=max(frames))
@@ -891,6 +892,8 @@ def test_second_generation_run_kernels_without_dc_blocker(M, demod, env, frames,
     against the first-generation kernels: without the DC scan's approximated run-start state the CF32 results are bitwise
     those of k_run64 (same FIR order, same DFT butterflies)."""
     x = synth_cf32(M * sum(frames), M, seed=3)
+    if M == 64:
+        monkeypatch.setenv("CSDR_RUN64_V2_ALL", "1")              # (k_run64v2 for calls of every size)
     kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames), dc_block=False, **extra)
     a = cs.Chain(**kw)
     monkeypatch.setenv(env, "1000000" if env == "CSDR_RUN_MIN_TILES" else "1")     # M = 256: the look-back tile kernel is the other implementation
