@@ -39,8 +39,8 @@
 #define B3_TRACE 0       // 1: s_memtime stamps of run 1's wave 0 / wave 4 per phase (12 KiB of LDS), written to Run1024v3Args::trace
 #endif
 #ifndef B3_ABLATE
-#define B3_ABLATE 0      // timing experiments only: 2 no output stores, 4 no freqdem, 8 no flush transposition (stores of registers), 16 no DFT passes 1-2,
-                         // 32 no FIR, 64 no pass 3 / tail at all, 128 no window shift
+#define B3_ABLATE 0      // timing experiments only (wrong results): 2 no output stores, 4 no freqdem, 8 row stores straight out of the registers (no LDS
+                         // turn: the lines go to the wrong rows), 16 no DFT passes 1-2, 32 no FIR, 64 no pass 3 / tail at all
 #endif
 
 namespace csdr {
