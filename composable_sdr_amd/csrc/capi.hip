@@ -635,7 +635,7 @@ const RouteRow ROUTES[] = {
     {1024, ST1 | ST2 | ST4 | ST8, PLAN_BIG1024, "fused-k_run1024",
      "k_run1024v3<FM | CF32> (whole band, calls of whole 128-byte output lines = 32 F32 / 16 CF32 frames, >= 4 lines per CU run); "
      "k_run1024v2<FM[, G]> (FM output, other whole 4-frame tiles, run-sized; interleaved shards G = 2, 4, 8)",
-     "k_run1024<FM | CF32> (short and ragged calls) [+ k_pfb1024_fixup, k_shard_gather1024]", "k_run1024v3<CF32> | k_run1024<CF32> -> k_agc_spec -> k_agc_fix [-> k_mix]"},
+     "k_run1024<FM | CF32> (short and ragged calls) [+ k_pfb1024_fixup, k_shard_gather1024]", "k_run1024v3<CF32> -> CF32 plane (tile-major) -> k_agc_spec_tm | k_run1024<CF32> -> k_agc_spec; -> k_agc_fix [-> k_mix]"},
     {0, ST_ANY, PLAN_GENERIC, "generic",
      "k_dc_tile -> k_pfb_fir (M = 1024, forced generic: k_pfb1024) -> k_fft_r16 | k_fft_pow2 | k_dft_direct [interleaved shard: k_fold + (M / G)-point DFT] "
      "-> k_transpose_fm | k_mix_frames | k_transpose;  DeNo --mix over all channels: k_dc_fold + k_mixid_finish (M % 4096 == 0) | k_dc_tile + k_branch0_fir "
@@ -869,7 +869,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         if (agc_on) {
             // d_A: channel-major CF32 from the channelizer; d_B: per-channel tail output in front of --mix
             // (the fused M = 256 plans may write it tile-major for k_agc_spec_tm, which reads up to a segment in front of / behind the plane)
-            h->a_guard = h->fused ? agc_tail_tm_guard(C) : 0;
+            h->a_guard = (h->fused || h->big) ? agc_tail_tm_guard(C) : 0;
             if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf + 2 * h->a_guard))) return fail(r);
             if (h->a_guard) CSDR_HIP_CLEAN(hipMemset(h->d_A, 0, sizeof(float2) * ((size_t)C * h->max_nf + 2 * h->a_guard)), csdr_chain_destroy(h));
             if (cfg->mix && (r = dev_alloc(&h->d_B, (size_t)C * h->max_nf))) return fail(r);
@@ -1182,8 +1182,9 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         const bool agc_on = h->d_agc != nullptr, fm = h->cfg.demod == CSDR_DEMOD_FM, mixo = h->cfg.mix != 0;
         float2 *Z = (agc_on && (fm || mixo || h->agc_tail)) ? h->d_A + h->a_guard : (float2 *)d_out;
         FusedCall fcall{};
-        // AGC tail behind the fused M = 256 chain, run-sized calls of whole tiles: the plane between the two kernels is tile-major
-        const bool tm = agc_on && h->agc_tail && h->fused && Z != (float2 *)d_out && agc_tail_tm_supported(h->agc_tail, nf) && fused_tile_major_ok(h->fused, nf);
+        // AGC tail behind the fused M = 256 / M = 1024 chains, run-sized calls of whole tiles: the plane between the two kernels is tile-major
+        const bool tm = agc_on && h->agc_tail && Z != (float2 *)d_out && agc_tail_tm_supported(h->agc_tail, nf) &&
+                        (h->fused ? fused_tile_major_ok(h->fused, nf) : (h->big && big_tile_major_ok(h->big, nf)));
         fcall.tile_major = tm;
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         fcall.indep = h->call_indep; fcall.ev_tail = h->call_ev_tail;

@@ -72,6 +72,7 @@ int  big_reset(BigPlan *plan, hipStream_t s);
 int  big_process(BigPlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
 void big_seek(BigPlan *plan, uint64_t frames);
 const char *big_name(const BigPlan *plan);
+bool big_tile_major_ok(const BigPlan *plan, uint32_t nf);     // FusedCall::tile_major for this call (CF32 output through k_run1024v3<CF32>)
 void big_destroy(BigPlan *plan);
 
 // k_run64v2 (kernels_run64_v2.hip): whole-band M = 64 calls with CF32 output and nf % 64 == 0; same state buffers as k_run64
@@ -96,6 +97,7 @@ struct Run1024v2Host {
     char *stage;                // [nruns] output staging blocks of 128 KiB
     uint32_t nf, nruns, parity0;
     uint32_t G = 1, g = 0;      // interleaved shard g of G (tables rotated by the plan)
+    bool tile_major = false;    // k_run1024v3<CF32>: the lines of a 16-frame block back to back ([block][1024][128 B]) instead of row-major [1024][nf]
     bool dc_block;
     double beta;
     float fm_ref;

@@ -581,6 +581,11 @@ const char *big_name(const BigPlan *p)
     return p->cfg.fm ? "k_run1024<FM>" : "k_run1024<CF32>";
 }
 
+bool big_tile_major_ok(const BigPlan *p, uint32_t nf)
+{
+    return p && p->v3_ok && !p->cfg.fm && !p->cfg.mix && (uint64_t)nf * 8192u < (1ull << 31) && run1024_v3_runs(nf, false, p->cus) != 0;
+}
+
 int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *timer)
 {
     const FusedConfig &c = p->cfg;
@@ -589,6 +594,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     int r;
     const uint32_t v2runs = (p->v2_ok && (nf & 3u) == 0 && (uint64_t)nf * 8192u < (1ull << 31)) ? run1024_v2_runs(nf, p->cus) : 0;
     p->v2_last = v2runs != 0;
+    if (call.tile_major && !big_tile_major_ok(p, nf)) { set_error("big_process: tile-major output asked for a call k_run1024v3<CF32> does not take"); return CSDR_ERR_INVALID; }
     const uint32_t v3runs = (p->v3_ok && (uint64_t)nf * 8192u < (1ull << 31)) ? run1024_v3_runs(nf, c.fm, p->cus) : 0;
     p->v3_last = v3runs != 0;
     if (v3runs) p->v2_last = false;
@@ -601,6 +607,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.stage = p->d_stage;
         H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
         H.G = c.G; H.g = c.G > 1 ? c.c0 : 0u;
+        H.tile_major = call.tile_major && v3runs && !c.fm;
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
         if (v3runs) { if ((r = run1024_v3_launch(H, c.fm, v3runs, s, timer))) return r; }
         else if ((r = run1024_v2_launch(H, c.fm, s, timer))) return r;

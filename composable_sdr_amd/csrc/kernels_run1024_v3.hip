@@ -65,6 +65,7 @@ struct Run1024v3Args {
     const float2 *vend_in; float2 *vend_out;      // DC blocker state v1
     const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r'
     uint32_t nf, nb, nruns, parity0;
+    uint32_t tile_major;        // CF32: lines of a block back to back, [block][1024][128 B] (the plane k_agc_spec_tm reads), instead of rows [1024][nf]
     unsigned long long *trace;  // debug (CSDR_RUN1024_V3_TRACE=file): s_memtime stamps of run 1's wave 0 (front) and wave 4 (back), [role][step][4]
     float alpha, beta, l2beta, fm_ref, tiny;
     float b16[16];              // beta^(16 r)
@@ -373,6 +374,8 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     // 512 16-byte slots: writer lane l, piece p -> slot 8 l + (p ^ ((l >> 1) & 7)); reader instruction m, lane l -> row r = 8 m + (l >> 3),
     // piece l & 7.  Slot sigma lies at 8192 (sigma >> 7) + 2048 wave + 16 (sigma & 127).
     const unsigned row_b = A.nf * (FM ? 4u : 8u);                               // bytes per output row
+    const bool tmaj = !FM && A.tile_major != 0;
+    const unsigned line_row = tmaj ? 128u : row_b, blk_step = tmaj ? 1024u * 128u : 128u;      // bytes between the lines of neighbouring channels / blocks
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)(1024u * row_b), 0x00020000);
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
@@ -451,14 +454,14 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                     const unsigned fl_w = 8192u * (unsigned)(lf >> 4) + 2048u * wave_u + 128u * (unsigned)(lf & 15) + ((unsigned)((lf >> 1) & 7) << 4);   // ^ (p << 4)
                     const unsigned fl_r0 = 2048u * wave_u + 128u * (unsigned)(lf >> 3) + 16u * (unsigned)((lf & 7) ^ (lf >> 4));                           // m even: + 8192 (m >> 1)
                     const unsigned fl_r1 = 2048u * wave_u + 1024u + 128u * (unsigned)(lf >> 3) + 16u * (unsigned)((lf & 7) ^ (4 + (lf >> 4)));            // m odd
-                    const unsigned st_v = (64u * wave_u + (unsigned)(lf >> 3)) * row_b + 16u * (unsigned)(lf & 7);
-                    const unsigned o0 = (FM ? 16u : 32u) * (b - (B3_TB - 1u));   // the block's first frame in a row, bytes
+                    const unsigned st_v = (64u * wave_u + (unsigned)(lf >> 3)) * line_row + 16u * (unsigned)(lf & 7);
+                    const unsigned o0 = (b / B3_TB) * blk_step;                  // the block's line in a row (row-major: 128 bytes per block)
 #pragma unroll
                     for (int k3 = 0; k3 < 4; k3++) {
                         if (B3_ABLATE & 8) {
 #pragma unroll
                             for (int m = 0; m < 8; m++)
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){stg[k3][4 * m], stg[k3][4 * m + 1], stg[k3][4 * m + 2], stg[k3][4 * m + 3]}), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * row_b), 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){stg[k3][4 * m], stg[k3][4 * m + 1], stg[k3][4 * m + 2], stg[k3][4 * m + 3]}), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * line_row), 0);
                             continue;
                         }
 #pragma unroll
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 #pragma unroll
                         for (int m = 0; m < 8; m++) {
                             const v4f v = *reinterpret_cast<const v4f *>(Bw + ((m & 1) ? fl_r1 : fl_r0) + 8192 * (m >> 1));
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * row_b), 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * line_row), 0);
                         }
                     }
                 }
@@ -511,7 +514,7 @@ int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream
     A.x = h.x; A.out = h.out; A.taps_q = h.taps_q; A.tw = h.tw;
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
     A.rp_in = h.rp_in; A.rp_out = h.rp_out;
-    A.nf = h.nf; A.nb = h.nf / B3_T4; A.nruns = nruns; A.parity0 = h.parity0;
+    A.nf = h.nf; A.nb = h.nf / B3_T4; A.nruns = nruns; A.parity0 = h.parity0; A.tile_major = (!fm && h.tile_major) ? 1u : 0u;
     const double beta = h.dc_block ? h.beta : 0.0;
     A.alpha = h.dc_block ? (float)(1.0 - beta) : 0.0f; A.beta = (float)beta; A.l2beta = h.dc_block ? (float)std::log2(beta) : -1000.0f;
     for (int i = 0; i < 16; i++) A.b16[i] = (float)std::pow(beta, 16.0 * i);

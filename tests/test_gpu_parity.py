@@ -1090,6 +1090,43 @@ def test_agc_tail_tile_major_route_is_bit_identical_to_sequential(demod, G, monk
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("demod", ["fm", "none"])
+def test_agc_tail_tile_major_route_at_1024_channels_is_bit_identical_to_sequential(demod, monkeypatch):
+    """The same at M = 1024: k_run1024v3<CF32> writes the plane tile-major (the 128-byte lines of a 16-frame block back to back) for
+    k_agc_spec_tm; against the one-lane-per-channel kernels behind the row-major plane, BIT FOR BIT, keyed signal, state carried over
+    run-sized, ragged and short calls."""
+    import torch
+    from composable_sdr_amd import _lib
+    M, kf = 1024, 0.3
+    monkeypatch.setenv("CSDR_AGC_W", "512")
+    monkeypatch.setenv("CSDR_AGC_L_TM", "688")
+    frames = [8192, 8192 + 16, 33, 4096 + 32]
+    dev = torch.device("cuda", 0)
+    xd = _bursty_torch(M, sum(frames), 977, dev)
+    kw = dict(channels=M, demod=demod, kf=kf, agc=8.0, max_frames=max(frames))
+    a = cs.Chain(flags=_lib.FLAG_QUIET, **kw)
+    b = cs.Chain(flags=_lib.FLAG_QUIET | _lib.FLAG_AGC_SEQUENTIAL, **kw)
+    w = 1 if demod == "fm" else 2
+    pos, names = 0, []
+    for f in frames:
+        oa = torch.zeros(M * f * w, dtype=torch.float32, device=dev); ob = torch.zeros_like(oa)
+        ptr = xd.data_ptr() + pos * M * 8
+        a.process_device(ptr, M * f, oa.data_ptr(), 0)
+        b.process_device(ptr, M * f, ob.data_ptr(), 0)
+        torch.cuda.synchronize()
+        names.append(a.kernel_time()[0])
+        assert torch.equal(oa.view(torch.int32), ob.view(torch.int32)), (demod, f, pos)
+        opened = float((ob != 0).float().mean())
+        assert 0.02 < opened < 0.98 or f < 100, opened
+        pos += f
+    checked, redone = a.agc_stats()
+    tmc = a.agc_tile_major_calls()
+    print(f"tile-major AGC tail at 1024 channels, {demod}: {tmc} of {len(frames)} calls on k_agc_spec_tm ({names}); segments checked {checked}, recomputed {redone}")
+    assert tmc == 3 and redone > 0
+    a.status(); b.status()
+    a.close(); b.close()
+
+
 def test_agc_tail_steady_state_needs_no_recompute():
     """on a stationary signal (the bench's) the speculation always verifies after the first call"""
     from composable_sdr_amd import _lib
