@@ -306,7 +306,7 @@ int  csdr_chain_debug_trace(csdr_chain *h, unsigned long long *out, uint32_t nti
 /* Diagnostics of the time-parallel AGC tail since create: segments whose speculative start state was
  * checked against the true state, and how many of them had to be recomputed sequentially. */
 int  csdr_chain_debug_agc(csdr_chain *h, uint32_t *checked, uint32_t *redone);
-/* Calls since create whose AGC tail ran on a tile-major plane (k_agc_spec_tm: fused 256-channel chains, run-sized calls of whole
+/* Calls since create whose AGC tail ran on a tile-major plane (k_agc_spec_tm: fused 256- and 1024-channel chains, run-sized calls of whole
  * 16-frame tiles; every other call takes the row-major k_agc_spec).  Both produce the sequential recurrence bit for bit. */
 uint32_t csdr_chain_debug_agc_tile_major_calls(const csdr_chain *h);
 
