@@ -69,11 +69,11 @@ def test_run1024v3_has_no_register_spills_and_fits_one_workgroup_per_cu(tmp_path
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     blocks = [b for b in re.split(r"remark: Function Name: ", out.stderr)[1:] if "k_run1024v3" in b.splitlines()[0]]
-    assert len(blocks) == 1
-    b = blocks[0]
-    assert int(re.search(r"SGPRs Spill: (\d+)", b).group(1)) == 0 and int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, b[:600]
-    assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0
-    assert int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)) <= 160 * 1024
+    assert len(blocks) == 2                               # <FM>, <CF32>
+    for b in blocks:
+        assert int(re.search(r"SGPRs Spill: (\d+)", b).group(1)) == 0 and int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, b[:600]
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0
+        assert int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)) <= 160 * 1024
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
