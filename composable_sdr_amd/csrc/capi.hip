@@ -625,7 +625,7 @@ struct RouteRow {
 };
 const RouteRow ROUTES[] = {
     {256, ST1 | ST2 | ST4 | ST8, PLAN_FUSED256, "fused-256",
-     "k_run256v2<FM | CF32[, G]> (whole band: calls of >= 2048 whole tiles of 16 frames; interleaved shards G = 2, 4, 8: every whole tile); "
+     "k_run256v2<FM | CF32[, G]> (whole band: calls of >= 1024 whole tiles of 16 frames; interleaved shards G = 2, 4, 8: every whole tile); "
      "k_run256v3 with CSDR_RUN_V3=1 (experiment, not faster)",
      "k_tile256<FM | CF32> (look-back tile kernel: chunk-sized calls, ragged ends, and contiguous channel shards at every size) [+ k_shard_gather]",
      "channelizer -> CF32 plane (tile-major for run-sized calls of whole tiles) -> k_agc_spec_tm | k_agc_spec -> k_agc_fix [-> k_mix]"},

@@ -375,7 +375,7 @@ struct FusedPlan {
     u64 *d_agg = nullptr, *d_ylast = nullptr;
     void *d_premix = nullptr;    // per-channel output before mixing
     u64 *d_trace = nullptr;
-    uint32_t run_min_tiles = 2048;   // chunks with at least this many tiles use the run kernel (measured crossover)
+    uint32_t run_min_tiles = 1024;   // chunks with at least this many tiles use the run kernel (measured crossover: FM ~900 tiles, CF32 ~700; profiles/r04_call_size_sweeps.txt)
     uint32_t cus = 256;
     float slot_weight[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // tile share of the k-th co-resident run of a CU
     uint32_t resident_wgs_v2 = 512;  // workgroups of k_run256v2 the device holds at once
