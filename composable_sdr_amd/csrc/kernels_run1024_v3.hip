@@ -118,8 +118,10 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     {
         float2 acc = make_float2(0.f, 0.f);
         if (w > 0 && !back) {
-            // read-only warm-up (as k_run1024v2): the DC state before tile_begin from the six tiles in front of it, one batch of loads
-            const unsigned h0 = tile_begin - B3_WU;
+            // read-only warm-up (as k_run1024v2): the DC state before tile_begin from the six tiles in front of it, one batch of loads.  A run
+            // that starts fewer than six tiles into the call (short calls: runs of one block) folds the tiles there are -- zeros stand for the
+            // others -- and takes the rest from the stream's state below, which is then exact
+            const int h0 = (int)tile_begin - B3_WU;
             float4 raw[8], rb[8], rc[8], rd[8], re[8], rf[8];
             float wt0, wt1;
             {
@@ -143,16 +145,15 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                 acc = cfma(acc, A.b256[16], p);
             };
             static_assert(B3_WU == 6, "one batch of six warm-up tiles");
-            tile_load(x4 + (size_t)h0 * 2048, 256, raw, lt); tile_load(x4 + (size_t)(h0 + 1) * 2048, 256, rb, lt);
-            tile_load(x4 + (size_t)(h0 + 2) * 2048, 256, rc, lt); tile_load(x4 + (size_t)(h0 + 3) * 2048, 256, rd, lt);
-            tile_load(x4 + (size_t)(h0 + 4) * 2048, 256, re, lt); tile_load(x4 + (size_t)(h0 + 5) * 2048, 256, rf, lt);
+            auto wload = [&](int t, float4 (&r)[8]) { tile_load(x4 + (size_t)(t > 0 ? t : 0) * 2048, t >= 0 ? 256 : 0, r, lt); };
+            wload(h0, raw); wload(h0 + 1, rb); wload(h0 + 2, rc); wload(h0 + 3, rd); wload(h0 + 4, re); wload(h0 + 5, rf);
             fold(raw); fold(rb); fold(rc); fold(rd); fold(re); fold(rf);
         }
         const float2 sum = wg_sum(acc, red, tid);       // red[0..3]: the front waves (the back waves park zeros in red[4..7])
         if (w == 0) c = A.vend_in[0];
         else {
             c = sum;
-            if (tile_begin - B3_WU == 0) c = cfma(A.vend_in[0], exp2f((float)(4096 * B3_WU) * A.l2beta), c);
+            if ((int)tile_begin - B3_WU <= 0) c = cfma(A.vend_in[0], exp2f((float)(4096u * tile_begin) * A.l2beta), c);
         }
     }
     if (back) {                                         // freqdem history (after the reduction scratch is done with)
@@ -544,11 +545,10 @@ int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream
 uint32_t run1024_v3_runs(uint32_t nf, bool fm, uint32_t cus)
 {
     const uint32_t B3_TB = fm ? B3_TBF : B3_TBC;
-    // one workgroup per CU; runs are whole blocks of 8 (F32) / 4 (CF32) tiles (a row's 128-byte line); a run >= 1 spends 6 read-only + 4 halo
-    // tiles in front of its first tile: at least 12 tiles per run (mid-sized calls, e.g. the reference's 4096-frame chunks, then get twice
-    // the runs that four blocks per run would give them)
+    // one workgroup per CU; runs are whole blocks of 8 (F32) / 4 (CF32) tiles (a row's 128-byte line), at least one (a run >= 1 walks 4
+    // halo tiles in front of its first tile and folds the up to 6 tiles in front of those: short calls get as many runs as they have blocks)
     if (nf % (B3_T4 * B3_TB)) return 0;
-    const uint32_t nblk = nf / (B3_T4 * B3_TB), minb = fm ? 2u : 3u;
+    const uint32_t nblk = nf / (B3_T4 * B3_TB), minb = 1u;
     uint32_t nruns = cus;
     if (const char *e = getenv("CSDR_RUN1024_V3_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
     if (nruns > nblk / minb) nruns = nblk / minb;
