@@ -105,7 +105,7 @@ struct Run1024v2Host {
 uint32_t run1024_v2_runs(uint32_t nf, uint32_t cus);    // 0: call too short for the kernel
 int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTimer *timer);
 // third-generation FM kernel (kernels_run1024_v3.hip): one 512-thread workgroup per CU, output lines staged in registers (no staging
-// block); whole band, calls of whole output lines (nf = 0 mod 32 frames F32 / 16 frames CF32) with at least 4 lines per run
+// block); whole band, calls of whole output lines (nf = 0 mod 32 frames F32 / 16 frames CF32)
 uint32_t run1024_v3_runs(uint32_t nf, bool fm, uint32_t cus);    // 0: the call is not for this kernel
 int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_t s, KernelTimer *timer);
 
