@@ -202,3 +202,28 @@ def test_wbfm_tail_restatement_properties():
     whole = d2.execute_block(q2.execute_block(x[:4000]))
     parts = np.concatenate([d3.execute_block(q3.execute_block(x[:1000])), d3.execute_block(q3.execute_block(x[1000:4000]))])
     assert np.array_equal(whole, parts)
+
+
+@pytest.mark.parametrize("M,m,As", [(4, 7, 80.0), (64, 7, 80.0), (256, 7, 80.0), (4, 10, 60.0), (20, 7, 80.0)])
+def test_kaiser_prototype_against_scipy_window_and_published_beta(M, m, As):
+    """The channelizer's prototype (Liquid.chs:813: firpfbch_crcf_create_kaiser -> liquid_firdes_kaiser(2 M m + 1, 0.5 / M, As, 0)) as the
+    published construction built from THIRD-PARTY pieces: Kaiser's empirical beta(As) as scipy.signal.kaiser_beta has it, the Kaiser
+    window of scipy.signal.windows.kaiser (its own I0), and an ideal low-pass sinc(2 fc t) -- not scipy's firwin, which rescales to
+    unit DC gain where liquid does not.  KAT1 pins three of these taps to the reference's own print-out; this pins all of them to the
+    textbook form."""
+    from scipy.signal import kaiser_beta
+    from scipy.signal.windows import kaiser
+    N = 2 * M * m + 1
+    h = O.kaiser_prototype(M, m, As).astype(np.float64)
+    t = np.arange(N) - (N - 1) / 2.0
+    x = 2.0 * (0.5 / M) * t
+    w = kaiser(N, kaiser_beta(As), sym=True)
+    want = np.sinc(x) * w
+    far = np.abs(x) >= 0.01
+    assert np.abs(h - want)[far].max() < 2e-7                  # float32 taps against float64
+    # liquid's sincf is not sin(pi x) / (pi x) below |x| = 0.01 but cos(pi x / 2) cos(pi x / 4) cos(pi x / 8) (math.c), which the
+    # restatement follows: up to (pi x)^2 / 384 = 2.6e-6 above the textbook value there (taps next to the centre of wide banks)
+    near = ~far
+    prod = np.cos(np.pi * x / 2) * np.cos(np.pi * x / 4) * np.cos(np.pi * x / 8) * w
+    assert np.abs(h - prod)[near].max() < 2e-7 and np.abs(h - want)[near].max() < 3e-6
+    assert abs(h[(N - 1) // 2] - 1.0) < 1e-7 and np.allclose(h, h[::-1], atol=0)      # centre tap 1, exactly symmetric
