@@ -227,3 +227,20 @@ def test_kaiser_prototype_against_scipy_window_and_published_beta(M, m, As):
     prod = np.cos(np.pi * x / 2) * np.cos(np.pi * x / 4) * np.cos(np.pi * x / 8) * w
     assert np.abs(h - prod)[near].max() < 2e-7 and np.abs(h - want)[near].max() < 3e-6
     assert abs(h[(N - 1) // 2] - 1.0) < 1e-7 and np.allclose(h, h[::-1], atol=0)      # centre tap 1, exactly symmetric
+
+
+def test_dc_blocker_against_scipy_lfilter():
+    """dcBlocker (Liquid.chs:575-589: iirfilt_crcf_create_dc_blocker(0.0005)) = the transfer function (1 - z^-1) / (1 - (1 - alpha) z^-1)
+    (KAT3 pins the coefficients) run by scipy.signal.lfilter in float64: the float32 direct-form-II restatement follows it to rounding
+    over 200 000 samples of a signal with a DC offset, in chunks (state carried)."""
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(11)
+    n = 200000
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.3 + (0.7 - 0.4j)).astype(np.complex64)
+    q = O.DcBlock(0.0005)
+    got = np.concatenate([q.execute(x[i:j]) for i, j in ((0, 1), (1, 4097), (4097, 100000), (100000, n))])
+    beta = float(np.float32(1) - np.float32(0.0005))
+    want = lfilter([1.0, -1.0], [1.0, -beta], x.astype(np.complex128))
+    # direct form II keeps v ~ DC / alpha = 1600 in float32: an ulp of the state is 1e-4 of the output (the reference's own arithmetic)
+    assert np.abs(got - want).max() < 3e-4 and np.sqrt(np.mean(np.abs(got - want) ** 2)) < 1e-4
+    assert abs(np.mean(got[-50000:])) < 2e-3                    # the offset is gone
