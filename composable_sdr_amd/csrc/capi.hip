@@ -633,9 +633,9 @@ const RouteRow ROUTES[] = {
      "k_run64v2 (CF32 output, whole band, nf % 64 == 0, >= 8 tiles of 64 frames per run)", "k_run64<FM | CF32> (FM output, shards, ragged calls)",
      "k_run64<CF32> -> k_agc_spec -> k_agc_fix [-> k_mix]"},
     {1024, ST1 | ST2 | ST4 | ST8, PLAN_BIG1024, "fused-k_run1024",
-     "k_run1024v3<FM | CF32> (whole band, calls of whole 128-byte output lines = 32 F32 / 16 CF32 frames); "
-     "k_run1024v2<FM[, G]> (FM output, other whole 4-frame tiles, run-sized; interleaved shards G = 2, 4, 8)",
-     "k_run1024<FM | CF32> (short and ragged calls) [+ k_pfb1024_fixup, k_shard_gather1024]", "k_run1024v3<CF32> -> CF32 plane (tile-major) -> k_agc_spec_tm | k_run1024<CF32> -> k_agc_spec; -> k_agc_fix [-> k_mix]"},
+     "k_run1024v3<FM | CF32> (whole band, calls of whole 4-frame tiles; a call that ends inside a 128-byte line stores the front part of it); "
+     "k_run1024v2<FM, G> (interleaved shards G = 2, 4, 8, FM output, run-sized calls of whole tiles)",
+     "k_run1024<FM | CF32> (ragged calls, contiguous shards, the other calls of interleaved shards) [+ k_pfb1024_fixup, k_shard_gather1024]", "k_run1024v3<CF32> -> CF32 plane (tile-major) -> k_agc_spec_tm | k_run1024<CF32> -> k_agc_spec; -> k_agc_fix [-> k_mix]"},
     {0, ST_ANY, PLAN_GENERIC, "generic",
      "k_dc_tile -> k_pfb_fir (M = 1024, forced generic: k_pfb1024) -> k_fft_r16 | k_fft_pow2 | k_dft_direct [interleaved shard: k_fold + (M / G)-point DFT] "
      "-> k_transpose_fm | k_mix_frames | k_transpose;  DeNo --mix over all channels: k_dc_fold + k_mixid_finish (M % 4096 == 0) | k_dc_tile + k_branch0_fir "

@@ -547,10 +547,10 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
             tq[(size_t)PM * 16 + 2 * (size_t)r] = wpre[PM + r].x; tq[(size_t)PM * 16 + 2 * (size_t)r + 1] = wpre[PM + r].y;
         }
         CSDR_HIP(hipMemcpy(p->d_taps_q, tq.data(), sizeof(float) * tq.size(), hipMemcpyHostToDevice));
-        // k_run1024v2: FM output only (calls of whole 4-frame tiles that are not whole 32-frame lines, and the interleaved shards); its CF32
-        // variant (measured slower than k_run1024<CF32>: 405-415 us against 384) is no longer built: k_run1024v3<CF32> takes those calls
-        p->v2_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && !getenv("CSDR_RUN1024_V1") && cfg.fm;
-        // whole band, calls of whole output lines: k_run1024v3 (FM: 282 us against k_run1024v2's 352, no staging block; CSDR_RUN1024_V3=0 for the comparison)
+        // k_run1024v2: the interleaved shards only (FM output); its whole-band instantiations are no longer built -- k_run1024v3 takes every
+        // whole-band call of whole 4-frame tiles (a call that ends inside a 128-byte line stores the front part of it)
+        p->v2_ok = false;
+        // whole band, calls of whole 4-frame tiles: k_run1024v3 (CSDR_RUN1024_V3=0: k_run1024 for the comparison)
         p->v3_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && cfg.G == 1 && !getenv("CSDR_RUN1024_V1") && !(getenv("CSDR_RUN1024_V3") && atoi(getenv("CSDR_RUN1024_V3")) == 0);
         if (cfg.G > 1) p->v2_ok = cfg.fm && !getenv("CSDR_RUN1024_V1");       // k_run1024v2<FM, G>; CF32 shards: whole band + row gather (below)
         // until the first call: the kernel a call of max_nf frames would take (csdr_chain_path names it)
@@ -583,7 +583,7 @@ const char *big_name(const BigPlan *p)
 
 bool big_tile_major_ok(const BigPlan *p, uint32_t nf)
 {
-    return p && p->v3_ok && !p->cfg.fm && !p->cfg.mix && (uint64_t)nf * 8192u < (1ull << 31) && run1024_v3_runs(nf, false, p->cus) != 0;
+    return p && p->v3_ok && !p->cfg.fm && !p->cfg.mix && nf % 16u == 0 && (uint64_t)nf * 8192u < (1ull << 31) && run1024_v3_runs(nf, false, p->cus) != 0;
 }
 
 int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *timer)

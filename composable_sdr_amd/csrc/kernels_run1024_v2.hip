@@ -544,8 +544,7 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
     else if (h.G == 4) hipLaunchKernelGGL((k_run1024v2<true, 4>), dim3(h.nruns), dim3(256), 0, s, A);
     else if (h.G == 8) hipLaunchKernelGGL((k_run1024v2<true, 8>), dim3(h.nruns), dim3(256), 0, s, A);
     else if (h.G > 1) { set_error("k_run1024v2: interleaved shards of stride %u are not built (2, 4, 8)", h.G); return -1; }
-    else if (fm) hipLaunchKernelGGL((k_run1024v2<true, 1>), dim3(h.nruns), dim3(256), 0, s, A);
-    else { set_error("k_run1024v2: F32 output only (CF32 output: k_run1024v3<CF32> / k_run1024<CF32>)"); return -1; }
+    else { set_error("k_run1024v2: interleaved shards only (whole band: k_run1024v3 / k_run1024)"); return -1; }
     if (timer && (r = timer->end(s))) return r;
     CSDR_HIP(hipGetLastError());
     return 0;

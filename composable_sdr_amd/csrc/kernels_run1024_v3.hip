@@ -73,12 +73,13 @@ struct Run1024v3Args {
     PhaseK pk;
 };
 
-// run w: blocks of TB tiles, evenly
+// run w: blocks of TB tiles, evenly; the call's last block may be a partial one (nb % TB tiles: its rows get the front part of a line)
 __host__ __device__ __forceinline__ void run3_bounds(uint32_t nb, uint32_t nruns, unsigned w, unsigned TB, unsigned &first, unsigned &last)
 {
-    const unsigned nblk = nb / TB;
+    const unsigned nblk = (nb + TB - 1) / TB;
     first = TB * (unsigned)((unsigned long long)w * nblk / nruns);
     last = TB * (unsigned)((unsigned long long)(w + 1) * nblk / nruns);
+    if (last > nb) last = nb;
 }
 
 template <bool FM>
@@ -447,8 +448,8 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                 }
             }
             if (keep) {
-                if (ts == B3_TB - 1u && !(B3_ABLATE & 2)) {
-                    // ---- the block is complete: every row's 128 bytes leave in one piece
+                if ((ts == B3_TB - 1u || b + 1 == last) && !(B3_ABLATE & 2)) {
+                    // ---- the block is complete (or the call ends inside it: pieces 0 .. ts only): every row's 128 bytes leave in one piece
                     char *Bw = const_cast<char *>(B);
                     unsigned lf = (unsigned)l2;                                  // per-lane offsets of the flush, derived here: as loop invariants they would pin five more VGPRs
                     asm volatile("" : "+v"(lf));
@@ -457,6 +458,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
                     const unsigned fl_r1 = 2048u * wave_u + 1024u + 128u * (unsigned)(lf >> 3) + 16u * (unsigned)((lf & 7) ^ (4 + (lf >> 4)));            // m odd
                     const unsigned st_v = (64u * wave_u + (unsigned)(lf >> 3)) * line_row + 16u * (unsigned)(lf & 7);
                     const unsigned o0 = (b / B3_TB) * blk_step;                  // the block's line in a row (row-major: 128 bytes per block)
+                    const bool pok = (FM ? (lf & 7u) : ((lf & 7u) >> 1)) <= ts;  // my 16-byte piece of the line exists (always, but in the call's last block)
 #pragma unroll
                     for (int k3 = 0; k3 < 4; k3++) {
                         if (B3_ABLATE & 8) {
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 #pragma unroll
                         for (int m = 0; m < 8; m++) {
                             const v4f v = *reinterpret_cast<const v4f *>(Bw + ((m & 1) ? fl_r1 : fl_r0) + 8192 * (m >> 1));
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * line_row), 0);
+                            if (pok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)st_v, (int)(o0 + (unsigned)(8 * m + 256 * k3) * line_row), 0);
                         }
                     }
                 }
@@ -546,13 +548,14 @@ uint32_t run1024_v3_runs(uint32_t nf, bool fm, uint32_t cus)
 {
     const uint32_t B3_TB = fm ? B3_TBF : B3_TBC;
     // one workgroup per CU; runs are whole blocks of 8 (F32) / 4 (CF32) tiles (a row's 128-byte line), at least one (a run >= 1 walks 4
-    // halo tiles in front of its first tile and folds the up to 6 tiles in front of those: short calls get as many runs as they have blocks)
-    if (nf % (B3_T4 * B3_TB)) return 0;
-    const uint32_t nblk = nf / (B3_T4 * B3_TB), minb = 1u;
+    // halo tiles in front of its first tile and folds the up to 6 tiles in front of those: short calls get as many runs as they have
+    // blocks); the call's last block may be partial (nf = 0 mod 4: whole tiles)
+    if (nf % B3_T4) return 0;
+    const uint32_t nblk = (nf / B3_T4 + B3_TB - 1) / B3_TB;
     uint32_t nruns = cus;
     if (const char *e = getenv("CSDR_RUN1024_V3_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
-    if (nruns > nblk / minb) nruns = nblk / minb;
-    return nruns;                                       // 0: too short (or ragged) for this kernel
+    if (nruns > nblk) nruns = nblk;
+    return nruns;                                       // 0: a ragged call (not whole 4-frame tiles)
 }
 
 }  // namespace csdr
