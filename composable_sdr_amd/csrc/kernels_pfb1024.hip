@@ -464,7 +464,7 @@ struct BigPlan {
     float2 *d_tw = nullptr, *d_wpre = nullptr;
     float2 *d_uhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
     float2 *d_scratch = nullptr;     // yfirst | ylast
-    char *d_stage = nullptr;         // k_run1024v2: 128 KiB of output staging per run
+    char *d_stage = nullptr;         // (k_run1024v2's whole-band staging blocks: no longer built, never allocated)
     void *d_full = nullptr;          // interleaved shard, calls k_run1024v2 does not take: whole-band result [1024][max_nf] (allocated on first use)
     void *d_premix = nullptr;
     int cur = 0;
@@ -504,7 +504,6 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         ALLOC(p->d_rp[i], sizeof(float2) * (cfg.G > 1 ? (uint32_t)PM : cfg.C));     // interleaved shard: indexed by the primed channel k'
     }
     ALLOC(p->d_scratch, sizeof(float2) * 2 * (size_t)p->cus * PM);
-    ALLOC(p->d_stage, (size_t)(2 * p->cus) * 131072u);
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
 #undef ALLOC
     CSDR_HIP(hipMemcpy(p->d_taps, cfg.taps, sizeof(float) * PM * PP, hipMemcpyHostToDevice));
