@@ -129,6 +129,18 @@ def cpu_baseline(M, demod, kf, agc, x_host, seconds, mix=False):
     return res
 
 
+def kernel_sources_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources of libcsdr_hip.so (csrc/*.hip, *.h, sorted by name): what a
+    profiles/traffic.json entry must have been collected with to be quoted"""
+    import hashlib
+    d = os.path.join(ROOT, "composable_sdr_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 class SmiSampler:
     """sclk / socket power from rocm-smi, sampled by a side thread while a run is in flight (each call is a child process)."""
 
@@ -205,7 +217,9 @@ def main():
     out_elem = 4 if a.demod == "fm" else 8
     # two input buffers (> the 256 MiB Infinity Cache together) alternate between steps;
     # rank r's stripe is a different stretch of the stream (different seed offset)
-    chan = a.shard == "channel" and world > 1
+    # --shard channel: north_star's partition.  Also accepted on ONE GPU (a world of one rank): the step then still goes through the
+    # C ABI's collective entry points (csdr_comm_* / csdr_chain_process_device_mix), which is how a one-GPU box exercises them
+    chan = a.shard == "channel"
     if chan and M % world:
         raise SystemExit(f"--shard channel needs --gpus | --channels ({world} does not divide {M})")
     # time stripes: rank r's stripe is a different stretch of the stream (different seed offset);
@@ -217,11 +231,19 @@ def main():
     # separate pass of K launches with an event pair around every launch (`roofline.launch_ms`): the pairs cost the stream a few us
     # per launch and stay out of `value`
     flags = _lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS | _lib.FLAG_TIME_REGION
+    comm = None
+    if chan or world > 1:
+        # the data-path collectives run under the C ABI (include/csdr.h csdr_comm: RCCL over xGMI); torch.distributed only carries
+        # the bootstrap id, the barriers and the max-over-ranks of the clock.  (gloo test hook: several ranks on one GPU cannot
+        # form an RCCL communicator -- there ShardedChain falls back to torch.distributed.)
+        from composable_sdr_amd.sharded import Comm
+        if not one_gpu:
+            comm = Comm.from_process_group(dist, None, local) if use_dist else Comm(0, 1, Comm.unique_id(), local)
     if chan:
         from composable_sdr_amd.pipes import ChainConfig
         from composable_sdr_amd.sharded import ShardedChain
         sc = ShardedChain(ChainConfig(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=flags),
-                          mode="channel", interleave=True)
+                          mode="channel", interleave=True, rank=rank, world=world, comm=comm)
         chain = sc.chain
     else:
         chain = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=flags)
@@ -231,7 +253,7 @@ def main():
     # second handle for the per-launch kernel timing pass behind the timed region (created now: allocations between the two
     # would be an idle gap)
     kch = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS,
-                   chan_first=(rank if chan else 0), chan_stride=(world if chan else 0))
+                   chan_first=(rank if chan and world > 1 else 0), chan_stride=(world if chan and world > 1 else 0))
 
     def step(i):
         if chan and a.mix:
@@ -260,6 +282,20 @@ def main():
             d = float(t.item())
         return d, chain.kernel_time()
 
+    # channel shards work on ONE stream: the chunk has to reach every rank (8 B per input sample over xGMI).  The bench synthesises
+    # the identical chunk on every rank, so the broadcast is timed here once, on its own (csdr_comm_broadcast = ncclBroadcast)
+    bcast = None
+    if chan and comm is not None:
+        barrier()
+        for r in range(3):
+            if r == 1:
+                barrier(); tb0 = time.perf_counter()
+            comm.broadcast(xs[1].data_ptr(), nx * 8, 0, stream)
+        barrier()
+        tbc = (time.perf_counter() - tb0) / 2
+        bcast = {"ms": round(tbc * 1e3, 4), "bytes": nx * 8, "gb_per_s": round(nx * 8 / tbc / 1e9, 1), "ranks": world,
+                 "note": "csdr_comm_broadcast (ncclBroadcast) of one step's input from rank 0, timed alone; not inside `value` "
+                         "(every rank synthesises the same chunk)"}
     # (0) the contract's W + K steps on an idle board: reported as `cold_window`, never `value`
     barrier()
     dt_cold, _ = timed(a.steps, a.warmup)
@@ -331,7 +367,7 @@ def main():
         from composable_sdr_amd.sharded import ShardedChain
         xc = [synth_cf32_torch(nx, M, dev, seed=20260101 + 7919 * i) for i in range(2)]
         sc2 = ShardedChain(ChainConfig(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local,
-                                       flags=_lib.FLAG_QUIET), mode="channel", interleave=True)
+                                       flags=_lib.FLAG_QUIET), mode="channel", interleave=True, comm=comm)
         xcv = [x.view(-1) for x in xc]
 
         def step2(i):
@@ -355,7 +391,13 @@ def main():
                  "path": sc2.chain.path,
                  "sharding": f"channel-interleaved: rank g owns channels g + {world} m (every rank reads the whole stream; DC blocker, pre-mix and FIR are not divided)",
                  "collective": (f"RCCL all-reduce(SUM) of {nf} {'F32' if a.demod == 'fm' else 'CF32'} per step" if a.mix else "none"),
+                 "collective_api": ("csdr_chain_process_device_mix (C ABI, RCCL)" if comm is not None else "torch.distributed (gloo test hook)") if a.mix else None,
                  "rccl_ranks": dist.get_world_size()}
+        if comm is not None:
+            barrier(); tb0 = time.perf_counter()
+            comm.broadcast(xc[1].data_ptr(), nx * 8, 0, stream)
+            barrier()
+            chan2["input_broadcast_ms"] = round((time.perf_counter() - tb0) * 1e3, 4)
         sc2.chain.close()
 
     # N > 1: SURVEY 8e(B) for the AGC configuration -- linear front end on time stripes, ONE all-to-all of the channel-major CF32
@@ -367,25 +409,30 @@ def main():
         from composable_sdr_amd.pipes import ChainConfig
         from composable_sdr_amd.sharded import ShardedChain
         agc_h = a.agc if a.agc != 0.0 else 10.0
-        sch = ShardedChain(ChainConfig(channels=M, demod=a.demod, kf=a.kf, agc=agc_h, max_frames=nf, device=local, flags=_lib.FLAG_QUIET), mode="hybrid")
+        sch = ShardedChain(ChainConfig(channels=M, demod=a.demod, kf=a.kf, agc=agc_h, max_frames=nf, device=local, flags=_lib.FLAG_QUIET), mode="hybrid",
+                           comm=comm)
         plane = torch.empty(M * nf * 2, dtype=torch.float32, device=dev)
         recv = torch.empty_like(plane)
-
-        def step3(i):
-            sch.process_device_hybrid(xv[i & 1], plane, recv, out, stream)
         reps3 = max(3, a.steps // 2)
-        for i in range(2):
-            step3(i)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(reps3):
-            step3(i)
-        barrier()
-        d3 = time.perf_counter() - t1
-        t = torch.tensor([d3], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        d3 = float(t.item())
+
+        def run3(sub, ov):
+            for i in range(2):
+                sch.process_device_hybrid(xv[i & 1], plane, recv, out, stream, substripes=sub, overlap=ov)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(reps3):
+                sch.process_device_hybrid(xv[i & 1], plane, recv, out, stream, substripes=sub, overlap=ov)
+            barrier()
+            d = time.perf_counter() - t1
+            t = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        d3s = run3(2, False)            # the same two rounds of sub-stripes, exchanges in line with the kernels
+        d3 = run3(2, True)              # exchanges on a second stream: under the next round's front end / the previous round's tail
         hyb = {"value": round(nx * world * reps3 / d3 / 1e6, 1), "unit": "MS/s", "ms_per_step": round(d3 / reps3 * 1e3, 4), "steps": reps3, "scaling": "weak",
+               "overlap": {"substripes": 2, "exchange_stream": "second stream (events both ways)", "ms_per_step_serial": round(d3s / reps3 * 1e3, 4),
+                           "ms_per_step_overlapped": round(d3 / reps3 * 1e3, 4)},
+               "collective_api": "csdr_hybrid_exchange (C ABI: grouped ncclSend / ncclRecv)" if comm is not None else "torch.distributed (gloo test hook)",
                "agc_db": agc_h, "path": sch.chain.path + " -> all_to_all -> " + sch.tail.path,
                "sharding": f"hybrid (SURVEY 8e(B)): DC blocker + pre-mix + firpfbch on time stripes (one per rank), all-to-all of the [{M}][{nf}] CF32 plane, "
                            f"AGC + squelch{' + freqdem' if a.demod == 'fm' else ''} on channel blocks of {M // world}",
@@ -415,8 +462,17 @@ def main():
         except Exception:
             tj = {}
 
+    # a traffic.json entry is only as good as the kernels it was counted on: every entry carries the hash of the kernel sources
+    # (csrc/*.hip, *.h) it was collected with (tools/collect_profile.py); a different hash today -> traffic is reported as null
+    src_sha = kernel_sources_sha16()
+    stale = []
+
     def traffic_of(kernel):
-        return tj.get(f"{kernel}|M={M}|nf={nf}", {}).get("hbm_bytes_per_launch")
+        e = tj.get(f"{kernel}|M={M}|nf={nf}", {})
+        if e and e.get("src_sha16") != src_sha:
+            stale.append(kernel)
+            return None
+        return e.get("hbm_bytes_per_launch")
     traffic = traffic_of(kname)
     cfg_name = {(64, "none", False): "cfg2", (256, "fm", False): "cfg3", (1024, "fm", False): "cfg4 shape (one GPU)" if world == 1 else "cfg4",
                 (4096, "none", True): "cfg5 shape (one GPU)" if world == 1 else "cfg5"}.get((M, a.demod, bool(a.mix)), "custom")
@@ -428,19 +484,23 @@ def main():
                                f"AGC {'off (-a 0)' if a.agc == 0 else a.agc}, {nf} frames/step "
                                f"({nx * 8 / 2**20:.0f} MiB in, {M * nf * out_elem / 2**20:.0f} MiB out), HBM-resident",
                    "channels": M, "frames_per_step": nf, "demod": a.demod, "kf": a.kf, "agc_db": a.agc, "mix": bool(a.mix),
-                   "path": chain.path, "preheat_steps": preheat_steps,
+                   "path": f"{chain.path.split('|')[0]}|{kname}", "route": chain.path, "preheat_steps": preheat_steps,
                    "sharding": ("none" if world == 1 else
                                 (f"channel-interleaved: rank g owns channels g + {world} m, pruned DFT (fold + {M // world}-point)" if chan
                                  else "time stripes, 1 per rank")),
                    "collective": (f"RCCL all-reduce(SUM) of {nf} {'F32' if a.demod == 'fm' else 'CF32'} per step" if (chan and a.mix) else "none"),
-                   "rccl_ranks": (dist.get_world_size() if use_dist else 1)},
+                   "collective_api": (("csdr_chain_process_device_mix (C ABI, RCCL)" if comm is not None else "torch.distributed (gloo test hook)")
+                                      if (chan and a.mix) else None),
+                   "rccl_ranks": (comm.world if comm is not None else (dist.get_world_size() if use_dist else 1))},
         "hbm_roofline_frac_whole_step": round(value * 1e6 * alg_bytes_per_sample / 1e9 / (HBM_PEAK_GBS * (1 if chan else world)), 4),
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                      "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4) if achieved else None,
                      "traffic": traffic, "launch_ms": round(kavg_ms, 4), "launches": klaunches,
-                     "traffic_source": "profiles/traffic.json: rocprofv3 --pmc passes of this configuration (FETCH_SIZE x 2 + WRITE_SIZE per launch, "
-                                       "tools/profile_all.sh + tools/collect_all.sh), not re-measured in this run",
+                     "traffic_source": ("profiles/traffic.json: rocprofv3 --pmc passes of this configuration (FETCH_SIZE x 2 + WRITE_SIZE per launch, "
+                                        "tools/profile_all.sh + tools/collect_all.sh), not re-measured in this run; kernel sources unchanged since "
+                                        f"(src_sha16 {src_sha})") if not stale else
+                                       f"null: profiles/traffic.json was collected on other kernel sources than today's (src_sha16 {src_sha}); re-run tools/profile_all.sh",
                      "launch_ms_timed_region": round(kreg_ms, 4) if klaunches_r else None,
                      "frac_timed_region": round(nx * alg_bytes_per_sample / (kreg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if klaunches_r else None,
                      "alg_bytes_per_sample": alg_bytes_per_sample, "samples_per_launch": nx},
@@ -456,10 +516,14 @@ def main():
         # beside the contract's K-step window: the same step over 400 further launches, right behind it
         res["sustained"] = {"steps": 400, "ms_per_step": round(d_s * 1e3, 4), "value": round(nx / d_s / 1e6, 1), "unit": "MS/s",
                             "hbm_roofline_frac_whole_step": round(nx * alg_bytes_per_sample / d_s / 1e9 / HBM_PEAK_GBS, 4)}
+    if bcast:
+        res["input_broadcast"] = bcast
     if chan2:
         res["channel_shard"] = chan2
+        res["value_channel_shard"] = chan2["value"]      # north_star's partition (strong scaling), beside `value` (time stripes)
     if hyb:
         res["hybrid"] = hyb
+        res["value_hybrid"] = hyb["value"]               # SURVEY 8e(B) with the AGC on (weak scaling)
     if world == 1 and not a.no_agc_variant and a.agc == 0.0 and M == 256 and not a.mix:
         # cfg3 with the AGC on (squelch threshold -a 10 between the tone and the noise channels): the PFB kernel
         # writes channel-major CF32, the time-parallel verified AGC tail (bit-identical to the sequential
@@ -488,7 +552,8 @@ def main():
         # the AGC step is two kernels (channelizer to channel-major CF32 scratch, then the AGC + freqdem tail): achieved
         # = algorithmic bytes of the STEP over the step time; traffic = counter bytes of both launches
         def traffic_tm(kernel):
-            return tj.get(f"{kernel}|M={M}|nf={nf}|tm", {}).get("hbm_bytes_per_launch")
+            e = tj.get(f"{kernel}|M={M}|nf={nf}|tm", {})
+            return e.get("hbm_bytes_per_launch") if e.get("src_sha16") == src_sha else None
         ta = traffic_tm("k_run256v2<CF32>") or traffic_of("k_run256v2<CF32>")
         tb = traffic_of("k_agc_spec_tm") or traffic_of("k_agc_spec")
         res["agc_variant"]["roofline"] = {"bound": "hbm", "kernel": "k_run256v2<CF32> (tile-major plane) + k_agc_spec_tm (+ k_agc_fix)",

@@ -10,6 +10,7 @@ DEMOD_NONE, DEMOD_FM, DEMOD_AM, DEMOD_WBFM = 0, 1, 2, 3
 FLAG_TIME_KERNELS, FLAG_FORCE_GENERIC, FLAG_QUIET, FLAG_AGC_SEQUENTIAL, FLAG_NO_MIX_IDENTITY = 1, 2, 4, 8, 16
 FLAG_TIME_REGION = 32
 FLAG_TAIL_ONLY = 64
+FLAG_DFT_BACKWARD = 128
 
 ERR_INVALID, ERR_HIP, ERR_NODEV, ERR_SIZE, ERR_NOMEM = -1, -2, -3, -4, -5
 
@@ -94,7 +95,20 @@ SIGNATURES = {
     "csdr_chain_debug_agc": (_i32, [_vp, _vp, _vp]),
     "csdr_chain_debug_agc_tile_major_calls": (_u32, [_vp]),
     "csdr_chain_kernel_time": (C.c_char_p, [_vp, C.POINTER(C.c_double), _pu32]),
+    "csdr_chain_get_cfg": (_i32, [_vp, C.POINTER(ChainCfg)]),
+    # collectives (RCCL over xGMI, csrc/comm.cpp)
+    "csdr_comm_unique_id": (_i32, [_vp]),
+    "csdr_comm_create": (_i32, [_i32, _i32, _vp, _i32, _pp]),
+    "csdr_comm_rank": (_i32, [_vp]),
+    "csdr_comm_world": (_i32, [_vp]),
+    "csdr_comm_destroy": (_i32, [_vp]),
+    "csdr_comm_broadcast": (_i32, [_vp, _vp, C.c_size_t, _i32, _vp]),
+    "csdr_comm_allreduce_f32": (_i32, [_vp, _vp, C.c_size_t, _vp]),
+    "csdr_chain_process_device_mix": (_i32, [_vp, _vp, _vp, _u32, _vp, _pu32, _vp]),
+    "csdr_chain_process_mix": (_i32, [_vp, _vp, _vp, _u32, _vp, _pu32]),
+    "csdr_hybrid_exchange": (_i32, [_vp, _vp, _vp, _u32, _pu32, _u32, _vp]),
 }
+COMM_ID_BYTES = 128
 
 
 def lib_path():

@@ -119,6 +119,8 @@ struct csdr_chain {
     float2 *d_tw = nullptr, *d_nco_tab = nullptr, *d_dcstate = nullptr, *d_scratch = nullptr;
     uint32_t G = 1;                  // chan_stride: interleaved shard g = c0 of G (generic route, pruned DFT)
     float2 *d_tw_g = nullptr, *d_fold_ph = nullptr, *d_fold = nullptr;   // (M/G)-point twiddles, fold phasors, folded frames
+    bool dft_backward = false;       // CSDR_FLAG_DFT_BACKWARD: rows leave through d_perm and a row permutation k -> (M - k) mod M
+    void *d_perm = nullptr;
     bool mix_identity = false;       // DeNo --mix over all channels: M * (branch-0 FIR) instead of bank + DFT + sum
     float2 *d_u0 = nullptr, *d_u0hist = nullptr;     // branch-0 samples of the call behind p - 1 of history; history between calls (two copies, ping-pong)
     int u0_cur = 0;
@@ -903,6 +905,12 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             h->path = "generic+pruned-dft";
         }
     }
+    if ((cfg_in->flags & CSDR_FLAG_DFT_BACKWARD) && M > 1 && !(cfg_in->mix != 0)) {
+        if (C != M || G > 1) { set_error("chain: CSDR_FLAG_DFT_BACKWARD is built for whole-band handles (no channel shard)"); return fail(CSDR_ERR_INVALID); }
+        h->dft_backward = true;
+        CSDR_HIP_CLEAN(hipMalloc(&h->d_perm, (size_t)C * h->max_nf * ((cfg_in->demod == CSDR_DEMOD_NONE) ? 8u : 4u)), csdr_chain_destroy(h));
+        h->path += "+dft-backward";
+    }
     if (am) {
         h->am = true; h->am_mix = am_mix;
         if ((r = dev_alloc(&h->d_amz, (size_t)C * h->max_nf))) return fail(r);
@@ -1107,7 +1115,20 @@ int csdr_chain_process_device(csdr_chain *h, const void *d_in, uint32_t n_in, vo
     return own ? CSDR_OK : chain_mark_user_stream(h, (hipStream_t)stream);
 }
 
+static int chain_process_device_any0(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream);
 static int chain_process_device_any(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
+{
+    if (!h || !h->dft_backward || n_in == 0 || !d_out) return chain_process_device_any0(h, d_in, n_in, d_out, n_out, stream);
+    // CSDR_FLAG_DFT_BACKWARD: the chain as built (forward DFT) into d_perm, then row k of the output = its row (M - k) mod M
+    uint32_t n = 0;
+    int r = chain_process_device_any0(h, d_in, n_in, h->d_perm, &n, stream);
+    if (r) return r;
+    if (n_out) *n_out = n;
+    DevGuard guard(h->device);
+    return launch_rows_reversed(h->d_perm, d_out, h->C, (size_t)(n / h->C) * csdr_chain_out_elem_size(h), (hipStream_t)stream);
+}
+
+static int chain_process_device_any0(csdr_chain *h, const void *d_in, uint32_t n_in, void *d_out, uint32_t *n_out, void *stream)
 {
     if (h && h->wbfm) {
         if (n_out) *n_out = 0;
@@ -1492,6 +1513,12 @@ int csdr_chain_debug_agc(csdr_chain *h, uint32_t *checked, uint32_t *redone)
 }
 uint32_t csdr_chain_debug_agc_tile_major_calls(const csdr_chain *h) { return h && h->agc_tail ? agc_tail_tm_calls(h->agc_tail) : 0u; }
 const char *csdr_chain_path(const csdr_chain *h) { return h ? h->path.c_str() : ""; }
+int csdr_chain_get_cfg(const csdr_chain *h, csdr_chain_cfg *cfg_out)
+{
+    if (!h || !cfg_out) { set_error("csdr_chain_get_cfg: null argument"); return CSDR_ERR_INVALID; }
+    *cfg_out = h->cfg;
+    return CSDR_OK;
+}
 
 const char *csdr_chain_kernel_time(csdr_chain *h, double *total_ms, uint32_t *launches)
 {
@@ -1521,7 +1548,7 @@ int csdr_chain_destroy(csdr_chain *h)
     h->timer.destroy();
     void *ptrs[] = {h->d_taps, h->d_tw, h->d_nco_tab, h->d_dcstate, h->d_scratch, h->d_u, h->d_hist_tmp, h->d_A, h->d_B,
                     h->d_agc, h->d_rp[0], h->d_rp[1], h->d_amz, h->d_amf, h->d_amq[0], h->d_amq[1], h->d_tw_g, h->d_fold_ph, h->d_fold, h->d_u0, h->d_u0hist,
-                    h->d_wbf, h->d_wbo, h->d_wbh, h->d_wbhist[0], h->d_wbhist[1], h->d_wbst[0], h->d_wbst[1]};
+                    h->d_wbf, h->d_wbo, h->d_wbh, h->d_wbhist[0], h->d_wbhist[1], h->d_wbst[0], h->d_wbst[1], h->d_perm};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &sl : h->slot) {
         if (sl.d_in) (void)hipFree(sl.d_in);

@@ -116,6 +116,8 @@ int launch_fm(const float2 *Z, float *F, uint32_t C, uint32_t nf, float ref, con
 // out[i] = ((in[0][i] + in[1][i]) + ...) + in[C-1][i], row length E floats
 int launch_mix(const float *in, float *out, uint32_t C, uint32_t E, hipStream_t s);
 int launch_agc_init(AgcState *st, uint32_t C, hipStream_t s);
+// out row k = in row (C - k) mod C (CSDR_FLAG_DFT_BACKWARD: the analyzer's transform taken as e^{+j}); in != out
+int launch_rows_reversed(const void *in, void *out, uint32_t C, size_t row_bytes, hipStream_t s);
 // frame-major tails: freqdem straight from Y[nf][M] into channel-major F, or mixed over channels per frame
 int launch_transpose_fm(const float2 *Y, float *F, uint32_t M, uint32_t nf, uint32_t c0, uint32_t C, float ref,
                         const float2 *rp_in, float2 *rp_out, hipStream_t s);

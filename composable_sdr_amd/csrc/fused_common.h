@@ -337,6 +337,36 @@ __device__ __forceinline__ float2 scan_staged(float2 *R, float2 *E, float2 *T, c
     return e;
 }
 
+// scan_staged on an image whose frames are FS float2 apart (256 = dense; k_run256v2 pads its frames, kernels_fused_v2.hip)
+template <int FS>
+__device__ __forceinline__ float2 scan_staged_fs(float2 *R, float2 *E, float2 *T, const TileArgs &A, int tid)
+{
+    const int q = tid, sw = (q >> 1) & 7;
+    float4 *R4 = reinterpret_cast<float4 *>(R + FS * (q >> 4)) + 8 * (q & 15);
+    float2 s = make_float2(0.f, 0.f);
+    const float na = -A.alpha, be = A.beta;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float4 v = R4[i ^ sw];
+        float2 x0 = make_float2(v.x, v.y), x1 = make_float2(v.z, v.w);
+        const float2 z0 = cfma(s, na, x0);
+        s = cfma(s, be, x0);
+        const float2 z1 = cfma(s, na, x1);
+        s = cfma(s, be, x1);
+        R4[i ^ sw] = make_float4(z0.x, z0.y, z1.x, z1.y);
+    }
+    float2 t;
+    t = dpp2<0x111>(s); s = cfma(t, A.b16[1], s);
+    t = dpp2<0x112>(s); s = cfma(t, A.b16[2], s);
+    t = dpp2<0x114>(s); s = cfma(t, A.b16[4], s);
+    t = dpp2<0x118>(s); s = cfma(t, A.b16[8], s);
+    const float2 e = dpp2<0x111>(s);
+    if (E) E[q] = e;
+    if ((q & 15) == 15) T[q >> 4] = s;
+    __syncthreads();
+    return e;
+}
+
 // Zero-state v before frame f of a tile, from its 16 frame totals: every 16-lane row runs the
 // same decayed DPP scan over T[0..15] and picks the entry of the frame before its own.
 __device__ __forceinline__ float2 frame_carry_zero_state(const float2 *T, const TileArgs &A, int tid)

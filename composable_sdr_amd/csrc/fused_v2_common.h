@@ -35,7 +35,9 @@ __device__ __forceinline__ unsigned dma_offset(int tid)
     const int slot = 64 * wave + lane, q = slot >> 3, i = (slot & 7) ^ ((q >> 1) & 7);
     return (unsigned)(8 * q + i) * 16u;
 }
-template <bool STREAM = false>
+// IT_STEP: LDS bytes between the destinations of consecutive instructions of a wave (4096 = the dense image; k_run256v2 pads
+// its frames and passes 2 x its frame stride: instruction `it` of wave w lands in frame 2 it + (w >> 1))
+template <bool STREAM = false, unsigned IT_STEP = 4096u>
 __device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, unsigned goff, unsigned lds_wave)
 {
     // the eight destination addresses are recomputed per call (one s_add each): as loop invariants they are sixteen SGPRs that
@@ -43,7 +45,7 @@ __device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, u
     asm volatile("" : "+s"(lds_wave));
 #pragma unroll
     for (int it = 0; it < 8; it++) {
-        const unsigned dst = lds_wave + 4096u * (unsigned)it;
+        const unsigned dst = lds_wave + IT_STEP * (unsigned)it;
         const float4 *src = tile_base + 256 * it;
         unsigned keep;
         if (STREAM)

@@ -46,6 +46,11 @@
 #ifndef V2_BAR_E
 #define V2_BAR_E 0      // 1: the (redundant) barrier between the X reads and the Z writes of pass 1, for A/B
 #endif
+#ifndef V2_PAD
+#define V2_PAD 1        // 1 (round 5): every frame of a tile buffer is padded by 128 bytes (stride 2176): the two frames a 32-lane b64 group of
+                        // pass 1 touches (X reads, Z writes) and the 16 frames a b128 group of pass 2 reads land on different bank halves --
+                        // tools/lds_conflicts_run256v2.py: 382 -> 286 LDS cycles per tile and wave, conflict-free.  0: round 4's dense image (A/B)
+#endif
 #ifndef V2_SNOP
 // Wait states in front of the asm stores would cover a scalar base that comes straight out of a spill lane (v_readlane ->
 // VMEM hazard, fused_v2_common.h); they cost 1 % of the launch, and this kernel has no SGPR spills (the bases are SALU
@@ -59,10 +64,13 @@
 namespace csdr {
 namespace {
 
-constexpr int V2_BUF = 4096;                       // float2 per tile buffer (32 KiB)
+constexpr unsigned V2_FSB = 2048u + (V2_PAD ? 128u : 0u);   // bytes between the frames of a tile buffer
+constexpr int V2_FS2 = (int)V2_FSB / 8;            // the same in float2
+constexpr int V2_BUF = 16 * V2_FS2;                // float2 per tile buffer (32 KiB + 2 KiB of padding)
 // two tile buffers, then: STASH 256, T 16, RED 16, pass-1 twiddles 256
 constexpr int V2_STASH = 2 * V2_BUF;
-constexpr int V2_F2 = V2_STASH + 256 + 32 + 256 + (V2_COLSCAN ? 512 : 0);   // 8736 float2 = 69 888 B: two workgroups per CU (V2_COLSCAN: + run totals and run carries, 73 984 B)
+constexpr int V2_F2 = V2_STASH + 256 + 32 + 256 + (V2_COLSCAN ? 512 : 0);   // 9248 float2 = 73 984 B: two workgroups per CU (dense image: 69 888 B)
+#define V2_ZSW(f) (V2_PAD ? (((f) >> 1) & 7) : ((f) & 7))       // 16-byte slot swizzle of frame f's Z rows
 
 struct V2Args {
     RunArgs r;
@@ -101,7 +109,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const int col_off = 16 * (j >> 4) + 2 * (((j & 15) >> 1) ^ (j >> 5)) + (j & 1);
     const unsigned goff = dma_offset(tid);
     const unsigned wave_u = (unsigned)__builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)R + 1024u * wave_u;
+    // wave w's DMA instruction `it` fills the 1 KiB half (w & 1) of frame 2 it + (w >> 1)
+    const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)R + V2_FSB * (wave_u >> 1) + 1024u * (wave_u & 1u);
 
 #define V2LSTAMP(i) do { if (A.trace && RA.trace_light && tid == 0) A.trace[(size_t)first * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     V2LSTAMP(0);
@@ -114,8 +123,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const bool cold = w > 0 || RA.indep;
     const int halo = (int)first - 1;
     auto tile_ptr = [&](int t) -> const float4 * { return t >= 0 ? x4 + (size_t)t * 2048 : RA.prev_tail + (size_t)(WU + 1 + t) * 2048; };
-    if (first < last) dma_tile(x4 + (size_t)first * 2048, goff, lds_wave);
-    if (cold) dma_tile(tile_ptr(halo), goff, lds_wave + (unsigned)(V2_BUF * 8));
+    if (first < last) dma_tile<false, 2 * V2_FSB>(x4 + (size_t)first * 2048, goff, lds_wave);
+    if (cold) dma_tile<false, 2 * V2_FSB>(tile_ptr(halo), goff, lds_wave + (unsigned)(V2_BUF * 8));
     float h[P];
 #pragma unroll
     for (int n = 0; n < P; n++) h[n] = A.taps[(M256 - 1 - j) + n * M256];
@@ -204,10 +213,10 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         if (h0 == 0 && !RA.indep) ch = cfma(A.vend_in[0], exp2f((float)(4096 * halo) * RA.l2beta), ch);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the two DMA'd tiles (older than every warm-up load)
         __syncthreads();
-        scan_staged(H, E, Tt, A, tid);
+        scan_staged_fs<V2_FS2>(H, E, Tt, A, tid);
 #pragma unroll
-        for (int f = 3; f < NB; f++) wa[f] = H[256 * f + col_off];
-        w2 = H[256 * 2 + col_off];                      // FM: the 14th tap of the halo tile's last frame (freqdem history of the run)
+        for (int f = 3; f < NB; f++) wa[f] = H[V2_FS2 * f + col_off];
+        w2 = H[V2_FS2 * 2 + col_off];                      // FM: the 14th tap of the halo tile's last frame (freqdem history of the run)
         const float kj = -A.alpha * A.bj[j & 15];
         const float br = A.b16[tid & 15], bf = A.b256[tid >> 4];
         float2 vb, ve;
@@ -274,15 +283,15 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                      opaque_v(1e-37f), opaque_v(A.fm_ref), opaque_v(RA.pk.hp), opaque_v(RA.pk.pi)};
     // LDS byte offsets inside a tile buffer that do not change from tile to tile
     const int q = tid, sw = (q >> 1) & 7;
-    const unsigned raw_a = (unsigned)q * 128u + ((unsigned)sw << 4);            // slot i of my run: raw_a ^ (i << 4)
+    const unsigned raw_a = (unsigned)q * 128u + (unsigned)(q >> 4) * (V2_FSB - 2048u) + ((unsigned)sw << 4);   // slot i of my run: raw_a ^ (i << 4)
     const int f1 = tid >> 4, b1 = tid & 15;                                     // pass 1: frame, column digit
     const int k1 = tid >> 4, f2 = tid & 15;                                     // pass 2 / tail: channel digit, frame
-    const unsigned x_a = (unsigned)f1 * 2048u + (unsigned)b1 * 8u;              // X[f1][16 a + b1]: (x_a ^ ((a >> 1) << 4)) + 128 a
-    const unsigned zw_a = (unsigned)(f1 * 256 + ((((b1 >> 1) ^ (f1 & 7)) << 1) | (b1 & 1))) * 8u;   // Z[f1][k1][b1]: + 128 k1
-    const unsigned z_a = (unsigned)(f2 * 256 + k1 * 16) * 8u + ((unsigned)(f2 & 7) << 4);           // pair i of Z[f2][k1][.]: z_a ^ (i << 4)
+    const unsigned x_a = (unsigned)f1 * V2_FSB + (unsigned)b1 * 8u;             // X[f1][16 a + b1]: (x_a ^ ((a >> 1) << 4)) + 128 a
+    const unsigned zw_a = (unsigned)f1 * V2_FSB + (unsigned)((((b1 >> 1) ^ V2_ZSW(f1)) << 1) | (b1 & 1)) * 8u;   // Z[f1][k1][b1]: + 128 k1
+    const unsigned z_a = (unsigned)f2 * V2_FSB + (unsigned)k1 * 128u + ((unsigned)V2_ZSW(f2) << 4);             // pair i of Z[f2][k1][.]: z_a ^ (i << 4)
     // interleaved shard: thread row q = k1 = s NK1 + j1; output row of channel (g + G j1) + 16 k2 in the shard's [M / G][nf] plane: j1 + NK1 k2
     const int j1 = k1 % NK1, hb = (G == 8) ? ((k1 >> 1) & 1) : 0;              // G = 8: lane bit of the slice (slots S0 + 2 hb, S0 + 2 hb + 1)
-    const unsigned z_a_g = (unsigned)(f2 * 256 + G * j1 * 16) * 8u + ((unsigned)(f2 & 7) << 4);
+    const unsigned z_a_g = (unsigned)f2 * V2_FSB + (unsigned)(G * j1) * 128u + ((unsigned)V2_ZSW(f2) << 4);
     const uint32_t voff = ((uint32_t)(G == 1 ? k1 : j1 + 16 * hb) * A.out_stride + A.out_t0 + (uint32_t)f2) * (FM ? 4u : 8u);  // + NK1 k2 rows, + 16 b frames
     const size_t row16 = (size_t)NK1 * A.out_stride * (FM ? 4u : 8u);
 #define V2STAMP(i) do { if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b_ * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -310,11 +319,11 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         // A/B builds (verdict r03 #1 (ii)): the last WU + 1 tiles of a run are the next run's warm-up window + halo, already fetched once
         // at the launch's start; every other tile is read exactly once per launch and gets the streaming policy
         if (!(V2_ABLATE & 1) && b + 1 < last) {
-            if (b + 1 + (WU + 1) < last) dma_tile<true>(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
-            else dma_tile(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
+            if (b + 1 + (WU + 1) < last) dma_tile<true, 2 * V2_FSB>(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
+            else dma_tile<false, 2 * V2_FSB>(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
         }
 #else
-        if (!(V2_ABLATE & 1) && b + 1 < last) dma_tile(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
+        if (!(V2_ABLATE & 1) && b + 1 < last) dma_tile<false, 2 * V2_FSB>(x4 + (size_t)(b + 1) * 2048, goff, lds_wave + (unsigned)(par ^ 1) * (V2_BUF * 8u));
 #endif
 #if V2_COLSCAN
         // ---- DC blocker on the column-layout registers: thread j reads its raw column once; a run of 16 consecutive samples is one
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         // the run totals cross the frame through 2 KiB of LDS (col_run_carries: carry into every run from the earlier runs of its
         // frame, frame totals), the frame states V[f] chain in registers as before
 #pragma unroll
-        for (int f = 0; f < NB; f++) nw[f] = Bf[256 * f + col_off];
+        for (int f = 0; f < NB; f++) nw[f] = Bf[V2_FS2 * f + col_off];
         col_run_scan(nw, TRc, A, tid);
         V2STAMP(2);
         bar();                                          // B_c: run totals visible
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         V2STAMP(3);
         // ---- column layout: thread j owns branch j; frame state chain V[f] (uniform), y = y' - alpha beta^j V[f], pre-mix
 #pragma unroll
-        for (int f = 0; f < NB; f++) nw[f] = Bf[256 * f + col_off];
+        for (int f = 0; f < NB; f++) nw[f] = Bf[V2_FS2 * f + col_off];
         {
             v2f V = to_v(c);
             const v2f kJv = {kJ, kJ}, bv = {b256, b256};
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) Bf[256 * (f0 + u) + col_off] = to_f2(acc[u]);
+            for (int u = 0; u < 4; u++) Bf[V2_FS2 * (f0 + u) + col_off] = to_f2(acc[u]);
         }
         V2STAMP(5);
         bar();                                          // B_d: X complete

@@ -728,6 +728,28 @@ __global__ __launch_bounds__(256) void k_mix(const float *__restrict__ in, float
     out[i] = acc;
 }
 
+// CSDR_FLAG_DFT_BACKWARD: out row k = in row (C - k) mod C; rows of W 4-byte words (V = 4: whole 16-byte vectors)
+template <int V> __global__ void k_rows_reversed(const float *__restrict__ in, float *__restrict__ out, uint32_t C, size_t W)
+{
+    const uint32_t k = blockIdx.y, src = k ? C - k : 0u;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (i >= W) return;
+    if (V == 4) *reinterpret_cast<float4 *>(out + (size_t)k * W + i) = *reinterpret_cast<const float4 *>(in + (size_t)src * W + i);
+    else out[(size_t)k * W + i] = in[(size_t)src * W + i];
+}
+
+int launch_rows_reversed(const void *in, void *out, uint32_t C, size_t row_bytes, hipStream_t s)
+{
+    const size_t W = row_bytes / 4;
+    if (!W || !C) return 0;
+    if (W % 4 == 0 && ((size_t)in | (size_t)out) % 16 == 0)
+        hipLaunchKernelGGL(k_rows_reversed<4>, dim3((unsigned)((W / 4 + 255) / 256), C), dim3(256), 0, s, (const float *)in, (float *)out, C, W);
+    else
+        hipLaunchKernelGGL(k_rows_reversed<1>, dim3((unsigned)((W + 255) / 256), C), dim3(256), 0, s, (const float *)in, (float *)out, C, W);
+    CSDR_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_mix(const float *in, float *out, uint32_t C, uint32_t E, hipStream_t s)
 {
     if (!E) return 0;

@@ -22,6 +22,7 @@
 #include <functional>
 #include <memory>
 #include <stdexcept>
+#include <time.h>
 #include <string>
 #include <vector>
 
@@ -239,7 +240,40 @@ inline Pipe<Array<cf32>, Array<cf32>> mixUp(float f, uint32_t max_in) { return n
 struct ChainOpts {
     uint32_t channels = 1; bool dc_block = true; float agc = 0.f; bool fm = false; bool am = false; bool wbfm = false; uint32_t decim = 4; float deemph_fc = 0.025f; float kf = 0.3f; bool mix = false;
     uint32_t max_frames = 4096; uint32_t flags = CSDR_FLAG_QUIET;
+    // channel shard of a multi-GPU run (one process per GPU): this process owns the channels rank, rank + world, ... (interleaved
+    // ownership); with mix the partial sums meet in ONE all-reduce per chunk (csdr_chain_process_mix over `comm`)
+    uint32_t world = 1, rank = 0; csdr_comm *comm = nullptr; int device = -1;       // device: HIP ordinal of this process's GPU (-1 = current)
+    uint32_t owned() const { return world > 1 ? channels / world : channels; }
+    uint32_t channel_of(uint32_t row) const { return world > 1 ? rank + world * row : row; }       // 0-based channel of output row `row`
 };
+
+// csdr_comm bootstrap through a file (RCCL's unique id is 128 opaque bytes that rank 0 makes and every rank needs): rank 0 writes
+// `path` atomically, the others wait for it.  device -1 = current.
+inline csdr_comm *commFromIdFile(const std::string &path, int rank, int world, int device = -1)
+{
+    unsigned char id[CSDR_COMM_ID_BYTES];
+    if (rank == 0) {
+        check(csdr_comm_unique_id(id));
+        const std::string tmp = path + ".tmp";
+        FILE *f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) throw std::runtime_error("cannot write " + tmp);
+        std::fclose(f);
+        if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+    } else {
+        for (int tries = 0;; tries++) {
+            FILE *f = std::fopen(path.c_str(), "rb");
+            size_t got = 0;
+            if (f) { got = std::fread(id, 1, sizeof id, f); std::fclose(f); }
+            if (got == sizeof id) break;
+            if (tries > 6000) throw std::runtime_error("no communicator id in " + path + " after 60 s");
+            struct timespec ts = {0, 10 * 1000 * 1000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+    csdr_comm *c = nullptr;
+    check(csdr_comm_create(rank, world, id, device, &c));
+    return c;
+}
 
 template <class Out> Pipe<Array<cf32>, std::vector<Array<Out>>> fusedChain(const ChainOpts &o)
 {
@@ -249,6 +283,11 @@ template <class Out> Pipe<Array<cf32>, std::vector<Array<Out>>> fusedChain(const
         csdr_chain_cfg_default(&cfg, o.channels);
         cfg.channels = o.channels; cfg.dc_block = o.dc_block; cfg.agc_threshold_db = o.agc;
         cfg.demod = o.fm ? CSDR_DEMOD_FM : (o.am ? CSDR_DEMOD_AM : (o.wbfm ? CSDR_DEMOD_WBFM : CSDR_DEMOD_NONE)); cfg.wbfm_decim = o.decim; cfg.deemph_fc = o.deemph_fc; cfg.kf = o.kf; cfg.mix = o.mix; cfg.max_frames = o.max_frames; cfg.flags = o.flags;
+        cfg.device = o.device;
+        if (o.world > 1) {
+            if (o.channels % o.world || o.rank >= o.world) throw std::runtime_error("channel shards: world must divide the channel count");
+            cfg.chan_first = o.rank; cfg.chan_stride = o.world;
+        }
         csdr_chain *h = nullptr;
         check(csdr_chain_create(&cfg, &h));
         return std::shared_ptr<void>(h, [](void *q) { csdr_chain_destroy(static_cast<csdr_chain *>(q)); });
@@ -261,12 +300,17 @@ template <class Out> Pipe<Array<cf32>, std::vector<Array<Out>>> fusedChain(const
         const bool mixed = o.mix && M > 1;
         const uint32_t no = o.wbfm ? nf / o.decim : nf;                        // DeWBFM: nf div decim samples per channel
         if (o.wbfm) { nf = no * o.decim; usable = nf * M; }                    // firDecimator drops the leftover (Liquid.chs:495-497)
-        Array<Out> flat((size_t)(mixed ? no : (size_t)M * no));
+        const uint32_t C = o.owned();                                          // rows this process produces
+        Array<Out> flat((size_t)(mixed ? no : (size_t)C * no));
         uint32_t n_out = 0;
-        if (usable) check(csdr_chain_process(h, reinterpret_cast<const float *>(a.data()), usable, flat.data(), &n_out));
+        if (usable) {
+            // --mix across ranks: local left fold over the owned channels + one all-reduce (Trans.hs:119-122 over the node)
+            if (mixed && o.comm) check(csdr_chain_process_mix(h, o.comm, reinterpret_cast<const float *>(a.data()), usable, flat.data(), &n_out));
+            else check(csdr_chain_process(h, reinterpret_cast<const float *>(a.data()), usable, flat.data(), &n_out));
+        }
         std::vector<Array<Out>> outs;
         if (mixed || M == 1) { outs.push_back(std::move(flat)); return outs; }
-        for (uint32_t k = 0; k < M; k++) outs.emplace_back(flat.begin() + (size_t)k * no, flat.begin() + (size_t)(k + 1) * no);
+        for (uint32_t k = 0; k < C; k++) outs.emplace_back(flat.begin() + (size_t)k * no, flat.begin() + (size_t)(k + 1) * no);
         return outs;
     };
     p.done = [](void *) {};

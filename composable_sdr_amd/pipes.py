@@ -249,6 +249,7 @@ class ChainConfig:
     pfb_m: int = 7
     pfb_as: float = 80.0
     tail_only: bool = False     # CSDR_FLAG_TAIL_ONLY: the per-channel tail alone on a channel-major CF32 plane [channels][nf]
+    dft_backward: bool = False  # CSDR_FLAG_DFT_BACKWARD: the analyzer's transform as e^{+j} (row k = forward row (M - k) mod M); include/csdr.h
 
 
 class Chain:
@@ -267,7 +268,7 @@ class Chain:
         c.kf, c.mix = cfg.kf, int(cfg.mix)
         c.chan_first, c.chan_count = cfg.chan_first, cfg.chan_count
         c.chan_stride = cfg.chan_stride
-        c.device, c.max_frames, c.flags = cfg.device, cfg.max_frames, cfg.flags | (_lib.FLAG_TAIL_ONLY if cfg.tail_only else 0)
+        c.device, c.max_frames, c.flags = cfg.device, cfg.max_frames, cfg.flags | (_lib.FLAG_TAIL_ONLY if cfg.tail_only else 0) | (_lib.FLAG_DFT_BACKWARD if cfg.dft_backward else 0)
         c.pfb_m, c.pfb_as = cfg.pfb_m, cfg.pfb_as
         h = C.c_void_p()
         check(lib().csdr_chain_create(C.byref(c), C.byref(h)))

@@ -33,11 +33,60 @@ Two partitions of the reference's `-c M` channelizer:
 Outputs stay on the rank that made them (per-channel files are written per rank); gather()
 collects them on rank 0 for tests.
 """
+import ctypes as C
 from dataclasses import replace
 
 import numpy as np
 
-from .pipes import Chain, ChainConfig
+from . import _lib
+from ._lib import check, lib
+from .pipes import Chain, ChainConfig, _Handle
+
+
+class Comm:
+    """`csdr_comm` (include/csdr.h): the collectives UNDER the C ABI -- RCCL over xGMI, one process per GPU.  What a non-Python host
+    (the Haskell program, host/soapy_sdr_file.cpp) calls; ShardedChain uses it instead of torch.distributed whenever the ranks are
+    on GPUs.  Bootstrapping: rank 0 makes `unique_id()`, every rank creates the communicator with those bytes (collective)."""
+
+    def __init__(self, rank, world, unique_id, device=-1):
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError("unique_id: %d bytes" % _lib.COMM_ID_BYTES)
+        h = C.c_void_p()
+        buf = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        check(lib().csdr_comm_create(rank, world, buf, device, C.byref(h)))
+        self._h = _Handle(h, lib().csdr_comm_destroy)
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * _lib.COMM_ID_BYTES)()
+        check(lib().csdr_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_process_group(cls, dist, group=None, device=-1):
+        """One csdr_comm per rank of an initialised torch.distributed group: rank 0's id travels over the group's own store."""
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(rank, world, box[0], device)
+
+    @property
+    def h(self):
+        return self._h.h
+
+    def allreduce_f32(self, d_ptr, count, stream=0):
+        check(lib().csdr_comm_allreduce_f32(self.h, C.c_void_p(d_ptr), count, C.c_void_p(stream)))
+
+    def broadcast(self, d_ptr, nbytes, root=0, stream=0):
+        check(lib().csdr_comm_broadcast(self.h, C.c_void_p(d_ptr), nbytes, root, C.c_void_p(stream)))
+
+    def hybrid_exchange(self, d_plane, d_recv, chan_per_rank, stripe_frames, elem_bytes=8, stream=0):
+        fr = (C.c_uint32 * len(stripe_frames))(*stripe_frames)
+        check(lib().csdr_hybrid_exchange(self.h, C.c_void_p(d_plane), C.c_void_p(d_recv), chan_per_rank, fr, elem_bytes, C.c_void_p(stream)))
+
+    def close(self):
+        self._h.close()
 
 WARMUP_SAMPLES = 32768     # DC blocker: (1 - 0.0005)^32768 = 7.6e-8 of the state is left
 
@@ -64,12 +113,20 @@ def channel_bounds(M, world, rank):
 
 class ShardedChain:
     def __init__(self, cfg: ChainConfig, mode="time", rank=None, world=None, group=None, chain_factory=Chain, interleave=False,
-                 tail_factory=None):
+                 tail_factory=None, comm=None):
+        """comm: a `Comm` (csdr_comm, the C ABI's collectives) to use for the data-path exchanges.  None: when the process group's
+        backend is RCCL ("nccl") one is made from the group (`Comm.from_process_group`), so that on GPUs every collective of the
+        data path goes through the C entry points a non-Python host would call; gloo groups (the CPU tests, several ranks on one
+        GPU) keep torch.distributed."""
         import torch.distributed as dist
         self.dist = dist if dist.is_available() and dist.is_initialized() else None
         self.rank = rank if rank is not None else (self.dist.get_rank(group) if self.dist else 0)
         self.world = world if world is not None else (self.dist.get_world_size(group) if self.dist else 1)
         self.group, self.mode, self.cfg = group, mode, cfg
+        self.comm = comm
+        if comm is None and self.dist is not None and self.world > 1 and self.dist.get_backend(group) == "nccl" and chain_factory is Chain:
+            self.comm = Comm.from_process_group(self.dist, group, cfg.device)
+        self._s_comm = None                          # second stream of the overlapped hybrid step
         if mode == "time":
             if cfg.agc != 0.0 and self.world > 1:
                 raise ValueError("time stripes cannot carry the AGC state; use mode='channel' with the AGC on")
@@ -97,6 +154,10 @@ class ShardedChain:
                 raise ValueError("hybrid sharding is for the AGC configurations; without the AGC use mode='time'")
             if cfg.demod not in ("none", "fm"):
                 raise ValueError("hybrid sharding: demod none / fm")
+            if cfg.mix:
+                # a rank's tail would return the partial mix of ITS channel block only and nothing here reduces those:
+                # `--mix` shards by channel (mode="channel": local left fold + one all-reduce)
+                raise ValueError("hybrid sharding does not reduce --mix across ranks; use mode='channel' with mix")
             self.interleave = False
             self.cn = cfg.channels // self.world
             self.c0 = self.rank * self.cn                     # contiguous channel blocks: the front end's plane is already grouped by destination rank
@@ -173,40 +234,90 @@ class ShardedChain:
         pieces = [np.ascontiguousarray(t.cpu().numpy()).view(np.complex64).reshape(self.cn, -1) for t in self.hybrid_exchange(plane, bounds)]
         return self.hybrid_tail(pieces)
 
-    def process_device_hybrid(self, x_dev, plane_dev, recv_dev, out_dev, stream=0):
-        """GPU-resident hybrid step (bench): x_dev = this rank's stripe (interleaved CF32 as float32, nf frames, state carried from the
-        rank's previous stripe), plane_dev / recv_dev = [M][nf][2] float32 scratch, out_dev = [G][M / G][nf] output elements (the G
-        stretches of the whole span, in time order).  Front end -> ONE all_to_all_single on the plane (RCCL over xGMI) -> the tail on
-        each stretch.  Equal stripes."""
+    def _exchange_device(self, plane_dev, recv_dev, nfs, stream):
+        """All-to-all of one sub-stripe's plane ([M][nfs][2] float32 -> [G][M / G][nfs][2]) on `stream` (an int handle).  RCCL through
+        the C ABI (csdr_hybrid_exchange) when the ranks have a csdr_comm; otherwise torch.distributed (gloo: through host memory)."""
         import torch
-        G, M = self.world, self.cfg.channels
-        nf = x_dev.numel() // 2 // M
-        self.chain.process_device(x_dev.data_ptr(), M * nf, plane_dev.data_ptr(), stream)
-        if self.dist is not None and G > 1:
-            cur = torch.cuda.current_stream(plane_dev.device) if plane_dev.is_cuda else None
-            if cur is not None and int(stream or 0) != int(cur.cuda_stream):
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.ExternalStream(int(stream or 0), device=plane_dev.device))
-                cur.wait_event(ev)
+        G = self.world
+        if G == 1 and self.comm is None:
+            recv_dev.copy_(plane_dev)
+            return
+        if self.comm is not None:
+            self.comm.hybrid_exchange(plane_dev.data_ptr(), recv_dev.data_ptr(), self.cn, [nfs] * G, 8, stream)
+            return
+        ext = torch.cuda.ExternalStream(int(stream), device=plane_dev.device) if (plane_dev.is_cuda and stream) else None
+        with (torch.cuda.stream(ext) if ext is not None else _nullctx()):
             if plane_dev.is_cuda and self.dist.get_backend(self.group) != "nccl":
                 # (test harness: several ranks on one GPU over gloo -- the exchange goes through host memory)
-                cur.synchronize()
+                (ext or torch.cuda.current_stream(plane_dev.device)).synchronize()
                 hp = plane_dev.cpu(); hr = torch.empty_like(hp)
                 self.dist.all_to_all_single(hr, hp, group=self.group)
                 recv_dev.copy_(hr)
             else:
                 self.dist.all_to_all_single(recv_dev, plane_dev, group=self.group)
-            if cur is not None and int(stream or 0) != int(cur.cuda_stream):
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                torch.cuda.ExternalStream(int(stream or 0), device=plane_dev.device).wait_event(ev)
-        else:
-            recv_dev = plane_dev
-        per = self.cn * nf * 2                                         # float32 elements of one stretch
+
+    def process_device_hybrid(self, x_dev, plane_dev, recv_dev, out_dev, stream=0, substripes=1, overlap=False):
+        """GPU-resident hybrid step (bench): x_dev = this rank's stretch of the step (interleaved CF32 as float32, nf frames, state carried
+        from the rank's previous stretch), plane_dev / recv_dev = [M][nf][2] float32 scratch, out_dev = the output elements.
+
+        The step's time order is S = `substripes` rounds of G sub-stripes: round i holds sub-stripe i of rank 0, 1, ..., G - 1
+        (S = 1: one stripe per rank, round 4's layout).  Per round: front end on the rank's sub-stripe -> ONE all-to-all of that plane
+        (RCCL over xGMI: csdr_hybrid_exchange) -> the tail walks the round's G stretches in time order (it is streaming-stateful).
+        out_dev = [S][G][M / G][nf / S] elements.
+
+        overlap=True (needs S >= 2 to matter): the exchanges run on a second stream, so that round i's plane crosses the links while
+        the front end of round i + 1 runs, and round i + 1's exchange runs under round i's tail; the tail calls stay in time order on
+        `stream`.  Same kernels, same order per handle: bit-identical to overlap=False."""
+        import torch
+        G, M, S = self.world, self.cfg.channels, int(substripes)
+        nf = x_dev.numel() // 2 // M
+        if nf % S or (nf // S) % 32:
+            raise ValueError("hybrid step: %d frames do not split into %d sub-stripes of whole 32-frame lines" % (nf, S))
+        nfs = nf // S
         w = 1 if self.cfg.demod == "fm" else 2
+        dev = plane_dev.device
+        on_gpu = plane_dev.is_cuda
+        s_main = int(stream or 0)
+        if on_gpu and not s_main:
+            s_main = int(torch.cuda.current_stream(dev).cuda_stream)
+        if overlap and on_gpu:
+            if self._s_comm is None:
+                self._s_comm = torch.cuda.Stream(device=dev)
+            s_x = int(self._s_comm.cuda_stream)
+        else:
+            s_x = s_main
+        main = torch.cuda.ExternalStream(s_main, device=dev) if (on_gpu and s_main) else (torch.cuda.current_stream(dev) if on_gpu else None)
+        xch = torch.cuda.ExternalStream(s_x, device=dev) if (on_gpu and s_x) else main
+        xf = x_dev.view(-1)
+        pf, rf, of = plane_dev.view(-1), recv_dev.view(-1), out_dev.view(-1)
+        done = []
+        for i in range(S):
+            pl = pf[i * M * nfs * 2:(i + 1) * M * nfs * 2]
+            rv = rf[i * M * nfs * 2:(i + 1) * M * nfs * 2]
+            self.chain.process_device(xf[i * M * nfs * 2:].data_ptr(), M * nfs, pl.data_ptr(), s_main)
+            if on_gpu and s_x != s_main:
+                ev = torch.cuda.Event(); ev.record(main); xch.wait_event(ev)
+            self._exchange_device(pl, rv, nfs, s_x)
+            if on_gpu and s_x != s_main:
+                ev = torch.cuda.Event(); ev.record(xch); done.append(ev)
+            else:
+                done.append(None)
+            if not overlap:
+                self._hybrid_tail_round(rv, of, i, nfs, w, s_main, main, done[i])
+        if overlap:
+            for i in range(S):
+                rv = rf[i * M * nfs * 2:(i + 1) * M * nfs * 2]
+                self._hybrid_tail_round(rv, of, i, nfs, w, s_main, main, done[i])
+        return S * G * self.cn * nfs
+
+    def _hybrid_tail_round(self, rv, of, i, nfs, w, s_main, main, ev):
+        G = self.world
+        if ev is not None:
+            main.wait_event(ev)
+        per = self.cn * nfs * 2                                        # float32 elements of one stretch of the plane
         for k in range(G):
-            self.tail.process_device(recv_dev.data_ptr() + 4 * per * k, self.cn * nf, out_dev.data_ptr() + 4 * self.cn * nf * w * k, stream)
-        return G * self.cn * nf
+            o = (i * G + k) * self.cn * nfs * w
+            self.tail.process_device(rv[per * k:].data_ptr(), self.cn * nfs, of[o:].data_ptr(), s_main)
 
     # ------------------------------------------------------------------ time stripes
     def process_stream(self, x):
@@ -253,6 +364,12 @@ class ShardedChain:
         """channel mode + mix with GPU-resident tensors (torch, on this rank's device): the chain writes the rank's partial
         mix straight into `out_dev`, then ONE all-reduce(SUM) on that tensor over RCCL/xGMI -- no host copy.  `x_dev`:
         the chunk (interleaved CF32 as float32), the same on every rank; returns the number of output elements."""
+        if self.comm is not None:
+            # the C ABI's entry point: chain + ncclAllReduce on the caller's stream (what a non-Python host calls)
+            n_out = C.c_uint32()
+            check(lib().csdr_chain_process_device_mix(self.chain.h, self.comm.h, C.c_void_p(x_dev.data_ptr()), x_dev.numel() // 2,
+                                                      C.c_void_p(out_dev.data_ptr()), C.byref(n_out), C.c_void_p(int(stream or 0))))
+            return n_out.value
         n = self.chain.process_device(x_dev.data_ptr(), x_dev.numel() // 2, out_dev.data_ptr(), stream)
         if self.dist is not None and self.world > 1:
             if out_dev.is_cuda:
@@ -282,3 +399,11 @@ class ShardedChain:
             return full
         objs = [o for o in objs if o is not None and o.size]
         return np.concatenate(objs, axis=-1 if self.mode == "time" else 0)
+
+
+class _nullctx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

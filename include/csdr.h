@@ -81,6 +81,16 @@ extern "C" {
                                      * all-to-all turns time stripes into channel shards, every rank runs this tail on its channels for
                                      * the whole time span.  Needs agc_threshold_db != 0; dc_block, chan_*, pfb_* are ignored.         */
 
+#define CSDR_FLAG_DFT_BACKWARD 128u /* The direction of firpfbch_crcf_analyzer_execute's transform (Liquid.chs:843) is recalled, not pinned by
+                                     * anything in the reference (hard part 1): the library computes the FORWARD DFT
+                                     * out[k] = sum_j X[j] e^{-j 2 pi jk/M}.  With this flag the handle delivers the other possible
+                                     * convention, out[k] = sum_j X[j] e^{+j 2 pi jk/M} = forward bin (M - k) mod M: output row k (file
+                                     * _ch<k+1>) is the forward chain's row (M - k) mod M, every per-channel tail (AGC, demod) unchanged
+                                     * on its row.  One extra pass over the OUTPUT (a row permutation behind the fused kernels); whole-band
+                                     * handles only (channel shards: CSDR_ERR_INVALID); with mix the sum over all channels is the same set
+                                     * of terms, so only the fold order differs (no-op).  Should a diff against a real liquid-dsp 1.3.2
+                                     * show the backward convention, this flag becomes the default and nothing else changes.        */
+
 const char *csdr_last_error(void);
 int  csdr_device_count(void);
 /* library / build identification: "csdr-hip gfx950 <version>" */
@@ -309,6 +319,50 @@ int  csdr_chain_debug_agc(csdr_chain *h, uint32_t *checked, uint32_t *redone);
 /* Calls since create whose AGC tail ran on a tile-major plane (k_agc_spec_tm: fused 256- and 1024-channel chains, run-sized calls of whole
  * 16-frame tiles; every other call takes the row-major k_agc_spec).  Both produce the sequential recurrence bit for bit. */
 uint32_t csdr_chain_debug_agc_tile_major_calls(const csdr_chain *h);
+
+/* the configuration a handle was created with (defaults filled in) */
+int  csdr_chain_get_cfg(const csdr_chain *h, csdr_chain_cfg *cfg_out);
+
+/* ------------------------------------------------------------------------ *
+ * Collectives: one process per GPU, RCCL over xGMI (csrc/comm.cpp).
+ *
+ * The reference reduces `--mix` on one host thread: `mix` = foldl1 (+) over the channel
+ * list (Trans.hs:119-122) behind `mux (replicate nch demod) . firpfbchChannelizer nc`
+ * (SoapySDR.hs:217-222).  When the -c N channels are split over the GPUs of a node every
+ * rank's chain folds its own channels and ONE all-reduce(SUM) of the nf output elements per
+ * chunk adds the partial mixes (summation order differs from the strict left fold: tolerance).
+ * Bootstrapping follows RCCL: rank 0 makes an id (csdr_comm_unique_id), the host hands the
+ * CSDR_COMM_ID_BYTES to every rank by its own means (a file, an environment variable, the
+ * Haskell program's command line), every rank calls csdr_comm_create with it (collective,
+ * blocking).  librccl.so.1 is loaded on the first csdr_comm_* call, not with the library.
+ * All calls enqueue on the caller's `stream` and do not synchronise.
+ * ------------------------------------------------------------------------ */
+#define CSDR_COMM_ID_BYTES 128
+typedef struct csdr_comm csdr_comm;
+int csdr_comm_unique_id(void *id_out);
+int csdr_comm_create(int rank, int world, const void *id, int device /* -1 = current */, csdr_comm **out);
+int csdr_comm_rank(const csdr_comm *c);
+int csdr_comm_world(const csdr_comm *c);
+int csdr_comm_destroy(csdr_comm *c);
+/* d_buf (bytes) of rank `root` -> every rank: the chunk a channel-sharded node works on (8 B per input sample) */
+int csdr_comm_broadcast(csdr_comm *c, void *d_buf, size_t bytes, int root, void *stream);
+/* in-place sum over ranks of `count` floats */
+int csdr_comm_allreduce_f32(csdr_comm *c, void *d_buf, size_t count, void *stream);
+/* csdr_chain_process_device of a channel-shard handle created with mix = 1, then the all-reduce of its output: d_out holds
+ * the mix over ALL channels on every rank (Trans.hs:119-122 across ranks).  *n_out = elements (nf). */
+int csdr_chain_process_device_mix(csdr_chain *h, csdr_comm *c, const void *d_in_cf32, uint32_t n_in, void *d_out, uint32_t *n_out,
+                                  void *stream);
+/* The same for host buffers (blocking, like csdr_chain_process): what a host that keeps its chunks in its own memory calls --
+ * the Haskell fold, host/soapy_sdr_file.cpp --world/--rank.  Every rank receives the full mix; the reference has ONE sink for it
+ * (SoapySDR.hs:217-222), so rank 0 writes the file. */
+int csdr_chain_process_mix(csdr_chain *h, csdr_comm *c, const float *in_cf32, uint32_t n_in, void *out, uint32_t *n_out);
+/* The exchange of the hybrid partition (replaces the hand-over between firpfbchChannelizer and `mux`, Trans.hs:124-129,
+ * when time stripes feed channel-block tails): d_plane = this rank's front-end output [world][chan_per_rank][stripe_frames[rank]]
+ * (a DeNo chain's channel-major plane: destination p's rows are contiguous), elem_bytes 8 (CF32) or 4.  d_recv receives, for
+ * p = 0 .. world-1 in time order, rank p's stripe of MY channel block: [chan_per_rank][stripe_frames[p]] at element offset
+ * chan_per_rank * sum_{q<p} stripe_frames[q].  One grouped ncclSend / ncclRecv per peer (every xGMI link carries one block each way). */
+int csdr_hybrid_exchange(csdr_comm *c, const void *d_plane, void *d_recv, uint32_t chan_per_rank, const uint32_t *stripe_frames,
+                         uint32_t elem_bytes, void *stream);
 
 #ifdef __cplusplus
 }

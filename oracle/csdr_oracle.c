@@ -250,6 +250,15 @@ void orc_pfb_destroy(orc_pfb *q)
     free(q->h); free(q->hsub); free(q->w); free(q->twr); free(q->twi); free(q->fr); free(q->fi); free(q);
 }
 const float *orc_pfb_taps(const orc_pfb *q) { return q->h; }
+/* The direction of firpfbch_crcf_analyzer_execute's transform (Liquid.chs:843) is RECALLED (forward, e^{-j}): nothing in the
+ * reference pins it (hard part 1).  backward != 0 makes every later analyzer_execute use e^{+j 2 pi jk/M}
+ * instead -- the other possible convention -- by conjugating the twiddle table; the product's CSDR_FLAG_DFT_BACKWARD is tested
+ * against this. */
+void orc_pfb_set_dft_backward(orc_pfb *q, int backward)
+{
+    for (unsigned k = 0; k < q->M; k++)
+        q->twi[k] = sin((backward ? 2.0 : -2.0) * M_PI * (double)k / (double)q->M);
+}
 
 /* forward, unnormalised DFT of X[0..M) (f64 inside) */
 static void orc_dft_forward(orc_pfb *q, const cf32 *X, cf32 *y)
@@ -326,6 +335,7 @@ orc_chan *orc_chan_create(unsigned M)
     return q;
 }
 void orc_chan_destroy(orc_chan *q) { if (q) { orc_pfb_destroy(q->fb); orc_nco_destroy(q->nco); free(q); } }
+void orc_chan_set_dft_backward(orc_chan *q, int backward) { orc_pfb_set_dft_backward(q->fb, backward); }
 uint32_t orc_chan_dtheta(const orc_chan *q) { return q->nco->d_theta; }
 uint32_t orc_chan_theta(const orc_chan *q) { return q->nco->theta; }
 
@@ -779,6 +789,7 @@ orc_chain *orc_chain_create_wbfm(unsigned M, int dc_block, int agc_enable, float
     for (unsigned k = 0; k < M; k++) { q->de[k] = orc_butter2_lowpass_create(deemph_fc); q->dec[k] = orc_firdecim_create_kaiser(decim, 10, 60.0f); }
     return q;
 }
+void orc_chain_set_dft_backward(orc_chain *q, int backward) { if (q->chan) orc_chan_set_dft_backward(q->chan, backward); }
 void orc_chain_destroy(orc_chain *q)
 {
     if (!q) return;

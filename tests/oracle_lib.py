@@ -51,6 +51,9 @@ def lib():
             "orc_pfb_destroy": (None, [vp]),
             "orc_pfb_taps": (vp, [vp]),
             "orc_pfb_analyzer_execute": (None, [vp, vp, vp]),
+            "orc_pfb_set_dft_backward": (None, [vp, i32]),
+            "orc_chan_set_dft_backward": (None, [vp, i32]),
+            "orc_chain_set_dft_backward": (None, [vp, i32]),
             "orc_chan_create": (vp, [u32]),
             "orc_chan_destroy": (None, [vp]),
             "orc_chan_dtheta": (u32, [vp]),
@@ -362,7 +365,7 @@ class Chain(_Obj):
     """assembleFold's DSP (SoapySDR.hs:208-226) on compacted chunks."""
     _destroy = "orc_chain_destroy"
 
-    def __init__(self, M, dc_block=True, agc_db=0.0, demod="none", kf=0.3, mix=False, decim=4, deemph_fc=0.025):
+    def __init__(self, M, dc_block=True, agc_db=0.0, demod="none", kf=0.3, mix=False, decim=4, deemph_fc=0.025, dft_backward=False):
         self.M = M
         self.demod = {"none": 0, "fm": 1, "am": 2, "wbfm": 3}[demod]
         self.mix = bool(mix) and M > 1
@@ -373,6 +376,8 @@ class Chain(_Obj):
         else:
             self.h = lib().orc_chain_create(M, int(dc_block), int(agc_db != 0.0), np.float32(agc_db),
                                             self.demod, np.float32(kf), int(self.mix))
+        if dft_backward:                      # the other possible convention of the analyzer's transform (unpinned: SURVEY 7.1)
+            lib().orc_chain_set_dft_backward(self.h, 1)
 
     def process(self, x):
         x = _c64(x)

@@ -24,10 +24,23 @@ def synth_cf32(n, M, seed=20260101, n0=0, dc=(0.01 + 0.01j), sigma=0.05, amp=0.5
     fm = (1.0 / M) / 64.0                    # cycles/sample
     dev = 0.2 * (1.0 / M) / 2.0              # peak deviation, cycles/sample
     x = np.full(n, dc, dtype=np.complex128)
-    for i, k in enumerate(act):
-        wk = channel_centre(k, M)
-        ph = wk * t + (dev / fm) * np.sin(2 * np.pi * fm * t + 0.37 * i)
-        x += a * np.exp(1j * ph)
+
+    def carriers(lo, hi):                    # every sample sums its tones in the same order whatever the blocking
+        tb, xb = t[lo:hi], x[lo:hi]
+        for i, k in enumerate(act):
+            wk = channel_centre(k, M)
+            ph = wk * tb + (dev / fm) * np.sin(2 * np.pi * fm * tb + 0.37 * i)
+            xb += a * np.exp(1j * ph)
+    if n * len(act) <= (1 << 22):
+        carriers(0, n)
+    else:
+        # n x (M / 4) complex exponentials (40 s for 2 M samples of the 1024-channel signal on one core: most of the GPU suite's wall
+        # time): blocks of time on a thread pool (numpy's ufuncs release the GIL)
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        blk = 1 << 15
+        with ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1)) as ex:
+            list(ex.map(lambda lo: carriers(lo, min(n, lo + blk)), range(0, n, blk)))
     x += (sigma / np.sqrt(2)) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
     return x.astype(np.complex64)
 

@@ -650,6 +650,124 @@ def test_hybrid_sharding_two_ranks_on_one_gpu():
     assert np.median(d[op]) < 2e-5 and np.quantile(d, 0.999) < 5e-4
 
 
+@pytest.mark.parametrize("M,demod,agc", [(256, "fm", 0.0), (64, "none", 0.0), (20, "none", 0.0), (1024, "fm", 0.0), (256, "fm", 10.0), (8, "wbfm", 0.0)])
+def test_dft_direction_flag_matches_a_backward_dft_oracle(M, demod, agc):
+    """SURVEY section 7, hard part 1: the direction of firpfbch_crcf_analyzer_execute's transform is recalled, not pinned.  With
+    CSDR_FLAG_DFT_BACKWARD the handle delivers the other convention; checked against the oracle run with an actual e^{+j} DFT
+    (oracle/csdr_oracle.c orc_pfb_set_dft_backward), every route (fused 64 / 256 / 1024, any-M, AGC tail, WBFM tail), over two calls."""
+    nfs = [96, 40] if M != 8 else [96, 48]
+    x = synth_cf32(M * sum(nfs), M, seed=300 + M)
+    ch = cs.Chain(channels=M, demod=demod, kf=0.3, agc=agc, max_frames=max(nfs), dft_backward=True)
+    fw = cs.Chain(channels=M, demod=demod, kf=0.3, agc=agc, max_frames=max(nfs))
+    assert "dft-backward" in ch.path
+    orc = O.Chain(M, demod=demod, kf=0.3 if demod != "wbfm" else 0.6, agc_db=agc, dft_backward=True)
+    pos = 0
+    perm = [(M - k) % M for k in range(M)]
+    for nf in nfs:
+        c = x[pos:pos + nf * M]; pos += nf * M
+        got, fwd, want = ch.process(c), fw.process(c), orc.process(c)
+        assert np.array_equal(got.view(np.uint32), fwd[perm].view(np.uint32))       # exactly the forward handle's rows, re-labelled
+        if demod == "none":
+            assert rel_rms(got, want) < 1e-5
+        elif agc:
+            assert int(np.sum((got == 0) != (want == 0))) == 0
+        else:
+            kf = 0.6 if demod == "wbfm" else 0.3
+            d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf)) if demod == "fm" else np.abs(got - want)
+            assert np.median(d) < 2e-5, (M, demod, np.median(d))
+    ch.close(); fw.close()
+    with pytest.raises(cs.CsdrError):
+        cs.Chain(channels=256, chan_first=1, chan_stride=2, dft_backward=True)     # shards: not built
+
+
+def test_comm_collectives_under_the_c_abi_world_of_one():
+    """include/csdr.h csdr_comm (RCCL loaded on demand) end to end on this box's one GPU: a communicator of one rank, then
+    csdr_chain_process_device_mix (chain + ncclAllReduce on the caller's stream) against the oracle's `mix` (Trans.hs:119-122),
+    csdr_comm_broadcast, and csdr_hybrid_exchange (its own block: a device copy).  N > 1 cannot be formed here (one GPU per box)."""
+    import torch
+    from composable_sdr_amd.pipes import ChainConfig
+    from composable_sdr_amd.sharded import Comm, ShardedChain
+    dev = torch.device("cuda", 0)
+    comm = Comm(0, 1, Comm.unique_id())
+    assert (comm.rank, comm.world) == (0, 1)
+    assert cs.lib().csdr_comm_rank(comm.h) == 0 and cs.lib().csdr_comm_world(comm.h) == 1
+    stream = torch.cuda.current_stream().cuda_stream
+    for M, demod, agc in ((64, "fm", 0.0), (256, "none", 0.0), (20, "fm", -10.0)):
+        nf = 2048
+        x = synth_cf32(M * nf, M, seed=900 + M)
+        sc = ShardedChain(ChainConfig(channels=M, demod=demod, kf=0.3, agc=agc, mix=True, max_frames=nf), mode="channel", rank=0, world=1, comm=comm)
+        xd = torch.from_numpy(x.view(np.float32).copy()).to(dev)
+        w = 1 if demod == "fm" else 2
+        od = torch.zeros(nf * w, dtype=torch.float32, device=dev)
+        n = sc.process_device_mix(xd, od, stream)
+        torch.cuda.synchronize()
+        assert n == nf
+        got = od.cpu().numpy()
+        got = got if demod == "fm" else got.view(np.complex64)
+        want = O.Chain(M, demod=demod, kf=0.3, agc_db=agc, mix=True).process(x)
+        local = cs.Chain(channels=M, demod=demod, kf=0.3, agc=agc, mix=True, max_frames=nf).process(x)
+        assert np.array_equal(got.view(np.uint32), local.view(np.uint32))           # a sum over one rank changes nothing
+        e = np.abs(got - want).max() / max(np.abs(want).max(), 1e-9)
+        print(f"csdr_chain_process_device_mix M={M} {demod} agc={agc}: max err / max = {e:.2e}")
+        assert e < 2e-5 * np.sqrt(M)
+        # a chain without mix is refused
+        plain = cs.Chain(channels=M, demod=demod, kf=0.3, max_frames=nf)
+        rc = cs.lib().csdr_chain_process_device_mix(plain.h, comm.h, xd.data_ptr(), M * nf, od.data_ptr(), None, stream)
+        assert rc == -1 and b"mix" in cs.lib().csdr_last_error()
+        plain.close(); sc.chain.close()
+    # broadcast from the only rank: the buffer is untouched; the hybrid exchange of a one-rank world is a copy of the plane
+    buf = torch.arange(1 << 16, dtype=torch.float32, device=dev)
+    keep = buf.clone()
+    comm.broadcast(buf.data_ptr(), buf.numel() * 4, 0, stream)
+    recv = torch.zeros_like(buf)
+    comm.hybrid_exchange(buf.data_ptr(), recv.data_ptr(), 32, [buf.numel() // 2 // 32], 8, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, keep) and torch.equal(recv, keep)
+    comm.close()
+
+
+def test_hybrid_step_overlapped_is_bit_identical_to_serial():
+    """The overlapped hybrid step (ShardedChain.process_device_hybrid(substripes=2, overlap=True): exchanges on a second stream, under
+    the next round's front end and the previous round's tail) against the same rounds with everything in line on one stream: bit for
+    bit, over several steps with the state carried; and against the single chain with the AGC on (a one-rank world: the stripes ARE the
+    stream).  The exchange goes through the C ABI (csdr_hybrid_exchange on a one-rank RCCL communicator)."""
+    import torch
+    from composable_sdr_amd.pipes import ChainConfig
+    from composable_sdr_amd.sharded import Comm, ShardedChain
+    from synth import synth_cf32_torch
+    dev = torch.device("cuda", 0)
+    M, nf, kf, steps = 256, 32768, 0.3, 3
+    comm = Comm(0, 1, Comm.unique_id())
+    cfg = ChainConfig(channels=M, demod="fm", kf=kf, agc=10.0, max_frames=nf)
+    xs = [synth_cf32_torch(M * nf, M, dev, seed=880 + i).view(-1) for i in range(steps)]
+    outs = {}
+    for ov in (False, True):
+        sc = ShardedChain(cfg, mode="hybrid", rank=0, world=1, comm=comm)
+        plane = torch.empty(M * nf * 2, dtype=torch.float32, device=dev); recv = torch.empty_like(plane)
+        side = torch.cuda.Stream(device=dev)                     # not the default stream: the caller's stream is honoured
+        res = []
+        for i in range(steps):
+            out = torch.zeros(M * nf, dtype=torch.float32, device=dev)
+            n = sc.process_device_hybrid(xs[i], plane, recv, out, side.cuda_stream, substripes=2, overlap=ov)
+            assert n == M * nf
+            res.append(out)
+        torch.cuda.synchronize()
+        outs[ov] = [o.cpu().numpy().reshape(2, M, nf // 2) for o in res]
+        sc.chain.close(); sc.tail.close()
+    for a, b in zip(outs[False], outs[True]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    one = cs.Chain(channels=M, demod="fm", kf=kf, agc=10.0, max_frames=nf)
+    for i in range(steps):
+        xh = xs[i].cpu().numpy().view(np.complex64)
+        for r in range(2):                                       # the single chain in the same calls: same kernels on the same samples
+            want = one.process(xh[r * M * nf // 2:(r + 1) * M * nf // 2])
+            assert np.array_equal(outs[True][i][r].view(np.uint32), want.view(np.uint32)), (i, r)
+    one.close(); comm.close()
+    from composable_sdr_amd.pipes import ChainConfig as CC
+    with pytest.raises(ValueError):
+        ShardedChain(CC(channels=M, demod="fm", kf=kf, agc=10.0, mix=True, max_frames=nf), mode="hybrid", rank=0, world=1)   # ADVICE r04
+
+
 @pytest.mark.parametrize("shard,mix", [("channel", True), ("channel", False), ("time", False)])
 def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
     """bench.py's N > 1 paths end to end under torch.distributed.run with two ranks (both on this box's only GPU, gloo
@@ -682,6 +800,11 @@ def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
         # the AGC configuration through time-sharded front ends, one all-to-all and channel-sharded tails, same run
         hy = r["hybrid"]
         assert hy["value"] > 0 and hy["scaling"] == "weak" and "all_to_all" in hy["path"] and "tail-only" in hy["path"] and hy["rccl_ranks"] == 2
+        assert hy["overlap"]["substripes"] == 2 and hy["overlap"]["ms_per_step_serial"] > 0 and r["value_hybrid"] == hy["value"]
+    if shard == "time":
+        assert r["value_channel_shard"] == r["channel_shard"]["value"]
+    # the label names the kernel that was timed, not a create-time string
+    assert r["config"]["path"].endswith("|" + r["roofline"]["kernel"])
 
 
 def test_seek_frames_sets_premix_phase():
@@ -776,6 +899,48 @@ def test_cpp_soapy_sdr_file_matches_python_replay(tmp_path):
         a = np.fromfile(tmp_path / f"py_ch{k}.f32", dtype=np.float32)
         b = np.fromfile(tmp_path / f"cc_ch{k}.f32", dtype=np.float32)
         assert a.size == n // M and np.array_equal(a, b)
+
+
+def test_cpp_soapy_sdr_file_channel_shards_and_mix_through_the_c_collectives(tmp_path):
+    """host/soapy_sdr_file --world / --rank / --id-file (one process per GPU; here the two processes of a world of two run one after the
+    other on this box's GPU, which per-channel sinks allow: no exchange step): process R writes exactly the files _ch<R+1>, _ch<R+1+W>, ...
+    (SoapySDR.hs:209-212) with the contents of the unsharded run; `--mix` in a world of one goes through csdr_chain_process_mix
+    (RCCL all-reduce under the C ABI) and leaves the unsharded run's bytes."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "composable_sdr_amd", "host", "soapy_sdr_file")
+    subprocess.check_call(["make", "-C", os.path.dirname(exe), "-s"])
+    M, n, W = 64, 64 * 4096 * 2 + 64 * 37, 2
+    x = synth_cf32(n + 100, M, seed=61)
+    src = tmp_path / "in.cf32"
+    x.tofile(src)
+    base = [exe, "--filename", str(src), "-n", str(n), "-c", str(M), "--demod", "DeNBFM", "0.3"]
+    r = subprocess.run(base + ["-o", str(tmp_path / "one")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    for g in range(W):
+        r = subprocess.run(base + ["-o", str(tmp_path / "sh"), "--world", str(W), "--rank", str(g)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        mine = sorted(f for f in os.listdir(tmp_path) if f.startswith("sh_ch"))
+        assert len(mine) == (g + 1) * M // W                  # only the owned channels' files appear
+    for k in range(1, M + 1):
+        a = np.fromfile(tmp_path / f"one_ch{k}.f32", dtype=np.float32)
+        b = np.fromfile(tmp_path / f"sh_ch{k}.f32", dtype=np.float32)
+        assert a.size == b.size == n // M
+        d = np.abs(wrap_pm(a.astype(np.float64) - b, 1.0 / 0.3))
+        assert np.median(d) < 2e-5, k                         # pruned DFT of the shard vs the whole band: chain tolerance
+    # --mix: a world of one through the communicator (id file bootstrap) == no communicator at all
+    r = subprocess.run(base + ["-m", "-o", str(tmp_path / "mix0")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(base + ["-m", "-o", str(tmp_path / "mix1"), "--world", "1", "--rank", "0", "--id-file", str(tmp_path / "id.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert os.path.getsize(tmp_path / "id.bin") == 128
+    a, b = np.fromfile(tmp_path / "mix0.f32", dtype=np.float32), np.fromfile(tmp_path / "mix1.f32", dtype=np.float32)
+    assert a.size == n // M and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # a sharded --mix without its bootstrap is refused
+    r = subprocess.run(base + ["-m", "--world", "2", "--rank", "0"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "--id-file" in r.stderr
 
 
 def test_sdr_process_offset_front_end(tmp_path):

@@ -62,3 +62,26 @@ def test_kat4_example3_sizes():
     x = np.zeros(4 * M * 1024, dtype=np.complex64)
     y = O.Chan(M).process(x)
     assert y.shape == (M, 4096)
+
+
+def test_kat5_per_channel_files_grow_in_32768_byte_quanta():
+    """KAT5 (images/ex1_5.gif frames 40 / 105: the per-channel files of the Example 3 run grow in 32 768-byte steps): `compact (4 * nch * 1024)`
+    (SoapySDR.hs:215) hands the channelizer 4096 frames at a time, so every `distribute_` write (Trans.hs:106-117) is 4096 CF32 = 32 768
+    bytes per channel -- whatever the source's chunk size (1000 here, not a divisor)."""
+    from composable_sdr_amd.pipes import Pipe
+    from composable_sdr_amd.trans import addPipe, collect, compact, distribute_
+    kat = _kat()["kat5_file_quanta"]
+    M = kat["channels"]
+    assert 4 * M * 1024 == kat["compact_samples"] and kat["frames_per_chunk"] * 8 == kat["bytes_per_write"]
+    chan = O.Chan(M)
+    pfb = Pipe(lambda: None, lambda r, a: list(chan.process(a)) if a.size else [a], lambda r: None)   # firpfbchChannelizer on the oracle
+    sinks = [collect() for _ in range(M)]
+    fold = compact(4 * M * 1024, addPipe(pfb, distribute_(sinks)))
+    x = np.zeros(3 * kat["compact_samples"], dtype=np.complex64)
+    sizes = [[] for _ in range(M)]
+    for a in np.array_split(x, x.size // 1000):
+        fold.step(a)
+        for k, s_ in enumerate(sinks):
+            sizes[k].append(sum(i.nbytes for i in s_.items))
+    for k in range(M):
+        assert all(v % kat["bytes_per_write"] == 0 for v in sizes[k]) and sizes[k][-1] >= 2 * kat["bytes_per_write"]

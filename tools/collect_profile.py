@@ -2,7 +2,7 @@
 """Copies the judged artefacts of a tools/profile.sh run into profiles/ and updates
 profiles/traffic.json (per-launch HBM bytes of the dominant kernel from the PMC passes).
 
-    tools/collect_profile.py gpurun_out/prof_TAG rNN [M nf]
+    tools/collect_profile.py gpurun_out/prof_TAG rNN [M nf] [tm] [primary]
 
 FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 derived counters).  On gfx950 FETCH_SIZE reports
 half of the bytes of a wide (16 B/lane) coalesced stream (MI355X_MICROARCH.md, section HBM): the
@@ -20,7 +20,14 @@ from collections import defaultdict
 src, tag = sys.argv[1], sys.argv[2]
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 nf = int(sys.argv[4]) if len(sys.argv) > 4 else 262144
+# explicit markers instead of guessing from the tag: "tm" = the run's k_run256v2<CF32> launches wrote the tile-major plane
+# of the AGC route (their own traffic.json key); "primary" = this run is the kernel's own configuration and may overwrite its key
+FLAGS = set(sys.argv[5:])
+TILE_MAJOR, PRIMARY = "tm" in FLAGS, "primary" in FLAGS
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import kernel_sources_sha16
+SRC_SHA = kernel_sources_sha16()
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -70,8 +77,12 @@ for k, c in vals.items():
         if rd + wr < (1 << 20):
             continue                                    # fix-up / init kernels
         # the AGC configuration's channelizer launch writes its CF32 plane TILE-MAJOR (round 4): its own key
-        key = f"{short_name(k)}|M={M}|nf={nf}" + ("|tm" if ("agc" in tag and short_name(k) == "k_run256v2<CF32>") else "")
+        key = f"{short_name(k)}|M={M}|nf={nf}" + ("|tm" if (TILE_MAJOR and short_name(k) == "k_run256v2<CF32>") else "")
+        old = tj.get(key)
+        if old and old.get("src_sha16") == SRC_SHA and old.get("source") != f"profiles/{tag}_rocprofv3_summary.txt" and not PRIMARY:
+            continue                                    # a kernel's own configuration (PRIMARY=1) wins; other tags do not overwrite it
         tj[key] = {
+            "src_sha16": SRC_SHA,
             "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
             "fetch_size_kib_raw": c["FETCH_SIZE"], "write_size_kib_raw": c["WRITE_SIZE"],
             "note": "median over the launches of one run; FETCH_SIZE x2 (gfx950 wide-load under-count), WRITE_SIZE as reported", "source": f"profiles/{tag}_rocprofv3_summary.txt"}
