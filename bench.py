@@ -207,6 +207,12 @@ def main():
     dev = torch.device("cuda", local)
     if use_dist:
         dist.init_process_group(backend="gloo" if one_gpu else "nccl", rank=rank, world_size=world)
+        if not one_gpu:
+            # the first collective creates torch's own RCCL communicator, whose version banner goes to stdout: keep stdout for the JSON line
+            from composable_sdr_amd.sharded import _stdout_to_stderr
+            with _stdout_to_stderr():
+                dist.barrier()
+                torch.cuda.synchronize()
 
     import composable_sdr_amd as cs
     from composable_sdr_amd import _lib

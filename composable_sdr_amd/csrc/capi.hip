@@ -627,8 +627,7 @@ struct RouteRow {
 };
 const RouteRow ROUTES[] = {
     {256, ST1 | ST2 | ST4 | ST8, PLAN_FUSED256, "fused-256",
-     "k_run256v2<FM | CF32[, G]> (whole band: calls of >= 1024 whole tiles of 16 frames; interleaved shards G = 2, 4, 8: every whole tile); "
-     "k_run256v3 with CSDR_RUN_V3=1 (experiment, not faster)",
+     "k_run256v2<FM | CF32[, G]> (whole band: calls of >= 1024 whole tiles of 16 frames; interleaved shards G = 2, 4, 8: every whole tile)",
      "k_tile256<FM | CF32> (look-back tile kernel: chunk-sized calls, ragged ends, and contiguous channel shards at every size) [+ k_shard_gather]",
      "channelizer -> CF32 plane (tile-major for run-sized calls of whole tiles) -> k_agc_spec_tm | k_agc_spec -> k_agc_fix [-> k_mix]"},
     {64, ST1, PLAN_SMALL64, "fused-k_run64",
@@ -648,11 +647,11 @@ const RouteRow *route_select(uint32_t M, uint32_t p, uint32_t G, uint32_t flags)
 {
     const RouteRow *generic = &ROUTES[sizeof(ROUTES) / sizeof(ROUTES[0]) - 1];
     if (M <= 1 || (flags & CSDR_FLAG_FORCE_GENERIC)) return generic;
-    if (G > 1 && getenv("CSDR_SHARD_GENERIC")) return generic;
+    if (G > 1 && diag_env("CSDR_SHARD_GENERIC")) return generic;
     for (const RouteRow &r : ROUTES) {
         if (r.M != M || !(G < 32 && (r.strides >> G) & 1u)) continue;
         const bool ok = r.plan == PLAN_FUSED256 ? fused_supported(M, p) : r.plan == PLAN_SMALL64 ? small_supported(M, p)
-                      : r.plan == PLAN_BIG1024 ? (big_supported(M, p) && !getenv("CSDR_NO_RUN1024")) : true;
+                      : r.plan == PLAN_BIG1024 ? (big_supported(M, p) && !diag_env("CSDR_NO_RUN1024")) : true;
         if (ok) return &r;
     }
     return generic;
@@ -878,7 +877,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         }
     } else {
         h->path = "generic";
-        const bool use1024 = G == 1 && pfb1024_supported(M, h->p) && !(cfg->mix && cfg->agc_threshold_db == 0.0f) && !getenv("CSDR_NO_PFB1024");
+        const bool use1024 = G == 1 && pfb1024_supported(M, h->p) && !(cfg->mix && cfg->agc_threshold_db == 0.0f) && !diag_env("CSDR_NO_PFB1024");
         h->timed_kernel = M > 1 ? (use1024 ? "k_pfb1024" : "k_pfb_fir") : "k_dc_apply";
         if (use1024) h->path = "generic+pfb1024";
         if (M > 1) {
@@ -890,7 +889,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
                           h->dctile && !(cfg->flags & CSDR_FLAG_NO_MIX_IDENTITY) && !am;
         if (h->mix_identity) {
             if ((r = dev_alloc(&h->d_u0, (size_t)(h->p - 1) + h->max_nf)) || (r = dev_alloc(&h->d_u0hist, 2 * (h->p - 1)))) return fail(r);
-            h->path = "generic+mix-identity"; h->timed_kernel = (M % 4096u == 0) ? (getenv("CSDR_PICK_LOOKBACK") ? "k_dc_pick_tile" : "k_dc_fold") : "k_dc_tile";   // refined per call
+            h->path = "generic+mix-identity"; h->timed_kernel = (M % 4096u == 0) ? "k_dc_fold" : "k_dc_tile";   // refined per call
         }
         if (G > 1) {
             const uint32_t Mg = M / G;
@@ -994,7 +993,7 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
                 if ((r = dctile_mix_identity(h->dctile, d_in, nx, nco, h->d_nco_tab, h->d_taps, M, h->p, hin, hout, (float2 *)d_out, s))) return r;
                 if ((r = h->timer.end(s))) return r;
             } else {
-                h->timed_kernel = (M % 4096u == 0) ? "k_dc_pick_tile" : "k_dc_tile";
+                h->timed_kernel = "k_dc_tile";
                 CSDR_HIP(hipMemcpyAsync(h->d_u0, hin, sizeof(float2) * (h->p - 1), hipMemcpyDeviceToDevice, s));
                 if ((r = h->timer.begin(s))) return r;
                 if ((r = dctile_process(h->dctile, d_in, h->d_u0 + (h->p - 1), nx, true, nco, h->d_nco_tab, s, M))) return r;
@@ -1012,7 +1011,7 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
         if (r) return r;
         // M = 1024: FIR + DFT + transpose [+ freqdem] in one kernel (no X / Y round trips through HBM); the frame-major
         // mix tails without AGC still want Y in HBM and keep the three-kernel route
-        const bool fused1024 = h->G == 1 && pfb1024_supported(M, h->p) && !(mixo && !agc) && !getenv("CSDR_NO_PFB1024");
+        const bool fused1024 = h->G == 1 && pfb1024_supported(M, h->p) && !(mixo && !agc) && !diag_env("CSDR_NO_PFB1024");
         if ((r = h->timer.begin(s))) return r;
         if (fused1024) {
             const bool fm_here = fm && !agc;                     // with the AGC on the tail does the freqdem

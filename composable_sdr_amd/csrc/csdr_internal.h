@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,18 @@ int  hip_fail(hipError_t e, const char *what, const char *file, int line);
             return rc__;                                                        \
         }                                                                       \
     } while (0)
+
+// ---- diagnostics knobs ------------------------------------------------------
+// The CSDR_* variables that change a launch plan (CSDR_RUN_MIN_TILES, CSDR_RUN_WEIGHTS, CSDR_AGC_L / _W, CSDR_WU, CSDR_RUN1024_V3, ...:
+// DESIGN.md section 6.1; several of them change RESULTS) exist for A/B measurements and for the tests that force a kernel onto a small
+// input.  They are read only when CSDR_DIAG=1 is set next to them: a production host does not inherit a knob from its environment by
+// accident.  (Read when a handle is created or a plan is made, never inside a launch loop.)  Not gated: CSDR_QUIET (a print),
+// CSDR_RCCL_LIB (where librccl lives), CSDR_LIB (which build of this library the Python binding loads).
+inline const char *diag_env(const char *name)
+{
+    const char *d = getenv("CSDR_DIAG");
+    return (d && d[0] == '1' && d[1] == 0) ? getenv(name) : nullptr;
+}
 
 // ---- host-side design (design.cpp) -----------------------------------------
 // Kaiser prototype of firpfbch_crcf_create_kaiser(ANALYZER, M, m, As)

@@ -49,7 +49,8 @@ void fused_destroy(FusedPlan *plan);
 // run_args points at a RunArgs (fused_common.h) the plan fills.
 int  run256_v2_launch(const void *run_args, bool fm, unsigned G, unsigned nruns, hipStream_t s);
 int  run256_v2_blocks_per_cu(bool fm);
-// third-generation run kernel (kernels_run256_v3.hip): one 512-thread workgroup per CU, front / back wave roles; whole band
+// round 4's experiment (tools/variants/kernels_run256_v3.hip, NOT part of the product library: measured not faster):
+// one 512-thread workgroup per CU, front / back wave roles; linked only by tools/variants/build_run256_v3.sh (-DCSDR_WITH_RUN256_V3)
 int  run256_v3_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s);
 
 

@@ -338,10 +338,11 @@ __device__ __forceinline__ float2 scan_staged(float2 *R, float2 *E, float2 *T, c
 }
 
 // scan_staged on an image whose frames are FS float2 apart (256 = dense; k_run256v2 pads its frames, kernels_fused_v2.hip)
-template <int FS>
+// RSW: the image's run swizzle is q & 7 instead of (q >> 1) & 7 (kernels_fused_v2.hip V2_RSW)
+template <int FS, bool RSW = false>
 __device__ __forceinline__ float2 scan_staged_fs(float2 *R, float2 *E, float2 *T, const TileArgs &A, int tid)
 {
-    const int q = tid, sw = (q >> 1) & 7;
+    const int q = tid, sw = RSW ? (q & 7) : ((q >> 1) & 7);
     float4 *R4 = reinterpret_cast<float4 *>(R + FS * (q >> 4)) + 8 * (q & 15);
     float2 s = make_float2(0.f, 0.f);
     const float na = -A.alpha, be = A.beta;

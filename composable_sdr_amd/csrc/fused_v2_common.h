@@ -37,6 +37,13 @@ __device__ __forceinline__ unsigned dma_offset(int tid)
 }
 // IT_STEP: LDS bytes between the destinations of consecutive instructions of a wave (4096 = the dense image; k_run256v2 pads
 // its frames and passes 2 x its frame stride: instruction `it` of wave w lands in frame 2 it + (w >> 1))
+// the same for an image whose run q keeps piece i in slot i ^ (q & 7) (k_run256v2's padded image: kernels_fused_v2.hip V2_RSW)
+__device__ __forceinline__ unsigned dma_offset_rsw(int tid)
+{
+    const int wave = tid >> 6, lane = tid & 63;
+    const int slot = 64 * wave + lane, q = slot >> 3, i = (slot & 7) ^ (q & 7);
+    return (unsigned)(8 * q + i) * 16u;
+}
 template <bool STREAM = false, unsigned IT_STEP = 4096u>
 __device__ __forceinline__ void dma_tile(const float4 *__restrict__ tile_base, unsigned goff, unsigned lds_wave)
 {

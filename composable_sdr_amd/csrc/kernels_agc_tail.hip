@@ -823,18 +823,18 @@ int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
     AgcTailPlan *p = new AgcTailPlan();
     p->C = C; p->max_nf = max_nf;
     if (TM_ABLATE) fprintf(stderr, "csdr: kernels_agc_tail.hip built with TM_ABLATE=%d: timing only, results are wrong\n", TM_ABLATE);
-    if (const char *e = getenv("CSDR_AGC_L")) { p->L = (uint32_t)atol(e); p->L = (p->L + 15u) / 16u * 16u; if (p->L < 16) p->L = 16; }
-    if (const char *e = getenv("CSDR_AGC_L_TM")) { p->L_tm = ((uint32_t)atol(e) + 15u) / 16u * 16u; if (p->L_tm < 16) p->L_tm = 16; if (p->L_tm > 8176u) p->L_tm = 8176u; }
-    if (const char *e = getenv("CSDR_AGC_W")) p->W = (uint32_t)atol(e);
+    if (const char *e = diag_env("CSDR_AGC_L")) { p->L = (uint32_t)atol(e); p->L = (p->L + 15u) / 16u * 16u; if (p->L < 16) p->L = 16; }
+    if (const char *e = diag_env("CSDR_AGC_L_TM")) { p->L_tm = ((uint32_t)atol(e) + 15u) / 16u * 16u; if (p->L_tm < 16) p->L_tm = 16; if (p->L_tm > 8176u) p->L_tm = 8176u; }
+    if (const char *e = diag_env("CSDR_AGC_W")) p->W = (uint32_t)atol(e);
     p->W = (p->W + 15u) / 16u * 16u;
     {
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (const char *e = getenv("CSDR_CUS")) { if (atoi(e) > 0 && atoi(e) < cus) cus = atoi(e); }      // experiments: a plan sized for a CU-masked stream
+        if (const char *e = diag_env("CSDR_CUS")) { if (atoi(e) > 0 && atoi(e) < cus) cus = atoi(e); }      // experiments: a plan sized for a CU-masked stream
         // k_agc_spec: two waves per workgroup at <= 256 VGPRs -> two waves per SIMD -> four workgroups per CU
         p->wg_slots = (uint32_t)cus * 4u;
-        if (const char *e = getenv("CSDR_AGC_WGS")) p->wg_slots = (uint32_t)cus * (uint32_t)(atol(e) > 0 ? atol(e) : 1);
+        if (const char *e = diag_env("CSDR_AGC_WGS")) p->wg_slots = (uint32_t)cus * (uint32_t)(atol(e) > 0 ? atol(e) : 1);
     }
     p->max_seg = (max_nf + 15u) / 16u + 1;                      // L >= 16
     const size_t n = (size_t)C * p->max_seg;
@@ -875,7 +875,7 @@ int agc_tail_stats(AgcTailPlan *p, unsigned *checked, unsigned *redone)
 // the tile-major route (k_agc_spec_tm): whole 16-frame blocks, at least two segments, channel count a multiple or a divisor of 64
 bool agc_tail_tm_supported(const AgcTailPlan *p, uint32_t nf)
 {
-    static const bool off = getenv("CSDR_AGC_TM") && atoi(getenv("CSDR_AGC_TM")) == 0;      // A/B: the row-major route for every call
+    static const bool off = diag_env("CSDR_AGC_TM") && atoi(diag_env("CSDR_AGC_TM")) == 0;      // A/B: the row-major route for every call
     if (off || !p || !nf || nf % 16u || p->W > 8192u || p->W % 16u) return false;
     if (!(p->C % 64u == 0 || (p->C < 64u && 64u % p->C == 0))) return false;
     if (nf < 4u * p->W) return false;                            // short calls: a handful of segments, the row-major kernel's ground

@@ -196,114 +196,8 @@ __global__ __launch_bounds__(256) void k_dc_tile(DcTileArgs D)
     }
 }
 
-// Lean variant for pick = a multiple of 4096 (the 4096-channel --mix shape): only the DC-blocker state in front of every tile
-// is needed, so a tile is folded straight out of the coalesced loads (decayed sum with per-lane weights: no LDS staging, no
-// per-sample scan, no store), the aggregates go through the same decoupled look-back, and one lane emits the tile's
-// first sample y0 = x0 - alpha v, pre-mixed.  8 B read per sample, nothing else.
-constexpr int PICK_T = 8;        // tiles per workgroup (one global ticket per 8 tiles: a single ticket word hands out ~90 per microsecond)
-__global__ __launch_bounds__(256) void k_dc_pick_tile(DcTileArgs D, float l2beta)
-{
-    __shared__ float2 red[4];
-    __shared__ float2 carry_s;
-    __shared__ unsigned tile_s;
-    const int tid = threadIdx.x;
-    if (tid == 0) tile_s = atomicAdd(D.ticket, 1u);
-    __syncthreads();
-    const unsigned b0 = tile_s * PICK_T;
-    if (b0 >= D.nb) return;
-    const unsigned b1 = min(D.nb, b0 + PICK_T);
-    float w0[8], w1[8];
-    {
-        const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int slot = 64 * (it * 4 + wave) + lane, q = slot >> 3;
-            const int i = (slot & 7) ^ ((q >> 1) & 7);
-            const int n = 16 * q + 2 * i;
-            w0[it] = exp2f((float)(4095 - n) * l2beta); w1[it] = exp2f((float)(4094 - n) * l2beta);
-        }
-    }
-    // pass 1: the zero-state aggregates of my tiles depend on nothing: fold and publish all of them first (a workgroup that
-    // waited for its predecessors before publishing would chain the whole launch)
-    float4 raw[8], nxt[8];
-    tile_load(reinterpret_cast<const float4 *>(D.x) + (size_t)b0 * 2048, 256, raw, tid);
-    float2 aggs[PICK_T];
-#pragma unroll
-    for (int u = 0; u < PICK_T; u++) {
-        const unsigned b = b0 + u;
-        aggs[u] = make_float2(0.f, 0.f);
-        if (b < b1) {
-            if (b + 1 < b1) tile_load(reinterpret_cast<const float4 *>(D.x) + (size_t)(b + 1) * 2048, 256, nxt, tid);
-            float2 p = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int it = 0; it < 8; it++) {
-                p = cfma(make_float2(raw[it].x, raw[it].y), w0[it], p);
-                p = cfma(make_float2(raw[it].z, raw[it].w), w1[it], p);
-            }
-            const float2 agg = wg_sum(p, red, tid);                 // v after the tile from a zero state
-            aggs[u] = agg;
-            if (tid == 0) {
-                __hip_atomic_store(&D.agg[2 * (size_t)b], ((u64)D.epoch << 32) | __float_as_uint(agg.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&D.agg[2 * (size_t)b + 1], ((u64)D.epoch << 32) | __float_as_uint(agg.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-#pragma unroll
-            for (int it = 0; it < 8; it++) raw[it] = nxt[it];
-        }
-    }
-    // pass 2: state in front of my first tile from the ten tiles before it, then one picked sample per tile
-    if (tid < 64) {
-        const unsigned b = b0;
-        const int k = tid;
-        float2 cb = make_float2(0.f, 0.f);
-        const bool need = (k >= 1 && k <= LOOKBACK && (int)b - k >= 0);
-        u64 g0 = 0, g1 = 0;
-        unsigned spins = 0;
-        bool ok = !need;
-        while (true) {
-            if (need && !ok) {
-                g0 = __hip_atomic_load(&D.agg[2 * (size_t)(b - k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                g1 = __hip_atomic_load(&D.agg[2 * (size_t)(b - k) + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = (unsigned)(g0 >> 32) == D.epoch && (unsigned)(g1 >> 32) == D.epoch;
-            }
-            if (__all(ok)) break;
-            if (++spins > SPIN_LIMIT) { if (k == 0) atomicOr(D.status, 4u); break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (need) cb = make_float2(__uint_as_float((unsigned)g0) * D.wtile[k - 1], __uint_as_float((unsigned)g1) * D.wtile[k - 1]);
-        if (k == 0 && b <= LOOKBACK) { const float2 v = D.vend_in[0]; cb = make_float2(v.x * D.wtile[b], v.y * D.wtile[b]); }
-        cb = cadd(cb, dpp2<0x111>(cb)); cb = cadd(cb, dpp2<0x112>(cb));
-        cb = cadd(cb, dpp2<0x114>(cb)); cb = cadd(cb, dpp2<0x118>(cb));
-        if (k == 15) carry_s = cb;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float2 c = carry_s;                                            // v before tile b0
-#pragma unroll
-        for (int u = 0; u < PICK_T; u++) {
-            const unsigned b = b0 + u;
-            if (b >= b1) break;
-            const uint32_t n0 = b * 4096u;
-            if (n0 % D.pick == 0) {
-                const float2 x0 = D.x[n0];
-                float2 y = make_float2(fmaf(-D.alpha, c.x, x0.x), fmaf(-D.alpha, c.y, x0.y));
-                if (D.do_mix) {
-                    float c_, s_;
-                    if (D.nco.tab_len) { const float2 cs = D.nco_tab[(D.nco.tab_pos + n0) % D.nco.tab_len]; c_ = cs.x; s_ = cs.y; }
-                    else {
-                        const uint32_t theta = D.nco.theta0 + n0 * D.nco.d_theta;
-                        sincosf((float)(6.283185307179586 * (double)(float)theta / 4294967296.0), &s_, &c_);
-                    }
-                    if (!D.nco.up) s_ = -s_;
-                    y = make_float2(y.x * c_ - y.y * s_, y.x * s_ + y.y * c_);
-                }
-                D.ypick[n0 / D.pick] = y;
-            }
-            c = cfma(c, D.wtile[1], aggs[u]);                       // v before the next tile
-            if (b == D.nb - 1) D.vend_out[0] = c;
-        }
-    }
-}
-
+// (Round 2 had a first version of this job with decoupled look-back, k_dc_pick_tile: 117 us against 98-107; deleted in round 5 --
+// no route reached it without a diagnostics knob.  `git show f9835f7:composable_sdr_amd/csrc/kernels_dc_tile.hip` has it.)
 // The same job without any inter-workgroup hand-off (round 2): the DC state in front of a frame is a decayed sum over
 // everything before it, so k_dc_fold leaves one zero-state aggregate (and the first sample) per 4096-sample tile -- one
 // wave per tile, four 8 KiB quarters with the next one in flight, no LDS, no barrier, no ticket: a plain streaming read --
@@ -512,8 +406,7 @@ int dctile_reset(DcTilePlan *p, hipStream_t s)
 // pre-mixed stream); hist_in / hist_out: the p - 1 picked samples before / after the call (different buffers)
 bool dctile_mix_identity_supported(const DcTilePlan *p, uint32_t M, uint32_t n, uint32_t taps_p)
 {
-    static const bool lookback_pick = getenv("CSDR_PICK_LOOKBACK") != nullptr;   // round-2 first version (k_dc_pick_tile + k_branch0_fir) for A/B
-    return !lookback_pick && M && M % 4096u == 0 && n && n % M == 0 && p->proto.beta > 0.f && taps_p >= 1 && taps_p <= 33;
+    return M && M % 4096u == 0 && n && n % M == 0 && p->proto.beta > 0.f && taps_p >= 1 && taps_p <= 33;
 }
 
 int dctile_mix_identity(DcTilePlan *p, const float2 *x, uint32_t n, const NcoParams &nco, const float2 *nco_tab, const float *taps,
@@ -548,10 +441,7 @@ int dctile_process(DcTilePlan *p, const float2 *x, float2 *y, uint32_t n, bool d
     if (++p->epoch == 0) p->epoch = 1;
     D.epoch = p->epoch; D.nco = nco; D.nco_tab = nco_tab; D.do_mix = do_mix ? 1 : 0;
     CSDR_HIP(hipMemsetAsync(p->d_ticket, 0, sizeof(unsigned), s));
-    if (pick && pick % 4096u == 0 && n % 4096u == 0 && D.beta > 0.f)
-        hipLaunchKernelGGL(k_dc_pick_tile, dim3((D.nb + PICK_T - 1) / PICK_T), dim3(256), 0, s, D, (float)std::log2((double)D.beta));
-    else
-        hipLaunchKernelGGL(k_dc_tile, dim3(D.nb), dim3(256), 0, s, D);
+    hipLaunchKernelGGL(k_dc_tile, dim3(D.nb), dim3(256), 0, s, D);
     CSDR_HIP(hipGetLastError());
     p->cur ^= 1;
     return 0;

@@ -379,7 +379,7 @@ struct FusedPlan {
     uint32_t cus = 256;
     float slot_weight[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};   // tile share of the k-th co-resident run of a CU
     uint32_t resident_wgs_v2 = 512;  // workgroups of k_run256v2 the device holds at once
-    bool use_v3 = false;             // CSDR_RUN_V3=1: k_run256v3 (one 512-thread workgroup per CU, front / back wave roles) for whole-band calls
+    bool use_v3 = false;             // variant builds only (CSDR_WITH_RUN256_V3 + CSDR_RUN_V3=1): k_run256v3, round 4's one-workgroup-per-CU experiment (tools/variants/)
     // independent launches (csdr_chain_submit_device): the last WU + 1 raw tiles of the previous chunk, three slots (the launch
     // two calls back may still be reading its slot when this call's copy is queued on the other stream)
     float *d_shard_tail = nullptr;   // interleaved shard: whole-band result of a call's ragged end, [256][< 16] CF32 at most
@@ -415,9 +415,9 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     ALLOC(p->d_yflag, sizeof(unsigned) * p->max_nb);
     ALLOC(p->d_agg, sizeof(u64) * 2 * p->max_nb);
     ALLOC(p->d_ylast, sizeof(u64) * (size_t)cfg.M * p->max_nb);
-    if (const char *e = getenv("CSDR_RUN_MIN_TILES")) p->run_min_tiles = (uint32_t)atol(e);
+    if (const char *e = diag_env("CSDR_RUN_MIN_TILES")) p->run_min_tiles = (uint32_t)atol(e);
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
-    if (getenv("CSDR_TRACE")) { ALLOC(p->d_trace, sizeof(u64) * 16 * p->max_nb); CSDR_HIP(hipMemset(p->d_trace, 0, sizeof(u64) * 16 * p->max_nb)); }
+    if (diag_env("CSDR_TRACE")) { ALLOC(p->d_trace, sizeof(u64) * 16 * p->max_nb); CSDR_HIP(hipMemset(p->d_trace, 0, sizeof(u64) * 16 * p->max_nb)); }
 #undef ALLOC
     CSDR_HIP(hipMemcpy(p->d_taps, cfg.taps, sizeof(float) * cfg.M * cfg.p, hipMemcpyHostToDevice));
     std::vector<float2> tw(cfg.M), wpre(2 * cfg.M);
@@ -455,12 +455,14 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
         int dev = 0, cus = 256;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (const char *e = getenv("CSDR_CUS")) { if (atoi(e) > 0 && atoi(e) < cus) cus = atoi(e); }      // experiments: a plan sized for a CU-masked stream
+        if (const char *e = diag_env("CSDR_CUS")) { if (atoi(e) > 0 && atoi(e) < cus) cus = atoi(e); }      // experiments: a plan sized for a CU-masked stream
         p->cus = (uint32_t)cus;
         p->resident_wgs_v2 = (uint32_t)(cus * run256_v2_blocks_per_cu(cfg.fm));
-        if (const char *e = getenv("CSDR_RESIDENT_WGS")) p->resident_wgs_v2 = (uint32_t)atol(e);
-        if (const char *e = getenv("CSDR_RUN_V3")) p->use_v3 = atoi(e) != 0;
-        if (const char *e = getenv("CSDR_RUN_WEIGHTS")) {
+        if (const char *e = diag_env("CSDR_RESIDENT_WGS")) p->resident_wgs_v2 = (uint32_t)atol(e);
+#ifdef CSDR_WITH_RUN256_V3          // variant build only (tools/variants/build_run256_v3.sh): round 4's one-workgroup-per-CU experiment
+        if (const char *e = diag_env("CSDR_RUN_V3")) p->use_v3 = atoi(e) != 0;
+#endif
+        if (const char *e = diag_env("CSDR_RUN_WEIGHTS")) {
             int k = 0;
             for (const char *q = e; *q && k < 8; k++) { p->slot_weight[k] = (float)atof(q); q = strchr(q, ','); if (!q) break; q++; }
         }
@@ -543,7 +545,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         // one run per resident workgroup slot (a single round), runs balanced to within one tile,
         // at least 8 tiles per run so that the warm-up reads stay below 7/8 of a run
         uint32_t nruns = v3 ? p->cus : p->resident_wgs_v2;
-        if (v3) { if (const char *e = getenv("CSDR_V3_RUNS")) nruns = (uint32_t)atol(e); }
+        if (v3) { if (const char *e = diag_env("CSDR_V3_RUNS")) nruns = (uint32_t)atol(e); }
         if (nruns > A.nb / 8) nruns = A.nb / 8;
         if (nruns < 1) nruns = 1;
         RA.nruns = nruns;
@@ -554,14 +556,14 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         static const float v2_weight_fm[8] = {1.24f, 0.76f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};      // with whole-line stores the younger workgroup loses more (r03 trace: 4.8 vs 7.6 us per tile)
         const float *v2_weight = c.fm ? v2_weight_fm : v2_weight_cf;
         static const float equal_weight[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-        static const bool pd_equal = getenv("CSDR_PD_EQUAL") != nullptr;
-        RA.split = make_split(A.nb, nruns, p->cus, (call.indep && pd_equal) ? equal_weight : ((v2 && !getenv("CSDR_RUN_WEIGHTS")) ? v2_weight : p->slot_weight));
-        { const char *e = getenv("CSDR_PRIO_ROT"); RA.prio_div = e ? (atoi(e) ? p->cus : 0u) : (v2 ? 0u : p->cus); }
-        { const char *e = getenv("CSDR_TRACE"); RA.trace_light = (e && atoi(e) == 2) ? 1u : 0u; }
-        { const char *e = getenv("CSDR_WU"); RA.wu = e ? (uint32_t)atoi(e) : (uint32_t)WU; }       // experiments: fewer tiles = wrong DC state at run starts
-        { const char *e = getenv("CSDR_WU_ROT"); RA.wu_rot = e ? (uint32_t)atoi(e) : 0u; }      // measured: no effect on the run-start burst
-        RA.pair_align = (v2 && (c.fm || getenv("CSDR_PAIR_ALIGN_CF"))) ? 1u : 0u;
-        { const char *e = getenv("CSDR_WU_BATCH6"); RA.wu_batch6 = e ? (uint32_t)atoi(e) : 1u; }
+        static const bool pd_equal = diag_env("CSDR_PD_EQUAL") != nullptr;
+        RA.split = make_split(A.nb, nruns, p->cus, (call.indep && pd_equal) ? equal_weight : ((v2 && !diag_env("CSDR_RUN_WEIGHTS")) ? v2_weight : p->slot_weight));
+        { const char *e = diag_env("CSDR_PRIO_ROT"); RA.prio_div = e ? (atoi(e) ? p->cus : 0u) : (v2 ? 0u : p->cus); }
+        { const char *e = diag_env("CSDR_TRACE"); RA.trace_light = (e && atoi(e) == 2) ? 1u : 0u; }
+        { const char *e = diag_env("CSDR_WU"); RA.wu = e ? (uint32_t)atoi(e) : (uint32_t)WU; }       // experiments: fewer tiles = wrong DC state at run starts
+        { const char *e = diag_env("CSDR_WU_ROT"); RA.wu_rot = e ? (uint32_t)atoi(e) : 0u; }      // measured: no effect on the run-start burst
+        RA.pair_align = (v2 && (c.fm || diag_env("CSDR_PAIR_ALIGN_CF"))) ? 1u : 0u;
+        { const char *e = diag_env("CSDR_WU_BATCH6"); RA.wu_batch6 = e ? (uint32_t)atoi(e) : 1u; }
         RA.l2beta = c.dc_block ? (float)std::log2((double)c.dc.beta) : -1000.0f;
         RA.tile_step = call.tile_major ? c.C * 128u : (uint32_t)NB * (c.fm ? 4u : 8u);
         const bool whole = nf == nb_full * NB;
@@ -571,7 +573,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         if (p->keep_tail && !shard && v2 && whole && nb_full >= WU + 1) {
             // this chunk's last WU + 1 tiles, for run 0 of the next call (queued in front of the launch: the copy only reads the input)
             const int nxt = (p->tail_w + 1) % 3;
-            static const bool nocopy = getenv("CSDR_PD_NOCOPY") != nullptr;      // scheduling experiments only (wrong run-0 starts)
+            static const bool nocopy = diag_env("CSDR_PD_NOCOPY") != nullptr;      // scheduling experiments only (wrong run-0 starts)
             if (!nocopy) hipLaunchKernelGGL(k_save_tail, dim3(2048 * (WU + 1) / 256), dim3(256), 0, s,
                                             reinterpret_cast<const float4 *>(call.d_in + (size_t)(nb_full - (WU + 1)) * 4096), p->d_tail[nxt]);
             if (call.ev_tail) CSDR_HIP(hipEventRecord(call.ev_tail, s));
@@ -579,7 +581,9 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         } else p->tail_valid = false;
         if (timer && (r = timer->begin(s))) return r;
         if (nb_full == 0) { /* shard, fewer than 16 frames: the tile kernel below does the whole call */ }
+#ifdef CSDR_WITH_RUN256_V3
         else if (v3) { if ((r = run256_v3_launch(&RA, c.fm, nruns, s))) return r; }
+#endif
         else if ((r = run256_v2_launch(&RA, c.fm, c.G, nruns, s))) return r;
         if (timer && (r = timer->end(s))) return r;
         const uint32_t rem = nf - nb_full * NB;

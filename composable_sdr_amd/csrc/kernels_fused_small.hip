@@ -412,7 +412,7 @@ int small_create(const FusedConfig &cfg, SmallPlan **out)
         if (occ < 1) occ = 1;
         p->resident_wgs = (uint32_t)(cus * occ);
         p->cus = (uint32_t)cus;
-        p->v2_ok = !cfg.fm && cfg.c0 == 0 && cfg.C == (uint32_t)MS && !getenv("CSDR_RUN64_V1");
+        p->v2_ok = !cfg.fm && cfg.c0 == 0 && cfg.C == (uint32_t)MS && !diag_env("CSDR_RUN64_V1");
     }
     *out = p;
     return 0;

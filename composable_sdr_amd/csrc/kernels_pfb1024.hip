@@ -550,8 +550,8 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         // whole-band call of whole 4-frame tiles (a call that ends inside a 128-byte line stores the front part of it)
         p->v2_ok = false;
         // whole band, calls of whole 4-frame tiles: k_run1024v3 (CSDR_RUN1024_V3=0: k_run1024 for the comparison)
-        p->v3_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && cfg.G == 1 && !getenv("CSDR_RUN1024_V1") && !(getenv("CSDR_RUN1024_V3") && atoi(getenv("CSDR_RUN1024_V3")) == 0);
-        if (cfg.G > 1) p->v2_ok = cfg.fm && !getenv("CSDR_RUN1024_V1");       // k_run1024v2<FM, G>; CF32 shards: whole band + row gather (below)
+        p->v3_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && cfg.G == 1 && !diag_env("CSDR_RUN1024_V1") && !(diag_env("CSDR_RUN1024_V3") && atoi(diag_env("CSDR_RUN1024_V3")) == 0);
+        if (cfg.G > 1) p->v2_ok = cfg.fm && !diag_env("CSDR_RUN1024_V1");       // k_run1024v2<FM, G>; CF32 shards: whole band + row gather (below)
         // until the first call: the kernel a call of max_nf frames would take (csdr_chain_path names it)
         p->v2_last = p->v2_ok && (cfg.max_nf & 3u) == 0 && run1024_v2_runs(cfg.max_nf, p->cus) != 0;
         p->v3_last = p->v3_ok && run1024_v3_runs(cfg.max_nf, cfg.fm, p->cus) != 0;

@@ -528,7 +528,7 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
     A.rp_in = h.rp_in; A.rp_out = h.rp_out; A.stage = h.stage;
     A.nf = h.nf; A.nb = h.nf / B2_T4; A.nruns = h.nruns; A.parity0 = h.parity0; A.out_stride = h.nf;
     {
-        static const double wt = getenv("CSDR_RUN1024_WEIGHT") ? atof(getenv("CSDR_RUN1024_WEIGHT")) : 1.2;   // share of the older workgroup of a CU (1 = even)
+        static const double wt = diag_env("CSDR_RUN1024_WEIGHT") ? atof(diag_env("CSDR_RUN1024_WEIGHT")) : 1.2;   // share of the older workgroup of a CU (1 = even)
         A.n0 = (h.nruns >= 2 && !(h.nruns & 1u) && wt > 1.0 && wt < 1.5) ? (uint32_t)std::llround(0.5 * wt * (double)A.nb) : 0u;
     }
     const double beta = h.dc_block ? h.beta : 0.0;
@@ -558,7 +558,7 @@ uint32_t run1024_v2_runs(uint32_t nf, uint32_t cus)
     // up to 1/4 less than the average: at least 24 tiles per run on average (>= 16 for every one)
     const uint32_t nb = nf / B2_T4;
     uint32_t nruns = 2 * cus;
-    if (const char *e = getenv("CSDR_RUN1024_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
+    if (const char *e = diag_env("CSDR_RUN1024_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
     if (nruns > nb / 24) nruns = nb / 24;
     if (nruns > 2) nruns &= ~1u;
     return nruns;                                       // 0: too short for this kernel

@@ -525,7 +525,7 @@ int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream
     A.fm_ref = h.fm_ref; A.tiny = 1e-37f;
     A.pk = phase_consts(1.0f);                          // unscaled polynomial (fm_quad scales a = min / max by ref)
     A.pk.hp *= h.fm_ref; A.pk.pi *= h.fm_ref; A.pk.ref = h.fm_ref;
-    static const char *trace_file = getenv("CSDR_RUN1024_V3_TRACE");
+    static const char *trace_file = diag_env("CSDR_RUN1024_V3_TRACE");
     static unsigned long long *d_trace = nullptr;
     if (trace_file && !d_trace) CSDR_HIP(hipMalloc(&d_trace, 1536 * sizeof(unsigned long long)));
     if (trace_file) { CSDR_HIP(hipMemsetAsync(d_trace, 0, 1536 * sizeof(unsigned long long), s)); A.trace = d_trace; }
@@ -553,7 +553,7 @@ uint32_t run1024_v3_runs(uint32_t nf, bool fm, uint32_t cus)
     if (nf % B3_T4) return 0;
     const uint32_t nblk = (nf / B3_T4 + B3_TB - 1) / B3_TB;
     uint32_t nruns = cus;
-    if (const char *e = getenv("CSDR_RUN1024_V3_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
+    if (const char *e = diag_env("CSDR_RUN1024_V3_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < nruns) nruns = v; }   // experiments
     if (nruns > nblk) nruns = nblk;
     return nruns;                                       // 0: a ragged call (not whole 4-frame tiles)
 }

@@ -310,7 +310,7 @@ uint32_t run64_v2_runs(uint32_t nf, uint32_t cus)
     // 4096 frames 17 us against 60 us, 131 072 frames 58 against 66, 262 144 frames 99 against 76)
     if (nf % 64u) return 0;
     const uint32_t nb = nf / 64u;
-    if (nb < 3072u && !getenv("CSDR_RUN64_V2_ALL")) return 0;
+    if (nb < 3072u && !diag_env("CSDR_RUN64_V2_ALL")) return 0;
     uint32_t nruns = 2 * cus;
     if (nruns > nb / 16) nruns = nb / 16;
     if (nruns > 2) nruns &= ~1u;
@@ -324,7 +324,7 @@ int run64_v2_launch(const Run64v2Host &h, hipStream_t s, KernelTimer *timer)
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
     A.nf = h.nf; A.nb = h.nf / 64u; A.nruns = h.nruns; A.parity0 = h.parity0; A.out_stride = h.nf;
     {
-        static const double wt = getenv("CSDR_RUN64_WEIGHT") ? atof(getenv("CSDR_RUN64_WEIGHT")) : 1.1;   // share of the older workgroup of a CU (1 = even; 1.1 measured best: 243 vs 250 us)
+        static const double wt = diag_env("CSDR_RUN64_WEIGHT") ? atof(diag_env("CSDR_RUN64_WEIGHT")) : 1.1;   // share of the older workgroup of a CU (1 = even; 1.1 measured best: 243 vs 250 us)
         A.n0 = (h.nruns >= 2 && !(h.nruns & 1u) && wt > 1.0 && wt < 1.5) ? (uint32_t)std::llround(0.5 * wt * (double)A.nb) : 0u;
     }
     const double beta = h.dc_block ? h.beta : 0.0;

@@ -43,6 +43,28 @@ from ._lib import check, lib
 from .pipes import Chain, ChainConfig, _Handle
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on the process's stdout when a communicator is created; a caller whose stdout is a protocol
+    (bench.py: ONE JSON line) gets it on stderr instead.  File-descriptor level: the print comes from native code."""
+
+    def __enter__(self):
+        import os
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *a):
+        import os
+        try:
+            C.CDLL(None).fflush(None)          # the banner sits in C stdio's buffer (stdout is a pipe or a file): out with it while fd 1 is stderr
+        except Exception:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class Comm:
     """`csdr_comm` (include/csdr.h): the collectives UNDER the C ABI -- RCCL over xGMI, one process per GPU.  What a non-Python host
     (the Haskell program, host/soapy_sdr_file.cpp) calls; ShardedChain uses it instead of torch.distributed whenever the ranks are
@@ -53,7 +75,8 @@ class Comm:
             raise ValueError("unique_id: %d bytes" % _lib.COMM_ID_BYTES)
         h = C.c_void_p()
         buf = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(unique_id))
-        check(lib().csdr_comm_create(rank, world, buf, device, C.byref(h)))
+        with _stdout_to_stderr():
+            check(lib().csdr_comm_create(rank, world, buf, device, C.byref(h)))
         self._h = _Handle(h, lib().csdr_comm_destroy)
         self.rank, self.world = rank, world
 

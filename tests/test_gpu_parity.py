@@ -18,7 +18,7 @@ import pytest
 
 import oracle_lib as O
 from synth import synth_cf32
-from util import max_abs_err, rel_rms, wrap_pm
+from util import knob, max_abs_err, rel_rms, wrap_pm
 
 pytestmark = pytest.mark.gpu
 
@@ -545,9 +545,9 @@ def test_fused256_run_kernel_matches_tile_kernel_and_oracle(monkeypatch):
     nfs = [16 * 40 + 5, 16 * 9, 300]
     x = synth_cf32(M * sum(nfs), M, seed=31, dc=0.05 + 0.02j)
     for demod in ("none", "fm"):
-        monkeypatch.setenv("CSDR_RUN_MIN_TILES", "1")
+        knob(monkeypatch, "CSDR_RUN_MIN_TILES", "1")
         run = cs.Chain(channels=M, demod=demod, kf=0.3, max_frames=max(nfs))
-        monkeypatch.setenv("CSDR_RUN_MIN_TILES", "1000000")
+        knob(monkeypatch, "CSDR_RUN_MIN_TILES", "1000000")
         tile = cs.Chain(channels=M, demod=demod, kf=0.3, max_frames=max(nfs))
         orc = O.Chain(M, demod=demod, kf=0.3)
         pos = 0
@@ -788,7 +788,7 @@ def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
     assert r["cold_window"]["value"] > 0 and r["sustained_long"]["seconds"] >= 0.25 and r["sustained_long"]["value"] > 0
     assert r["roofline"]["launches"] == 3 and r["roofline"]["launch_ms"] > 0
     if shard == "channel":
-        assert r["scaling"] == "strong" and "channel-interleaved" in r["config"]["sharding"] and "interleaved-shard" in r["config"]["path"]
+        assert r["scaling"] == "strong" and "channel-interleaved" in r["config"]["sharding"] and "interleaved-shard" in r["config"]["route"]
         assert ("all-reduce" in r["config"]["collective"]) == mix
     else:
         assert r["scaling"] == "weak" and "time stripes" in r["config"]["sharding"] and r["config"]["collective"] == "none"
@@ -977,7 +977,7 @@ def test_full_size_cfg3_linearity_and_kernel_agreement(monkeypatch):
     x2 = synth_cf32_torch(M * nf, M, dev, seed=2)
 
     def run(x, demod, run_min):
-        monkeypatch.setenv("CSDR_RUN_MIN_TILES", str(run_min))
+        knob(monkeypatch, "CSDR_RUN_MIN_TILES", str(run_min))
         ch = cs.Chain(channels=M, demod=demod, max_frames=nf)
         out = torch.empty(M * nf * (1 if demod == "fm" else 2), dtype=torch.float32, device=dev)
         ch.process_device(x.data_ptr(), M * nf, out.data_ptr(), 0)
@@ -1022,12 +1022,12 @@ def test_run64_v2_matches_first_generation_kernel_and_oracle(monkeypatch):
     then 8192 frames (8 runs with warm-up and halo), a ragged call (first generation again), and 2048 more."""
     M = 64
     frames = [5, 8192, 70, 2048]
-    monkeypatch.setenv("CSDR_RUN64_V2_ALL", "1")                  # (by default k_run64v2 takes calls of >= 3072 tiles only: below that k_run64 is faster)
+    knob(monkeypatch, "CSDR_RUN64_V2_ALL", "1")                  # (by default k_run64v2 takes calls of >= 3072 tiles only: below that k_run64 is faster)
     x = synth_cf32(M * sum(frames), M, seed=64)
     x = (x + np.complex64(0.05 - 0.02j)).astype(np.complex64)
     kw = dict(channels=M, demod="none", max_frames=max(frames))
     a = cs.Chain(**kw)
-    monkeypatch.setenv("CSDR_RUN64_V1", "1")
+    knob(monkeypatch, "CSDR_RUN64_V1", "1")
     b = cs.Chain(**kw)
     monkeypatch.delenv("CSDR_RUN64_V1")
     orc = O.Chain(M, demod="none")
@@ -1059,10 +1059,10 @@ def test_second_generation_run_kernels_without_dc_blocker(M, demod, env, frames,
     those of k_run64 (same FIR order, same DFT butterflies)."""
     x = synth_cf32(M * sum(frames), M, seed=3)
     if M == 64:
-        monkeypatch.setenv("CSDR_RUN64_V2_ALL", "1")              # (k_run64v2 for calls of every size)
+        knob(monkeypatch, "CSDR_RUN64_V2_ALL", "1")              # (k_run64v2 for calls of every size)
     kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames), dc_block=False, **extra)
     a = cs.Chain(**kw)
-    monkeypatch.setenv(env, "1000000" if env == "CSDR_RUN_MIN_TILES" else "1")     # M = 256: the look-back tile kernel is the other implementation
+    knob(monkeypatch, env, "1000000" if env == "CSDR_RUN_MIN_TILES" else "1")     # M = 256: the look-back tile kernel is the other implementation
     b = cs.Chain(**kw)
     monkeypatch.delenv(env)
     pos = 0
@@ -1148,8 +1148,8 @@ def test_agc_tail_is_bit_identical_to_sequential(M, demod, mix, kind, monkeypatc
     """the segmented, verified AGC tail must reproduce the one-lane-per-channel kernels bit for bit, for any
     signal (speculation only decides how much is recomputed), across calls and ragged chunk lengths"""
     from composable_sdr_amd import _lib
-    monkeypatch.setenv("CSDR_AGC_L", "256")          # many segments even at test sizes
-    monkeypatch.setenv("CSDR_AGC_W", "512")
+    knob(monkeypatch, "CSDR_AGC_L", "256")          # many segments even at test sizes
+    knob(monkeypatch, "CSDR_AGC_W", "512")
     frames = [4096, 1000, 2056 + 3, 16, 7, 3000] if M > 1 else [40000, 1000, 20563, 16, 7]
     nf = sum(frames)
     x = _bursty(M, nf, 1234 + M, kind)
@@ -1226,8 +1226,8 @@ def test_agc_tail_tile_major_route_is_bit_identical_to_sequential(demod, G, monk
     import torch
     from composable_sdr_amd import _lib
     M, kf = 256, 0.3
-    monkeypatch.setenv("CSDR_AGC_W", "512")
-    monkeypatch.setenv("CSDR_AGC_L_TM", "688")
+    knob(monkeypatch, "CSDR_AGC_W", "512")
+    knob(monkeypatch, "CSDR_AGC_L_TM", "688")
     frames = [36864, 40000, 33, 32768 + 48]
     dev = torch.device("cuda", 0)
     xd = _bursty_torch(M, sum(frames), 4321 + G, dev)
@@ -1265,8 +1265,8 @@ def test_agc_tail_tile_major_route_at_1024_channels_is_bit_identical_to_sequenti
     import torch
     from composable_sdr_amd import _lib
     M, kf = 1024, 0.3
-    monkeypatch.setenv("CSDR_AGC_W", "512")
-    monkeypatch.setenv("CSDR_AGC_L_TM", "688")
+    knob(monkeypatch, "CSDR_AGC_W", "512")
+    knob(monkeypatch, "CSDR_AGC_L_TM", "688")
     frames = [8192, 8192 + 16, 33, 4096 + 32]
     dev = torch.device("cuda", 0)
     xd = _bursty_torch(M, sum(frames), 977, dev)
@@ -1361,9 +1361,9 @@ def test_fused256_run_kernel_strong_dc_warm_up(monkeypatch):
     x = synth_cf32(M * nf, M, seed=8, dc=0.3 + 0.2j)
     from composable_sdr_amd import _lib
     fl = _lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS
-    monkeypatch.setenv("CSDR_RUN_MIN_TILES", "1")
+    knob(monkeypatch, "CSDR_RUN_MIN_TILES", "1")
     run = cs.Chain(channels=M, max_frames=nf, flags=fl)
-    monkeypatch.setenv("CSDR_RUN_MIN_TILES", "1000000")
+    knob(monkeypatch, "CSDR_RUN_MIN_TILES", "1000000")
     tile = cs.Chain(channels=M, max_frames=nf, flags=fl)
     a, t = run.process(x), tile.process(x)
     krun, ktile = run.kernel_time()[0], tile.kernel_time()[0]
@@ -1654,9 +1654,9 @@ def test_pfb1024_fused_kernel_matches_three_kernel_route_and_oracle(demod, agc, 
     if shard:
         kw.update(chan_first=shard[0], chan_count=shard[1])
     a = cs.Chain(**kw)                                   # k_run1024: DC blocker + pre-mix + FIR + DFT + tail in one kernel
-    monkeypatch.setenv("CSDR_NO_RUN1024", "1")
+    knob(monkeypatch, "CSDR_NO_RUN1024", "1")
     a2 = cs.Chain(**kw)                                  # k_dc_tile + k_pfb1024
-    monkeypatch.setenv("CSDR_NO_PFB1024", "1")
+    knob(monkeypatch, "CSDR_NO_PFB1024", "1")
     b = cs.Chain(**kw)                                   # k_dc_tile + k_pfb_fir + k_fft_r16 + k_transpose(_fm)
     monkeypatch.delenv("CSDR_NO_PFB1024")
     monkeypatch.delenv("CSDR_NO_RUN1024")
@@ -1706,7 +1706,7 @@ def test_run1024_v3_matches_first_generation_kernel_and_oracle(demod, monkeypatc
     x = (x + np.complex64(0.01 - 0.005j)).astype(np.complex64)    # a DC offset the blocker has to remove across run starts
     kw = dict(channels=M, demod=demod, kf=0.3, max_frames=max(frames))
     a = cs.Chain(**kw)                                            # default: k_run1024v3 where it applies
-    monkeypatch.setenv("CSDR_RUN1024_V3", "0")
+    knob(monkeypatch, "CSDR_RUN1024_V3", "0")
     b = cs.Chain(**kw)
     monkeypatch.delenv("CSDR_RUN1024_V3")
     orc = O.Chain(M, demod=demod, kf=0.3)
@@ -1779,8 +1779,8 @@ def test_full_size_cfg4_shape_1024ch_fm_properties(monkeypatch):
     tone = torch.arange(M, device=dev) % 4 == 1
     print("cfg4 shape one-vs-8 chunks FM: tone-channel max", float(d[tone].max()), "median all", float(d.median()))
     assert float(d[tone].max()) < 1e-5 and float(d.median()) < 5e-6
-    monkeypatch.setenv("CSDR_NO_RUN1024", "1")
-    monkeypatch.setenv("CSDR_NO_PFB1024", "1")
+    knob(monkeypatch, "CSDR_NO_RUN1024", "1")
+    knob(monkeypatch, "CSDR_NO_PFB1024", "1")
     gen, gpath = run(x, "fm")
     monkeypatch.delenv("CSDR_NO_RUN1024"); monkeypatch.delenv("CSDR_NO_PFB1024")
     assert "generic" in gpath and "pfb1024" not in gpath
@@ -2143,48 +2143,6 @@ def test_submit_device_on_interleaved_shard_with_short_chunks():
         assert torch.equal(ya, yb), f
     a.status(); b.status()
     a.close(); b.close()
-
-
-@pytest.mark.parametrize("demod", ["fm", "none"])
-def test_run256_v3_matches_second_generation_kernel_and_oracle(demod, monkeypatch):
-    """k_run256v3 (one 512-thread workgroup per CU, front / back wave roles, CSDR_RUN_V3=1) on run-sized, ragged and small calls
-    with the state carried from call to call, against k_run256v2 on the same calls (same arithmetic per tile; the run starts sit
-    elsewhere, so the agreement is the run-start tolerance) and against the oracle on the first calls."""
-    import torch
-    from composable_sdr_amd import _lib
-    from synth import synth_cf32_torch
-    M, kf = 256, 0.3
-    frames = [40000, 33, 40016, 16, 40001, 36864, 32768 + 16]
-    x = synth_cf32_torch(M * sum(frames), M, torch.device("cuda", 0), seed=4242, dc=(0.09, -0.04)).cpu().numpy().view(np.complex64).reshape(-1)
-    kw = dict(channels=M, demod=demod, kf=kf, max_frames=max(frames), flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
-    monkeypatch.setenv("CSDR_RUN_V3", "1")
-    a = cs.Chain(**kw)
-    monkeypatch.setenv("CSDR_RUN_V3", "0")
-    b = cs.Chain(**kw)
-    ga, gb, pos, names = [], [], 0, []
-    for f in frames:
-        xa = x[pos * M:(pos + f) * M]
-        ga.append(a.process(xa)); gb.append(b.process(xa)); pos += f
-        names.append((a.kernel_time()[0], b.kernel_time()[0]))
-    a.close(); b.close()
-    tag = "FM" if demod == "fm" else "CF32"
-    assert [n[0] for i, n in enumerate(names) if frames[i] >= 32768] == [f"k_run256v3<{tag}>"] * 5, names
-    assert [n[1] for i, n in enumerate(names) if frames[i] >= 32768] == [f"k_run256v2<{tag}>"] * 5, names
-    ga, gb = np.concatenate(ga, axis=1), np.concatenate(gb, axis=1)
-    n_or = sum(frames[:3])
-    want = O.Chain(M, demod=demod, kf=kf).process(x[: M * n_or])
-    if demod == "fm":
-        d = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / kf))
-        do = np.abs(wrap_pm(ga[:, :n_or].astype(np.float64) - want, 1.0 / kf))
-        ds = np.abs(wrap_pm(gb[:, :n_or].astype(np.float64) - want, 1.0 / kf))
-        print(f"k_run256v3 vs v2 FM: tone channels max {d[1::4].max():.3e}, median {np.median(d):.3e}; vs oracle tone p99.9 {np.quantile(do[1::4], 0.999):.3e} (v2: {np.quantile(ds[1::4], 0.999):.3e})")
-        assert d[1::4].max() < 5e-6 and np.median(d) < 5e-6
-        assert np.quantile(do[1::4], 0.999) < 2e-5 and np.median(do) < 1.05 * np.median(ds) + 1e-7
-    else:
-        print(f"k_run256v3 vs v2 CF32: rel-rms {rel_rms(ga, gb):.3e}; vs oracle {rel_rms(ga[:, :n_or], want):.3e} (v2: {rel_rms(gb[:, :n_or], want):.3e})")
-        assert rel_rms(ga, gb) < 1e-6
-        assert rel_rms(ga[:, :n_or], want) < 1.05 * rel_rms(gb[:, :n_or], want) + 1e-7 and rel_rms(ga[:, :n_or], want) < 3e-5
-        assert max_abs_err(ga[:, :n_or], want) < 1e-4 * np.abs(want).max()
 
 
 def test_round3_entry_points_reset_seek_and_fallbacks():

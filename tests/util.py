@@ -15,3 +15,10 @@ def max_abs_err(a, b):
 def wrap_pm(x, period):
     """wrap differences of a quantity that is only defined modulo `period`"""
     return (x + period / 2) % period - period / 2
+
+
+def knob(monkeypatch, name, value):
+    """Set one of the library's diagnostics knobs (CSDR_RUN_MIN_TILES, CSDR_AGC_W, ...: DESIGN.md 6.1) for a test that forces a kernel
+    onto a small input: the library reads them only next to CSDR_DIAG=1 (csrc/csdr_internal.h diag_env)."""
+    monkeypatch.setenv("CSDR_DIAG", "1")
+    monkeypatch.setenv(name, value)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """cfg5 shape on one GPU (4096-ch PFB, DeNo --mix): step time of the product path (M * branch-0 FIR behind the DC blocker,
 `generic+mix-identity`) and of the full bank + DFT + channel sum (CSDR_FLAG_NO_MIX_IDENTITY).  Usage: python tools/cfg5_time.py"""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs are live here
 import os
 import sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))

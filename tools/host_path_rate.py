@@ -3,6 +3,7 @@
   * csdr_chain_process        blocking, pageable caller buffers (what the reference's unsafe FFI call looks like)
   * csdr_chain_submit/collect up to CSDR_CHAIN_INFLIGHT chunks in flight, page-locked caller buffers (csdr_host_alloc)
 at the reference's chunk (4 * 256 * 1024 samples = 4096 frames) and at 65 536 frames.  Usage: python tools/host_path_rate.py"""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs (DESIGN.md 6.1) are live here
 import os
 import sys
 import time

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launch time of the dominant kernel of a chain at the bench size, for A/B builds (CSDR_LIB) and env knobs:
     python tools/kernel_time.py [demod=fm|none] [channels] [frames] [agc]"""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs are live here
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

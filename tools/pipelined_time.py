@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Serial (csdr_chain_process_device on one stream) against pipelined (csdr_chain_submit_device: independent launches on two
 alternating streams) throughput of the bench configuration, same inputs, alternating input buffers."""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs are live here
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

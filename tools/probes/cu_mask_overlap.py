@@ -2,6 +2,7 @@
 """Can the channelizer (power / VALU-bound) and the AGC tail (memory-bound) of the cfg3 + AGC step run side by side on disjoint sets of
 compute units?  Two handles -- a DeNo chain (k_run256v2<CF32>) and a tail-only chain (k_agc_spec*) -- on two streams created with
 hipExtStreamCreateWithCUMask; each alone on the whole device, each alone behind its mask, both at once."""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs (DESIGN.md 6.1) are live here
 import os, sys, time, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

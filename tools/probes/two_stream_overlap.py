@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Channelizer and AGC tail of different chunks on two plain streams (no CU masks): with ONE channelizer workgroup per CU
 (CSDR_RESIDENT_WGS) half of every CU's registers and LDS stay free for tail workgroups -- do the two kernels share the CUs?"""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs are live here
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-rank step time of the interleaved channel shards of the fused 256-channel chain (rank 0 of G, same stream on every rank)
 beside the whole band, FM and FM + AGC: what an N-GPU channel-sharded run does per GPU."""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs are live here
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

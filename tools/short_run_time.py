@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """The 20-step timed region of bench.py after different amounts of untimed pre-heating (the board's clock / power state takes
 tens of milliseconds of load to settle: a 25-launch run sits entirely inside that transient)."""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs are live here
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -2,6 +2,7 @@
 """Whole-step wall time and the dominant kernel's launch time of the bench configuration under the three timer modes
 (no events / one event pair per launch / one pair per region), and optionally the board power and clocks while the
 chain runs back to back (POWER=1: samples rocm-smi from a side thread).  Diagnostics for DESIGN section 6."""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs (DESIGN.md 6.1) are live here
 import os, sys, time, json, subprocess, threading
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

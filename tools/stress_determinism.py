@@ -3,6 +3,7 @@
 while a memory-bound kernel runs on a side stream; every output is compared BIT FOR BIT with its twin.  The run kernels reuse LDS
 buffers across barriers, count vmcnt by hand and stage output in registers: a missing wait shows up here as a mismatch that moves
 from run to run."""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs (DESIGN.md 6.1) are live here
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

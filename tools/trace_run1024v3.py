@@ -3,6 +3,7 @@
 of phase P's work, the wait at bar Q, phase Q's work and what lies between it and bar P, for both roles.  Needs a library whose
 kernels_run1024_v3.hip was built with -DB3_TRACE=1: tools/build_variant.sh b3trace kernels_run1024_v3.hip -DB3_TRACE=1, then
 CSDR_LIB=$PWD/composable_sdr_amd/variants/libcsdr_b3trace.so python tools/trace_run1024v3.py"""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs (DESIGN.md 6.1) are live here
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-phase timeline of the fused tile kernel (CSDR_TRACE=1): runs a few bench-sized steps and
 prints the median cycles between consecutive s_memtime stamps of thread 0, over all tiles."""
+import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs are live here
 import os
 import sys
 os.environ.setdefault("CSDR_TRACE", "1")
