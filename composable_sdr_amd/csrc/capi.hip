@@ -140,6 +140,7 @@ struct csdr_chain {
     FusedPlan *fused = nullptr;
     SmallPlan *small = nullptr;
     BigPlan *big = nullptr;          // M = 1024 run kernel
+    HugePlan *huge = nullptr;        // M = 4096: branch-tiled front kernel + 1024-point back kernel (kernels_pfb4096.hip)
     DcTilePlan *dctile = nullptr;   // generic path with the DC blocker: single-pass scan kernel
     uint32_t n_cus = 256;            // compute units of the device (run count of the fused M = 1024 kernel)
     AgcTailPlan *agc_tail = nullptr; // AGC on: time-parallel verified tail (unless CSDR_FLAG_AGC_SEQUENTIAL)
@@ -617,7 +618,7 @@ int csdr_ampdem_destroy(csdr_ampdem *h)
 // between its run-sized and its chunk-sized kernel by the call's frame count (the thresholds are part of the row's text).
 // ---------------------------------------------------------------------------
 namespace {
-enum RoutePlan { PLAN_FUSED256, PLAN_SMALL64, PLAN_BIG1024, PLAN_GENERIC };
+enum RoutePlan { PLAN_FUSED256, PLAN_SMALL64, PLAN_BIG1024, PLAN_HUGE4096, PLAN_GENERIC };
 constexpr uint32_t ST1 = 1u << 1, ST2 = 1u << 2, ST4 = 1u << 4, ST8 = 1u << 8, ST_ANY = ~0u;
 struct RouteRow {
     uint32_t M;                 // channels the row is for; 0: any count
@@ -637,6 +638,11 @@ const RouteRow ROUTES[] = {
      "k_run1024v3<FM | CF32> (whole band, calls of whole 4-frame tiles; a call that ends inside a 128-byte line stores the front part of it); "
      "k_run1024v2<FM, G> (interleaved shards G = 2, 4, 8, FM output, run-sized calls of whole tiles)",
      "k_run1024<FM | CF32> (ragged calls, contiguous shards, the other calls of interleaved shards) [+ k_pfb1024_fixup, k_shard_gather1024]", "k_run1024v3<CF32> -> CF32 plane (tile-major) -> k_agc_spec_tm | k_run1024<CF32> -> k_agc_spec; -> k_agc_fix [-> k_mix]"},
+    {4096, ST1, PLAN_HUGE4096, "fused-4096",
+     "k_front4096 (DC blocker + pre-mix + FIR, branch-tiled: four sibling workgroups per frame, radix-4 split of the DFT on the registers) -> z (8 B / sample) "
+     "-> k_back4096<CF32 | FM | FM,mix> (four 1024-point DFTs per frame, 16-frame blocks, whole 128-byte lines per row) [-> k_mix4096_finish]; whole band; "
+     "DeNo --mix without the AGC keeps the any-M route's mix identity",
+     "the same kernels (any call size; short calls use fewer runs)", "k_front4096 -> k_back4096<CF32> -> CF32 plane -> k_agc_spec -> k_agc_fix [-> k_mix]"},
     {0, ST_ANY, PLAN_GENERIC, "generic",
      "k_dc_tile -> k_pfb_fir (M = 1024, forced generic: k_pfb1024) -> k_fft_r16 | k_fft_pow2 | k_dft_direct [interleaved shard: k_fold + (M / G)-point DFT] "
      "-> k_transpose_fm | k_mix_frames | k_transpose;  DeNo --mix over all channels: k_dc_fold + k_mixid_finish (M % 4096 == 0) | k_dc_tile + k_branch0_fir "
@@ -651,7 +657,8 @@ const RouteRow *route_select(uint32_t M, uint32_t p, uint32_t G, uint32_t flags)
     for (const RouteRow &r : ROUTES) {
         if (r.M != M || !(G < 32 && (r.strides >> G) & 1u)) continue;
         const bool ok = r.plan == PLAN_FUSED256 ? fused_supported(M, p) : r.plan == PLAN_SMALL64 ? small_supported(M, p)
-                      : r.plan == PLAN_BIG1024 ? (big_supported(M, p) && !diag_env("CSDR_NO_RUN1024")) : true;
+                      : r.plan == PLAN_BIG1024 ? (big_supported(M, p) && !diag_env("CSDR_NO_RUN1024"))
+                      : r.plan == PLAN_HUGE4096 ? (huge_supported(M, p) && !diag_env("CSDR_NO_RUN4096")) : true;
         if (ok) return &r;
     }
     return generic;
@@ -727,6 +734,7 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
     if (h->fused) { int r = fused_reset(h->fused, s); if (r) return r; }
     if (h->small) { int r = small_reset(h->small, s); if (r) return r; }
     if (h->big) { int r = big_reset(h->big, s); if (r) return r; }
+    if (h->huge) { int r = huge_reset(h->huge, s); if (r) return r; }
     if (h->dctile) { int r = dctile_reset(h->dctile, s); if (r) return r; }
     return 0;
 }
@@ -846,6 +854,9 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
     // exactly-sequential per-channel AGC tail (one lane per channel) + freqdem + mix follow.
     // interleaved shards: the fused M = 256 chain takes strides 2, 4, 8 (k_run256v2<.., G>); every other shape the any-M route with a pruned DFT
     const RouteRow *route = route_select(M, h->p, G, cfg->flags);          // the one place a configuration is mapped to a plan (table above)
+    if (route->plan == PLAN_HUGE4096 && (C != M || (cfg->mix && cfg->demod == CSDR_DEMOD_NONE && cfg->agc_threshold_db == 0.0f && !am)))
+        route = route_select(M, h->p, G, cfg->flags | CSDR_FLAG_FORCE_GENERIC);   // contiguous shards; DeNo --mix over all channels (= M x branch 0: nothing beats not computing
+                                                                                   // the bank; CSDR_FLAG_NO_MIX_IDENTITY's full bank + DFT + sum stays on the any-M kernels too)
     h->use_fused = route->plan != PLAN_GENERIC;
     if (h->use_fused) {
         const bool agc_on = cfg->agc_threshold_db != 0.0f;
@@ -858,6 +869,10 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             if ((r = small_create(fc, &h->small))) return fail(r);
             h->path = std::string("fused-") + small_name(h->small) + (agc_on ? "+agc" : "");
             h->timed_kernel = small_name(h->small);
+        } else if (route->plan == PLAN_HUGE4096) {
+            if ((r = huge_create(fc, &h->huge))) return fail(r);
+            h->path = std::string("fused-4096|") + huge_name(h->huge) + (agc_on ? "+agc" : "");
+            h->timed_kernel = huge_name(h->huge);
         } else if (route->plan == PLAN_BIG1024) {
             if ((r = big_create(fc, &h->big))) return fail(r);
             h->path = std::string("fused-") + big_name(h->big) + (G > 1 ? "+interleaved-shard" : "") + (agc_on ? "+agc" : "");
@@ -1210,6 +1225,7 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         fcall.indep = h->call_indep; fcall.ev_tail = h->call_ev_tail;
         if (h->small) { if ((r = small_process(h->small, fcall, s, &h->timer))) return r; h->timed_kernel = small_name(h->small); }   // k_run64v2 or k_run64, by call
         else if (h->big) { if ((r = big_process(h->big, fcall, s, &h->timer))) return r; h->timed_kernel = big_name(h->big); }   // k_run1024v2 or k_run1024, by call
+        else if (h->huge) { if ((r = huge_process(h->huge, fcall, s, &h->timer))) return r; }
         else if ((r = fused_process(h->fused, fcall, s, &h->timer))) return r;
         h->theta += n_in * h->d_theta;
         if (agc_on && h->agc_tail) {
@@ -1476,6 +1492,7 @@ int csdr_chain_seek_frames(csdr_chain *h, uint64_t frames)
     if (h->fused) fused_seek(h->fused, frames);
     if (h->small) small_seek(h->small, frames);
     if (h->big) big_seek(h->big, frames);
+    if (h->huge) huge_seek(h->huge, frames);
     return CSDR_OK;
 }
 
@@ -1542,6 +1559,7 @@ int csdr_chain_destroy(csdr_chain *h)
     if (h->fused) fused_destroy(h->fused);
     if (h->small) small_destroy(h->small);
     if (h->big) big_destroy(h->big);
+    if (h->huge) huge_destroy(h->huge);
     if (h->dctile) dctile_destroy(h->dctile);
     if (h->agc_tail) agc_tail_destroy(h->agc_tail);
     h->timer.destroy();

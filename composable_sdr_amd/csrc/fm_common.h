@@ -20,7 +20,11 @@ __device__ __forceinline__ float atan2f_rn(float y, float x)
     // mn / mx, with 0/0 -> 0 and inf/inf -> 1: those are the two cases in which mn * rcp(mx) is 0 * inf = NaN
     // (finite / inf is already 0).  Written as selects on the product: with the tests on mx in front the compiler
     // builds exec-masked branches around the rcp, two per sample, on the critical path of the AGC tail.
-    float a = mn * __builtin_amdgcn_rcpf(mx);
+    // (round 5) v_rcp_f32 takes a denormal for zero: with the AGC's gain collapsed to ~1e-21 (the reference's g0 = 1000 start transient on
+    // a strong channel) the products conj(r') r are ~1e-41 and mn * rcp(mx) came out inf -> NaN outputs where liquid's
+    // cargf gives an angle.  Products below 1e-30 are scaled by 2^90 first (exact; nothing changes for any other input).
+    const float sc = (mx < 1e-30f) ? 0x1p90f : 1.0f;
+    float a = (mn * sc) * __builtin_amdgcn_rcpf(mx * sc);
     const float t = (mx == 0.0f) ? 0.0f : 1.0f;
     a = (a == a) ? a : t;
     const float z = a * a;
@@ -54,7 +58,7 @@ __device__ __forceinline__ float fm_sample_rn(float2 rp, float2 r, float ref)
 // cycles per wave on gfx950, the SGPR form 4.6: tools/probes/issue_probe2.hip), max / min / rcp stay per sample.  ~21
 // instructions per sample instead of ~33: what the worker wave of the time-parallel AGC tail (kernels_agc_tail.hip) is paced by.
 typedef float fm_v2f __attribute__((ext_vector_type(2)));
-struct FmRnK { float c[9]; float hp, pi, ref; };         // VOP3P takes no literals: the constants live in VGPRs
+struct FmRnK { float c[9]; float hp, pi, ref, tthr, tsc; };         // VOP3P takes no literals: the constants live in VGPRs
 __device__ __forceinline__ float fm_opaque(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ FmRnK fm_rn_consts(float ref)
 {
@@ -64,6 +68,7 @@ __device__ __forceinline__ FmRnK fm_rn_consts(float ref)
 #pragma unroll
     for (int i = 0; i < 9; i++) k.c[i] = fm_opaque(c[i]);
     k.hp = fm_opaque(1.57079632679489662f); k.pi = fm_opaque(3.14159265358979324f); k.ref = fm_opaque(ref);
+    k.tthr = fm_opaque(1e-30f); k.tsc = fm_opaque(0x1p90f);
     return k;
 }
 __device__ __forceinline__ float fm_sel(unsigned long long m, float t, float f)              // m ? t : f, condition in an SGPR pair
@@ -90,7 +95,12 @@ __device__ __forceinline__ void fm_quad_rn(const float2 (&rp)[4], const float2 (
         float mx, mn;
         asm("v_max_f32_e64 %0, |%1|, |%2|" : "=v"(mx) : "v"(q[u].x), "v"(q[u].y));
         asm("v_min_f32_e64 %0, |%1|, |%2|" : "=v"(mn) : "v"(q[u].x), "v"(q[u].y));
-        float a = mn * __builtin_amdgcn_rcpf(mx);
+        // products below 1e-30 (a collapsed AGC gain) are scaled by 2^90 in front of the rcp, exactly as atan2f_rn does
+        unsigned long long mt;
+        float sc;
+        asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(mt) : "v"(mx), "v"(k.tthr));
+        asm("v_cndmask_b32_e64 %0, 1.0, %1, %2" : "=v"(sc) : "v"(k.tsc), "s"(mt));
+        float a = (mn * sc) * __builtin_amdgcn_rcpf(mx * sc);
         // a = (a == a) ? a : ((mx == 0) ? 0 : 1)
         unsigned long long mz, mo;
         float t1;

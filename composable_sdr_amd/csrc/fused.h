@@ -76,6 +76,17 @@ const char *big_name(const BigPlan *plan);
 bool big_tile_major_ok(const BigPlan *plan, uint32_t nf);     // FusedCall::tile_major for this call (CF32 output through k_run1024v3<CF32>)
 void big_destroy(BigPlan *plan);
 
+// M = 4096 (kernels_pfb4096.hip): branch-tiled front kernel (DC blocker + pre-mix + FIR + first radix-4 stage) -> z -> back kernel (four
+// 1024-point DFTs per frame + tails); whole band; same call interface
+struct HugePlan;
+bool huge_supported(uint32_t M, uint32_t p);
+int  huge_create(const FusedConfig &cfg, HugePlan **out);
+int  huge_reset(HugePlan *plan, hipStream_t s);
+int  huge_process(HugePlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
+void huge_seek(HugePlan *plan, uint64_t frames);
+const char *huge_name(const HugePlan *plan);
+void huge_destroy(HugePlan *plan);
+
 // k_run64v2 (kernels_run64_v2.hip): whole-band M = 64 calls with CF32 output and nf % 64 == 0; same state buffers as k_run64
 struct Run64v2Host {
     const float2 *x; float2 *out;

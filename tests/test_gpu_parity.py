@@ -878,6 +878,86 @@ def test_config5_shape_4096ch_mix_matches_oracle():
     assert np.abs(got - want).max() < 1e-4 * np.abs(wfull).max() * np.sqrt(M)
 
 
+def test_freqdem_of_a_collapsed_agc_gain_stays_finite():
+    """Round 5 find: with the reference's g0 = 1000 start transient a strong channel drives the AGC gain down to ~1e-21, the
+    products conj(r') r of the open samples behind it are ~1e-41 -- denormal -- and v_rcp_f32 takes a denormal for zero: freqdem came out
+    NaN where liquid's cargf gives an angle.  fm_sample_rn / fm_quad_rn now scale such products by 2^90 first."""
+    rng = np.random.default_rng(7)
+    n = 4096
+    base = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    for scale, tol in ((1.0, 2e-6), (1e-12, 2e-6), (3e-21, None), (1e-23, None)):
+        x = (base * np.float32(scale)).astype(np.complex64)
+        got = _run_pipe(cs.fmDemodulator(0.3), [x])[0]
+        want = O.FreqDem(0.3).demodulate_block(x)
+        assert np.isfinite(got).all(), scale
+        d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / 0.3))
+        print(f"freqdem at |r| ~ {scale:g}: max |err| {d.max():.2e} median {np.median(d):.2e}")
+        if tol is not None:
+            assert d.max() < tol
+        else:
+            # the oracle's (and liquid's) own products are denormal here: a few significant bits; the GPU's scaled ones are exact
+            assert np.median(d) < 0.05
+    # and through the chain: AGC + FM on a signal whose start transient collapses the gain
+    M = 64
+    x = (synth_cf32(M * 600, M, seed=77) * np.float32(40.0)).astype(np.complex64)
+    got = cs.Chain(channels=M, demod="fm", kf=0.3, agc=-40.0, max_frames=600).process(x)
+    assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("demod,agc,mix", [("none", 0.0, False), ("fm", 0.0, False), ("fm", 0.0, True), ("fm", 23.0, False), ("none", -10.0, True)])
+def test_fused4096_chain_matches_oracle_and_any_m_route(demod, agc, mix):
+    """The fused 4096-channel route (k_front4096: branch-tiled DC blocker + pre-mix + FIR + radix-4 split; k_back4096: four 1024-point DFTs
+    per frame + tails; kernels_pfb4096.hip) against the oracle and against the any-M route (CSDR_FLAG_FORCE_GENERIC), every call on its
+    own.  Calls: 40 frames (one run; run 0 from the zero state), 9 (odd, fewer frames than the 21-frame cold-start window: the saved raw tail
+    is shifted, the NCO parity turns odd), 250 (two runs: a cold start inside the call; ends inside a 16-frame block), 1024 (eight runs:
+    the XCD-aware workgroup map).  (-a 23: at 4096 channels the noise-only channels of the synthetic signal sit at rssi ~ +10 dB -- sigma^2 x
+    0.93 M -- and the carriers at +36 dB; the squelch threshold goes between the two populations, as SURVEY 8d prescribes.)"""
+    from composable_sdr_amd import _lib
+    M, kf = 4096, 0.3
+    nfs = [40, 9, 250, 1024]
+    x = synth_cf32(M * sum(nfs), M, seed=4096)
+    x = (x + np.complex64(0.02 - 0.01j)).astype(np.complex64)        # a DC offset the blocker has to carry across runs and calls
+    kw = dict(channels=M, demod=demod, kf=kf, agc=agc, mix=mix, max_frames=max(nfs))
+    ch = cs.Chain(**kw)
+    gen = cs.Chain(flags=_lib.FLAG_QUIET | _lib.FLAG_FORCE_GENERIC, **kw)
+    assert "fused-4096" in ch.path and "k_front4096" in ch.path and "fused" not in gen.path
+    orc = O.Chain(M, demod=demod, kf=kf, agc_db=agc, mix=mix)
+    pos = 0
+    for nf in nfs:
+        c = x[pos:pos + nf * M]; pos += nf * M
+        got, alt, want = ch.process(c), gen.process(c), orc.process(c)
+        assert got.shape == want.shape
+        if agc:
+            if mix:
+                e = np.abs(got - want).max() / max(np.abs(want).max(), 1e-9)
+                print(f"fused-4096 DeNo+AGC mix nf={nf}: {e:.2e}")
+                assert e < 2e-5 * np.sqrt(M)
+            else:
+                assert int(np.sum((got == 0) != (want == 0))) == 0, nf
+                op = want != 0
+                d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
+                assert not op.any() or np.median(d[op]) < 2e-5
+        elif demod == "none":
+            print(f"fused-4096 DeNo nf={nf}: vs oracle {rel_rms(got, want):.2e}, vs any-M {rel_rms(got, alt):.2e}")
+            assert rel_rms(got, want) < 1e-5 and max_abs_err(got, want) < 1e-4 * np.abs(want).max()
+            assert rel_rms(got, alt) < 2e-6
+        elif mix:
+            # a sum of 4096 freqdem outputs, most of them from noise-only channels: a sample next to the branch cut of arg() lands on the
+            # other side of it under any rounding difference and moves the sum by exactly 1 / kf -- compared modulo 1 / kf
+            d, da = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf)), np.abs(wrap_pm(got.astype(np.float64) - alt, 1.0 / kf))
+            print(f"fused-4096 FM mix nf={nf}: mod 1/kf max err vs oracle {d.max():.2e} median {np.median(d):.2e}, vs any-M {da.max():.2e} (sum of {M} values <= {1 / (2 * kf):.2f})")
+            # (3072 of the 4096 summands are noise-only channels whose phase error is the CF32 error over a small |r|: the f32 routes agree
+            # with each other to < 5e-3, with the oracle's f64 DFT to the sum of those ill-conditioned terms)
+            assert np.median(d) < 1e-2 and np.quantile(d, 0.99) < 0.15 and da.max() < 5e-3
+        else:
+            d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
+            da = np.abs(wrap_pm(got.astype(np.float64) - alt, 1.0 / kf))
+            tone = np.arange(M) % 4 == 1
+            print(f"fused-4096 FM nf={nf}: median {np.median(d):.2e}, tone p99.9 {np.quantile(d[tone], 0.999):.2e}; vs any-M median {np.median(da):.2e}")
+            assert np.median(d) < 2e-5 and np.quantile(d[tone], 0.999) < 2e-5 and np.median(da) < 2e-6
+    ch.close(); gen.close()
+
+
 def test_cpp_soapy_sdr_file_matches_python_replay(tmp_path):
     """The C++ host (soapy_sdr_file) and the Python replay drive the same C ABI: identical bytes."""
     import os
