@@ -49,6 +49,9 @@ void fused_destroy(FusedPlan *plan);
 // run_args points at a RunArgs (fused_common.h) the plan fills.
 int  run256_v2_launch(const void *run_args, bool fm, unsigned G, unsigned nruns, hipStream_t s);
 int  run256_v2_blocks_per_cu(bool fm);
+// RunArgs::nowu launches: the near-DC channels of every run's first 112 frames get what the true DC state at the run's start adds (Rt: host table
+// [2 parities][DCFIX_F][4], fused_common.h)
+int  run256_dcfix_launch(const void *run_args, bool fm, unsigned nruns, const float2 *Rt, hipStream_t s);
 // round 4's experiment (tools/variants/kernels_run256_v3.hip, NOT part of the product library: measured not faster):
 // one 512-thread workgroup per CU, front / back wave roles; linked only by tools/variants/build_run256_v3.sh (-DCSDR_WITH_RUN256_V3)
 int  run256_v3_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s);

@@ -417,7 +417,15 @@ struct RunArgs {
     uint32_t wu_batch6;         // k_run256v2: the six warm-up tiles in one batch of loads (0: two batches of three)
     uint32_t wu, wu_rot;        // k_run256v2: read-only warm-up tiles in front of a run's halo tile (WU = 6); runs walk them in rotated order
     uint32_t tile_step;         // k_run256v2 / v3: bytes between consecutive tiles in the output (16 frames x element size for row-major rows; C x 128 tile-major)
+    // round 5, whole-band k_run256v2: no read-only warm-up window at a run's start.  The run starts its halo tile from DC state 0; what
+    // the true state would have added is, 16 frames later, confined to the four channels around DC (the step's edge excites every channel
+    // for 13 frames -- the length of the FIR -- inside the halo tile, which has no output): k_run256_dcfix adds c_true x (the chain's
+    // response to a unit state, a host table) to the channels 126..129 of the run's first 112 frames.  cpre[w + 1]: the state in front of
+    // run w's last tile (= run w + 1's halo tile), left by run w; side: [run][4][DCFIX_F] the uncorrected Y of those channels.
+    uint32_t nowu;
+    float2 *cpre, *side;
 };
+constexpr int DCFIX_F = 113;    // frame -1 of a run (freqdem history) + its first seven tiles
 
 __device__ __forceinline__ float2 wg_sum(float2 v, float2 *red, int tid)
 {

@@ -914,7 +914,12 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
         const uint64_t nseg_t = 64ull * gmax;
         L = (uint32_t)((nf + nseg_t - 1) / nseg_t);
         L = (L + 15u) / 16u * 16u;
-        if (L < p->Lmin) L = p->Lmin;
+        // Lmin bounds the warm-up re-reads ((W + L) / L times the plane) of a bandwidth-bound call.  A call whose whole plane sits in the
+        // L2s (the reference's own 4096-frame chunk: 8 MiB at 256 channels) is bound by the walk instead -- (W + L) samples of a ~200-cycle
+        // recurrence per lane -- and 11 segments of 400 left 53 of a workgroup's 64 lanes idle: such calls take every segment the device
+        // has a lane for (round 5: 161 -> ~120 us per reference chunk)
+        const uint32_t lmin = ((uint64_t)p->C * nf * sizeof(float2) <= (24ull << 20)) ? 16u : p->Lmin;
+        if (L < lmin) L = lmin;
         if (((L / 16u) & 1u) == 0) L += 16u;
     }
     const uint32_t nseg = (nf + L - 1) / L;

@@ -374,6 +374,10 @@ struct FusedPlan {
     unsigned *d_ticket = nullptr, *d_yflag = nullptr, *d_status = nullptr;
     u64 *d_agg = nullptr, *d_ylast = nullptr;
     void *d_premix = nullptr;    // per-channel output before mixing
+    // whole-band run-kernel launches without warm-up windows (RunArgs::nowu, round 5): DC state in front of every run's halo tile, the
+    // uncorrected near-DC channels of every run's first tiles, the chain's response to a unit DC state (k_run256_dcfix)
+    float2 *d_cpre = nullptr, *d_side = nullptr, *d_rt = nullptr;
+    bool nowu = false;
     u64 *d_trace = nullptr;
     uint32_t run_min_tiles = 1024;   // chunks with at least this many tiles use the run kernel (measured crossover: FM ~900 tiles, CF32 ~700; profiles/r04_call_size_sweeps.txt)
     uint32_t cus = 256;
@@ -418,6 +422,13 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     if (const char *e = diag_env("CSDR_RUN_MIN_TILES")) p->run_min_tiles = (uint32_t)atol(e);
     if (cfg.mix) ALLOC(p->d_premix, (size_t)cfg.C * cfg.max_nf * (cfg.fm ? 4 : 8));
     if (diag_env("CSDR_TRACE")) { ALLOC(p->d_trace, sizeof(u64) * 16 * p->max_nb); CSDR_HIP(hipMemset(p->d_trace, 0, sizeof(u64) * 16 * p->max_nb)); }
+    p->nowu = cfg.G == 1 && cfg.c0 == 0 && cfg.C == cfg.M && cfg.dc_block && !(diag_env("CSDR_NOWU") && atoi(diag_env("CSDR_NOWU")) == 0);
+    if (p->nowu) {
+        ALLOC(p->d_cpre, sizeof(float2) * 2050);
+        ALLOC(p->d_side, sizeof(float2) * 2048 * 4 * DCFIX_F);
+        ALLOC(p->d_rt, sizeof(float2) * 2 * DCFIX_F * 4);
+        CSDR_HIP(hipMemset(p->d_cpre, 0, sizeof(float2) * 2050));
+    }
 #undef ALLOC
     CSDR_HIP(hipMemcpy(p->d_taps, cfg.taps, sizeof(float) * cfg.M * cfg.p, hipMemcpyHostToDevice));
     std::vector<float2> tw(cfg.M), wpre(2 * cfg.M);
@@ -435,6 +446,46 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
     }
     CSDR_HIP(hipMemcpy(p->d_tw, tw.data(), sizeof(float2) * cfg.M, hipMemcpyHostToDevice));
     CSDR_HIP(hipMemcpy(p->d_wpre, wpre.data(), sizeof(float2) * 2 * cfg.M, hipMemcpyHostToDevice));
+    if (p->nowu) {
+        // Response of the chain, at the channels 126..129, to a DC-blocker state of 1 in front of a tile: the blocker's output carries
+        // -alpha beta^n of it at sample n, which goes through the pre-mix (the table above), the polyphase FIR and the DFT like any
+        // input.  Frames 15 .. 127 behind the tile's start = frame -1 .. 111 of the run that started its halo tile without its state;
+        // by then the step's edge (13 frames of FIR, every channel) has left the filter and what remains sits around DC.  Both parities of
+        // the tile's first frame; f64 throughout.
+        const uint32_t M = cfg.M, T = 15 + DCFIX_F;
+        const double beta = (double)cfg.dc.beta, alpha = 1.0 - beta, tp = -2.0 * 3.14159265358979323846;
+        std::vector<float2> rt((size_t)2 * DCFIX_F * 4);
+        std::vector<double> ur((size_t)T * M), ui((size_t)T * M), xr(M), xi(M);
+        for (uint32_t par = 0; par < 2; par++) {
+            for (uint32_t f = 0; f < T; f++)
+                for (uint32_t j = 0; j < M; j++) {
+                    const double e = -alpha * std::pow(beta, (double)f * M + j);
+                    const float2 wv = wpre[((par + f) & 1u) * M + j];
+                    ur[(size_t)f * M + j] = e * (double)wv.x; ui[(size_t)f * M + j] = e * (double)wv.y;
+                }
+            for (uint32_t t = 0; t < (uint32_t)DCFIX_F; t++) {
+                const uint32_t f = 15 + t;
+                for (uint32_t j = 0; j < M; j++) {
+                    double ar = 0.0, ai = 0.0;
+                    for (uint32_t n = 0; n < cfg.p && n <= f; n++) {
+                        const double hh = (double)cfg.taps[(M - 1 - j) + n * M];
+                        ar += hh * ur[(size_t)(f - n) * M + j]; ai += hh * ui[(size_t)(f - n) * M + j];
+                    }
+                    xr[j] = ar; xi[j] = ai;
+                }
+                for (uint32_t ch = 0; ch < 4; ch++) {
+                    const uint32_t k = 126 + ch;
+                    double yr = 0.0, yi = 0.0;
+                    for (uint32_t j = 0; j < M; j++) {
+                        const double a = tp * (double)((j * k) % M) / (double)M, cr = std::cos(a), ci = std::sin(a);
+                        yr += xr[j] * cr - xi[j] * ci; yi += xr[j] * ci + xi[j] * cr;
+                    }
+                    rt[((size_t)par * DCFIX_F + t) * 4 + ch] = make_float2((float)yr, (float)yi);
+                }
+            }
+        }
+        CSDR_HIP(hipMemcpy(p->d_rt, rt.data(), sizeof(float2) * rt.size(), hipMemcpyHostToDevice));
+    }
     CSDR_HIP(hipMemset(p->d_status, 0, sizeof(unsigned)));
     CSDR_HIP(hipMemset(p->d_yflag, 0, sizeof(unsigned) * p->max_nb));
     CSDR_HIP(hipMemset(p->d_agg, 0, sizeof(u64) * 2 * p->max_nb));
@@ -568,6 +619,10 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         RA.tile_step = call.tile_major ? c.C * 128u : (uint32_t)NB * (c.fm ? 4u : 8u);
         const bool whole = nf == nb_full * NB;
         RA.indep = (call.indep && v2 && whole && !c.mix && p->keep_tail && p->tail_valid) ? 1u : 0u;
+        // whole band, dependent launches: no warm-up windows (the DC state a run misses at its start is put back, where it still matters 16 frames
+        // later -- the four channels around DC -- by k_run256_dcfix behind the launch); runs of >= 8 tiles, <= 2048 of them
+        RA.nowu = (p->nowu && !shard && !v3 && !RA.indep && nruns >= 2 && nruns <= 2048) ? 1u : 0u;
+        RA.cpre = p->d_cpre; RA.side = p->d_side;
         RA.prev_tail = p->d_tail[p->tail_w];
         if (call.indep && !RA.indep) { set_error("fused: internal: independent launch requested from a call that cannot run as one"); return -1; }
         if (p->keep_tail && !shard && v2 && whole && nb_full >= WU + 1) {
@@ -586,6 +641,7 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
 #endif
         else if ((r = run256_v2_launch(&RA, c.fm, c.G, nruns, s))) return r;
         if (timer && (r = timer->end(s))) return r;
+        if (RA.nowu && nb_full && (r = run256_dcfix_launch(&RA, c.fm, nruns, p->d_rt, s))) return r;
         const uint32_t rem = nf - nb_full * NB;
         if (rem) {
             if (nb_full) p->cur ^= 1;                            // the tail starts from the run kernel's state
@@ -648,7 +704,7 @@ void fused_destroy(FusedPlan *p)
 {
     if (!p) return;
     void *ptrs[] = {p->d_shard_tail, p->d_tail[0], p->d_tail[1], p->d_tail[2], p->d_taps, p->d_tw, p->d_wpre, p->d_yhist[0], p->d_yhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0],
-                    p->d_rp[1], p->d_ticket, p->d_yflag, p->d_status, p->d_agg, p->d_ylast, p->d_premix, p->d_trace};
+                    p->d_rp[1], p->d_ticket, p->d_yflag, p->d_status, p->d_agg, p->d_ylast, p->d_premix, p->d_trace, p->d_cpre, p->d_side, p->d_rt};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }

@@ -59,6 +59,7 @@
 #endif
 
 #include "fused_v2_common.h"
+#include <cstddef>
 #include <type_traits>
 
 namespace csdr {
@@ -86,6 +87,32 @@ struct V2Args {
     RunArgs r;
 };
 
+// k_run256v2 re-reads two pointer arguments from the kernarg segment right where it uses them: as loop invariants they cost the tile loop
+// SGPRs it does not have (the asm stores rely on a kernel without SGPR spills: tests/test_build_invariants.py).  A hand-written SCALAR
+// load: a pointer fetched through the vector memory path would be waited for with an s_waitcnt vmcnt(N) that hipcc computes without
+// knowing about the asm DMA / stores in flight (first version: the pointer was used before it had arrived).
+template <size_t OFF> __device__ __forceinline__ unsigned kernarg_u32_s()
+{
+    unsigned v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const char *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "n"(OFF) : "memory");
+#endif
+    return v;
+}
+template <size_t OFF> __device__ __forceinline__ float2 *kernarg_ptr_s()
+{
+    float2 *p = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const char *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "n"(OFF) : "memory");
+    p = reinterpret_cast<float2 *>(v);
+#endif
+    return p;
+}
 // G > 1: INTERLEAVED CHANNEL SHARD g = A.c0 of G (rank g of G owns the channels g, g + G, ...; G | 16).  With
 // k = k1 + 16 k2 ownership only depends on k1, and W16^(a k1) = W16^(a g) W16^(a k1'), k1 = g + k1': the factor W16^(a g) is a
 // constant of polyphase branch j = 16 a + b1 and rides on its pre-mix phasor for free, after which the shard needs the pass-1
@@ -122,7 +149,15 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     // wave w's DMA instruction `it` fills the 1 KiB half (w & 1) of frame 2 it + (w >> 1)
     const unsigned lds_wave = (unsigned)(size_t)(__attribute__((address_space(3))) float2 *)R + V2_FSB * (wave_u >> 1) + 1024u * (wave_u & 1u);
 
+#ifndef V2_TRACE
+#define V2_TRACE 0      // 1: the phase stamps of tools/trace_tiles.py (CSDR_TRACE=1 / 2) are compiled in -- a variant build (tools/build_variant.sh trace
+                        // kernels_fused_v2.hip -DV2_TRACE=1): in the product kernel their scalar conditions cost the tile loop SGPRs it needs (round 5)
+#endif
+#if V2_TRACE
 #define V2LSTAMP(i) do { if (A.trace && RA.trace_light && tid == 0) A.trace[(size_t)first * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define V2LSTAMP(i) do { } while (0)
+#endif
     V2LSTAMP(0);
     // Everything the run start waits for is requested up front, so that the prologue is one burst of memory traffic and not
     // a chain of round trips: the first tile (buffer 0) and the halo tile (buffer 1) by DMA, the table values as plain loads.
@@ -160,7 +195,8 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 #pragma unroll
         for (int f = 3; f < NB; f++) wa[f] = A.yhist_in[(f - 3) * M256 + j];
     } else {
-        const int h0 = RA.indep ? halo - (int)RA.wu : (halo > (int)RA.wu ? halo - (int)RA.wu : 0);
+        // (RA.nowu: no warm-up window -- the halo tile starts from state 0 unless it is the call's first tile, whose state is the carried one)
+        const int h0 = RA.nowu ? halo : (RA.indep ? halo - (int)RA.wu : (halo > (int)RA.wu ? halo - (int)RA.wu : 0));
         const unsigned nwu = (unsigned)(halo - h0);
         float4 raw[8];
         // weight of my piece `it` of a tile: beta^(4095 - n), n = n0 + 512 it (the swizzle term of the slot does not depend on it): two
@@ -279,6 +315,10 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             fft16_v(vv);                                // vv[i] = Y[k1 + 16 XIDX(i)]
 #pragma unroll
             for (int i = 0; i < 16; i++) ST[tid * 16 + i] = to_f2(vv[i]);
+            if (G == 1 && RA.nowu) {                    // frame -1 of the run, channels 126..129 = (k1, k2) = (14, 7), (15, 7), (0, 8), (1, 8): slots 13 and 2
+                if (tid >= 14) RA.side[((size_t)w * 4 + (tid - 14)) * DCFIX_F] = to_f2(vv[13]);
+                else if (tid <= 1) RA.side[((size_t)w * 4 + 2 + tid) * DCFIX_F] = to_f2(vv[2]);
+            }
         }
         __syncthreads();
     }
@@ -304,7 +344,11 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
     const unsigned z_a_g = (unsigned)f2 * V2_FSB + (unsigned)(G * j1) * 128u + ((unsigned)V2_ZSW(f2) << 4);
     const uint32_t voff = ((uint32_t)(G == 1 ? k1 : j1 + 16 * hb) * A.out_stride + A.out_t0 + (uint32_t)f2) * (FM ? 4u : 8u);  // + NK1 k2 rows, + 16 b frames
     const size_t row16 = (size_t)NK1 * A.out_stride * (FM ? 4u : 8u);
+#if V2_TRACE
 #define V2STAMP(i) do { if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b_ * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define V2STAMP(i) do { } while (0)
+#endif
 
     // FM: the even tile of a pair keeps its 16 results per thread and the odd tile stores both, so that the two 64-byte halves of
     // a row's 128-byte line reach the L2 back to back and leave it as ONE write (halves that arrive a tile apart are evicted
@@ -322,7 +366,10 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
             if (((b_ - first) + w / RA.prio_div) & 1u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
         V2STAMP(0);
-        if (A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b_ * 16 + 15] = __builtin_amdgcn_s_memrealtime();
+        if (G == 1 && b + 1 == last && tid == 0) {      // the DC state in front of the next run's halo tile (launches without warm-up windows)
+            if (kernarg_u32_s<offsetof(V2Args, r.nowu)>()) kernarg_ptr_s<offsetof(V2Args, r.cpre)>()[w + 1] = c;
+        }
+        if (V2_TRACE && A.trace && !RA.trace_light && tid == 0) A.trace[(size_t)b_ * 16 + 15] = __builtin_amdgcn_s_memrealtime();
         bar();                                          // B_a: the tile image has landed (every wave waited for its own DMA); the other buffer is free
         V2STAMP(1);
 #ifdef V2_SELECTIVE_POLICY
@@ -554,6 +601,13 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
         }
         if (!(V2_ABLATE & 16)) fft16_v(vv);             // vv[i] = Y[k1 + 16 XIDX(i)] of frame f2
         V2STAMP(11);
+        if (G == 1 && cold && b - first < 7u && kernarg_u32_s<offsetof(V2Args, r.nowu)>()) {   // (uniform) the run's first seven tiles: Y of the channels around DC for k_run256_dcfix
+            // (the kernel arguments are re-read here, behind an opaque copy of the pointer: as loop invariants they cost the tile loop SGPRs it
+            // does not have -- the asm stores below rely on a kernel without SGPR spills)
+            float2 *sd = kernarg_ptr_s<offsetof(V2Args, r.side)>() + ((size_t)w * 4) * DCFIX_F + 1 + 16 * (size_t)(b - first) + f2;
+            if (k1 >= 14) sd[(k1 - 14) * DCFIX_F] = to_f2(vv[13]);
+            else if (k1 <= 1) sd[(2 + k1) * DCFIX_F] = to_f2(vv[2]);
+        }
         // ---- tail
         char *obase = reinterpret_cast<char *>(A.out) + (size_t)b * RA.tile_step;
         if (FM) {
@@ -636,6 +690,55 @@ __global__ __launch_bounds__(256, 2) void k_run256v2(V2Args VA)
 }
 
 }  // namespace
+
+// k_run256_dcfix: run w >= 1 of a launch that ran without warm-up windows (RunArgs::nowu).  Thread t = frame t - 1 of the run, t = 0 .. 112;
+// Y = side + c_true x R[t][ch] for the channels 126..129, then the run's own tail for them (freqdem against the corrected frame in front).
+template <bool FM>
+__global__ __launch_bounds__(128) void k_run256_dcfix(V2Args VA, const float2 *__restrict__ Rt)
+{
+    const RunArgs &RA = VA.r;
+    const TileArgs &A = RA.t;
+    __shared__ float2 Ys[4][DCFIX_F + 1];
+    const unsigned w = blockIdx.x + 1;
+    unsigned first, last;
+    run_range(RA.split, w, first, last);
+    if (RA.pair_align) { first &= ~1u; if (last != A.nb) last &= ~1u; }
+    if (first >= last || first == 0) return;            // (a run whose halo tile is the call's first tile started from the carried state: exact)
+    const int t = threadIdx.x;
+    const float2 c = RA.cpre[w];
+    const float2 *R = Rt + (size_t)(A.parity0 & 1u) * DCFIX_F * 4;
+    float2 y[4];
+    if (t < DCFIX_F) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) {
+            const float2 r = R[t * 4 + ch], s0 = RA.side[((size_t)w * 4 + ch) * DCFIX_F + t];
+            y[ch] = make_float2(fmaf(c.x, r.x, fmaf(-c.y, r.y, s0.x)), fmaf(c.x, r.y, fmaf(c.y, r.x, s0.y)));
+            Ys[ch][t] = y[ch];
+        }
+    }
+    __syncthreads();
+    if (t < 1 || t >= DCFIX_F) return;
+    const unsigned b = first + (unsigned)(t - 1) / 16u, f2 = (unsigned)(t - 1) & 15u;
+    if (b >= last) return;
+    char *obase = reinterpret_cast<char *>(A.out) + (size_t)b * RA.tile_step;
+    const FmK fk = {1e-37f, A.fm_ref, RA.pk.hp, RA.pk.pi};
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++) {
+        const size_t off = ((size_t)(126 + ch) * A.out_stride + A.out_t0 + f2) * (FM ? 4u : 8u);
+        if (FM) *reinterpret_cast<float *>(obase + off) = fm_sample(Ys[ch][t - 1], y[ch], fk);
+        else *reinterpret_cast<float2 *>(obase + off) = y[ch];
+    }
+}
+
+int run256_dcfix_launch(const void *run_args, bool fm, unsigned nruns, const float2 *Rt, hipStream_t s)
+{
+    if (nruns < 2) return 0;
+    V2Args VA;
+    VA.r = *static_cast<const RunArgs *>(run_args);
+    if (fm) hipLaunchKernelGGL(k_run256_dcfix<true>, dim3(nruns - 1), dim3(128), 0, s, VA, Rt);
+    else hipLaunchKernelGGL(k_run256_dcfix<false>, dim3(nruns - 1), dim3(128), 0, s, VA, Rt);
+    return 0;
+}
 
 static V2Args make_v2(const void *run_args)
 {

@@ -568,6 +568,41 @@ def test_fused256_run_kernel_matches_tile_kernel_and_oracle(monkeypatch):
                 assert rel_rms(a, w) < 1e-5
 
 
+@pytest.mark.parametrize("demod", ["fm", "none"])
+def test_run_kernel_without_warm_up_windows_matches_the_warm_up_build(demod, monkeypatch):
+    """Round 5: whole-band k_run256v2 launches read no warm-up window in front of a run; the run starts its halo tile from DC state 0 and
+    k_run256_dcfix adds what the true state contributes to the four channels around DC (126..129) over the run's first 112 frames.  Against
+    the same library with the windows (CSDR_NOWU=0), a strong DC offset, 24 runs, two calls (state carried, odd first frame index inside the
+    second): every channel, and the corrected ones on their own; against the oracle behind an f64 DC blocker as the strong-DC test does."""
+    M, kf = 256, 0.3
+    nfs = [16 * 200, 16 * 192 + 5]
+    x = synth_cf32(M * sum(nfs), M, seed=55, dc=0.3 - 0.2j)
+    knob(monkeypatch, "CSDR_RUN_MIN_TILES", "1")
+    a = cs.Chain(channels=M, demod=demod, kf=kf, max_frames=max(nfs))
+    knob(monkeypatch, "CSDR_NOWU", "0")
+    b = cs.Chain(channels=M, demod=demod, kf=kf, max_frames=max(nfs))
+    monkeypatch.delenv("CSDR_NOWU")
+    orc = O.Chain(M, demod=demod, kf=kf)
+    pos = 0
+    for nf in nfs:
+        c = x[pos:pos + nf * M]; pos += nf * M
+        ga, gb, w = a.process(c), b.process(c), orc.process(c)
+        near = slice(126, 130)
+        if demod == "none":
+            e_all, e_near = rel_rms(ga, gb), rel_rms(ga[near], gb[near])
+            print(f"no-warm-up vs warm-up DeNo nf={nf}: all {e_all:.2e}, channels 126..129 {e_near:.2e}; vs oracle {rel_rms(ga, w):.2e} (warm-up build {rel_rms(gb, w):.2e})")
+            assert e_all < 2e-6 and e_near < 2e-5
+            assert rel_rms(ga, w) < 1.2 * rel_rms(gb, w) + 1e-6 and max_abs_err(ga, w) < 1e-4 * np.abs(w).max()
+        else:
+            d = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / kf))
+            dw = np.abs(wrap_pm(ga.astype(np.float64) - w, 1.0 / kf))
+            tone = np.arange(M) % 4 == 1
+            print(f"no-warm-up vs warm-up FM nf={nf}: median {np.median(d):.2e}, tone max {d[tone].max():.2e}, 126..129 median {np.median(d[near]):.2e}; vs oracle tone max {dw[tone].max():.2e}")
+            assert np.median(d) < 2e-6 and d[tone].max() < 1e-5 and np.median(d[near]) < 2e-5
+            assert dw[tone].max() < 3e-5
+    a.close(); b.close()
+
+
 # --------------------------------------------------------------------------- sharding on the HIP chain
 @pytest.mark.parametrize("mode", ["time", "channel"])
 def test_sharded_two_ranks_on_one_gpu(mode):

@@ -6,7 +6,7 @@ NAME=$1; SRC=$2; shift 2
 cd "$(dirname "$0")/../composable_sdr_amd/csrc"
 make -s -j8 > /dev/null
 mkdir -p ../variants build/var_$NAME
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result "$@" -c $SRC -o build/var_$NAME/$SRC.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result -Wno-invalid-offsetof "$@" -c $SRC -o build/var_$NAME/$SRC.o
 OBJS=$(ls build/*.o | grep -v "build/$SRC.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libcsdr_$NAME.so $OBJS build/var_$NAME/$SRC.o -ldl
 echo "built variants/libcsdr_$NAME.so"
