@@ -1104,6 +1104,9 @@ static int chain_process_device_any(csdr_chain *h, const void *d_in, uint32_t n_
 // order itself behind it without keeping the caller's stream handle
 static int chain_mark_user_stream(csdr_chain *h, hipStream_t stream)
 {
+    // only a handle that has used its host-buffer entry points has anything to order against (no event record per call on
+    // the device-only hot path, and none inside a caller's stream capture); the first host-buffer call synchronises the device once
+    if (!h->s_k) return CSDR_OK;
     if (!h->e_user) CSDR_HIP(hipEventCreateWithFlags(&h->e_user, hipEventDisableTiming));
     CSDR_HIP(hipEventRecord(h->e_user, stream));
     h->user_stream_dirty = true;
@@ -1359,6 +1362,7 @@ static bool is_pinned(const void *p)
 static int chain_host_init(csdr_chain *h)
 {
     if (h->s_k) return CSDR_OK;
+    CSDR_HIP(hipDeviceSynchronize());                   // whatever csdr_chain_process_device calls have queued on caller streams so far
     CSDR_HIP(hipStreamCreateWithFlags(&h->s_in, hipStreamNonBlocking));
     CSDR_HIP(hipStreamCreateWithFlags(&h->s_k, hipStreamNonBlocking));
     CSDR_HIP(hipStreamCreateWithFlags(&h->s_out, hipStreamNonBlocking));

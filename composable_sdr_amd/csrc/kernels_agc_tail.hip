@@ -397,7 +397,9 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec(TailArgs A, uint32_t groups
 // and a workgroup's 64 streams are 64 CHANNELS at the same segment: every lane is at the same time position, block kk of the
 // workgroup is one contiguous 8 KiB, and nothing in the kernel depends on the lane any more except the state.
 //   * mover wave: eight global_load_lds_dwordx4 per block (HBM -> LDS ring without registers, XOR swizzle on the source address as
-//     in k_run256v2), TM_DEPTH blocks ahead; its vmcnt queue holds nothing else, so `s_waitcnt vmcnt(8 n)` is exact;
+//     in k_run256v2), TM_DEPTH blocks ahead; its vmcnt queue holds the DMA plus a few state records (the seg_start record at the end of the warm-up and a
+//     checkpoint every TM_CK samples are global stores inside the loop, and stores count in vmcnt on gfx9), so `s_waitcnt vmcnt(8 n)` can only
+//     wait for MORE than the n youngest blocks: always safe, exact in the iterations without such a store;
 //   * worker wave: the recurrence out of the ring, freqdem as fm_quad_rn (packed, SGPR-mask selects, bit-identical to
 //     fm_sample_rn), and the outputs straight from its registers as 64-byte (F32) / 128-byte (CF32) row pieces -- nothing goes back
 //     through the ring;

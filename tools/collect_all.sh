@@ -8,4 +8,7 @@ python3 tools/collect_profile.py gpurun_out/prof_${R}_cfg2_m64_deno ${R}_cfg2_m6
 python3 tools/collect_profile.py gpurun_out/prof_${R}_cfg4shape_1024_fm_v3 ${R}_cfg4shape_1024_fm_v3 1024 65536 > /dev/null
 python3 tools/collect_profile.py gpurun_out/prof_${R}_1024_deno_v3 ${R}_1024_deno_v3 1024 65536 > /dev/null
 python3 tools/collect_profile.py gpurun_out/prof_${R}_cfg5shape_4096_mix ${R}_cfg5shape_4096_mix 4096 16384 > /dev/null
+python3 tools/collect_profile.py gpurun_out/prof_${R}_4096_deno ${R}_4096_deno 4096 16384 > /dev/null
+python3 tools/collect_profile.py gpurun_out/prof_${R}_4096_fm ${R}_4096_fm 4096 16384 > /dev/null
+python3 tools/collect_profile.py gpurun_out/prof_${R}_4096_fm_mix ${R}_4096_fm_mix 4096 16384 > /dev/null
 cat profiles/traffic.json | head -80

@@ -86,6 +86,22 @@ for k, c in vals.items():
             "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
             "fetch_size_kib_raw": c["FETCH_SIZE"], "write_size_kib_raw": c["WRITE_SIZE"],
             "note": "median over the launches of one run; FETCH_SIZE x2 (gfx950 wide-load under-count), WRITE_SIZE as reported", "source": f"profiles/{tag}_rocprofv3_summary.txt"}
+# the fused 4096-channel route is two launches per call (k_front4096 -> z -> k_back4096<MODE>): bench.py times them as one step under
+# the name the plan reports; their bytes add up
+fr = [k for k in vals if "k_front4096" in k and "FETCH_SIZE" in vals[k] and "WRITE_SIZE" in vals[k]]
+bk = [k for k in vals if "k_back4096" in k and "FETCH_SIZE" in vals[k] and "WRITE_SIZE" in vals[k]]
+if fr and bk:
+    mode = bk[0].split("k_back4096<")[1].split(">")[0].strip()
+    name = {"0": "k_front4096+k_back4096<CF32>", "1": "k_front4096+k_back4096<FM>", "2": "k_front4096+k_back4096<FM,mix>"}.get(mode)
+    if name:
+        rd = sum(vals[k]["FETCH_SIZE"] for k in (fr[0], bk[0])) * 1024 * 2
+        wr = sum(vals[k]["WRITE_SIZE"] for k in (fr[0], bk[0])) * 1024
+        tj[f"{name}|M={M}|nf={nf}"] = {
+            "src_sha16": SRC_SHA, "hbm_bytes_per_launch": int(rd + wr), "read_bytes": int(rd), "write_bytes": int(wr),
+            "front_fetch_kib_raw": vals[fr[0]]["FETCH_SIZE"], "front_write_kib_raw": vals[fr[0]]["WRITE_SIZE"],
+            "back_fetch_kib_raw": vals[bk[0]]["FETCH_SIZE"], "back_write_kib_raw": vals[bk[0]]["WRITE_SIZE"],
+            "note": "front + back launch of one call (median each); FETCH_SIZE x2 (gfx950 wide-load under-count; the front's fetches include its four-fold L2-served re-reads only as far as they miss), WRITE_SIZE as reported",
+            "source": f"profiles/{tag}_rocprofv3_summary.txt"}
 json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
 print(open(os.path.join(dst, f"{tag}_rocprofv3_summary.txt")).read()[:1500])
 print(json.dumps(tj, indent=1))

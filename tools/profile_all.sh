@@ -10,3 +10,6 @@ tools/profile_lite.sh ${R}_cfg2_m64_deno --channels 64 --frames 1048576 --demod 
 tools/profile.sh ${R}_cfg4shape_1024_fm_v3 --channels 1024 --frames 65536
 tools/profile_lite.sh ${R}_1024_deno_v3 --channels 1024 --frames 65536 --demod none --no-agc-variant
 tools/profile_lite.sh ${R}_cfg5shape_4096_mix --channels 4096 --frames 16384 --demod none --mix --no-agc-variant
+tools/profile_lite.sh ${R}_4096_deno --channels 4096 --frames 16384 --demod none --no-agc-variant
+tools/profile_lite.sh ${R}_4096_fm --channels 4096 --frames 16384 --demod fm --no-agc-variant
+tools/profile_lite.sh ${R}_4096_fm_mix --channels 4096 --frames 16384 --demod fm --mix --no-agc-variant
