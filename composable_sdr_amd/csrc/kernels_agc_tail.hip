@@ -31,6 +31,12 @@
 #define CSDR_AGC_ABLATE 0      // timing experiments only: 1 no log/exp, 2 every block reloads the same (cached) lines, 4 no stores, 16 no compute, 32 mover skips the ring writes, 64 no barrier
 #endif
 
+#ifndef TM_ABLATE
+#define TM_ABLATE 0          // timing experiments only: 1 post wave without the freqdem arithmetic, 2 gain wave without the recurrence, 4 no output stores
+#endif
+#ifndef TM_TRACE
+#define TM_TRACE 0           // 1 (variant build, tools/build_variant.sh): where the two waves of three workgroups spend their cycles (device printf)
+#endif
 namespace csdr {
 
 namespace {
@@ -176,246 +182,6 @@ __device__ __forceinline__ void agc_quad(const float4 &va, const float4 &vb, Agc
     else { oa = make_float4(y[0].x, y[0].y, y[1].x, y[1].y); ob = make_float4(y[2].x, y[2].y, y[3].x, y[3].y); }
 }
 
-// One lane per (channel, segment) stream; a workgroup is 64 consecutive segments of ONE channel (grid = channels x
-// segment groups, so every address is the uniform row plus a lane-derived segment) served by TWO waves:
-//   * the worker (wave 0) runs the recurrence: block k of 16 samples per stream comes out of an LDS ring slot one line
-//     per lane, four samples at a time, and the outputs go back over the stream's own consumed input pieces;
-//   * the mover (wave 1) does everything that waits for memory: while block k is worked on it writes block k + 1
-//     (fetched during the previous iteration, 8 lanes per 128-byte line) into the next ring slot, issues the loads of
-//     block k + 2 and stores the outputs of block k - 1 as whole lines.
-// One LDS-only barrier per block (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() would drain the loads in
-// flight).  With a single wave doing load -> LDS -> arithmetic -> LDS -> store one after the other nothing overlapped:
-// at the segment lengths that keep the warm-up re-reads low there are too few streams for the other waves of a SIMD
-// to cover for it (0.44 ms per 67 M samples however the arithmetic was trimmed; data path alone 0.36, arithmetic
-// alone 0.33).
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-template <bool FM, bool PAIRS>
-__global__ __launch_bounds__(128, 2) void k_agc_spec(TailArgs A, uint32_t groups)   // <= 256 VGPRs
-{
-    __shared__ float4 ring[3][64 * 8];
-    const int lane = threadIdx.x & 63;
-    const bool mover = threadIdx.x >= 64;                       // wave-uniform
-    const uint32_t c = blockIdx.x / groups, sbase = (blockIdx.x % groups) * 64u;   // uniform: channel, first segment
-    const size_t row = (size_t)c * A.nf;
-    const uint32_t nblk = (A.W + A.L) / 16u, kreal = A.W / 16u;
-    const int pc = lane & 7;
-
-    // block k: instruction m of the cooperative access handles stream 8m + (lane >> 3).  Branch-free (clamped
-    // address, invalid halves zeroed afterwards) so that the eight loads are in flight together: with a branch per
-    // load the compiler waits for each one before the next and the block pays eight memory latencies in a row.
-    const size_t total = (size_t)A.C * A.nf;
-    auto load_block = [&](uint32_t k, float4 (&ld)[8]) {
-#pragma unroll
-        for (int m = 0; m < 8; m++) {
-            const uint32_t ss = sbase + 8 * m + (lane >> 3);
-            const int32_t t = (int32_t)(ss * A.L) - (int32_t)A.W + (int32_t)(16 * k) + 2 * pc;   // first of the piece's two samples
-            const uint32_t e = min(A.nf, ss * A.L + A.L);
-            const bool ok0 = ss < A.nseg && t >= 0 && (uint32_t)t < e, ok1 = ss < A.nseg && t >= 0 && (uint32_t)t + 1 < e;
-            const size_t idx = row + (uint32_t)max(t, 0);
-            float4 v;
-            if (PAIRS) v = *reinterpret_cast<const float4 *>(A.Z + min(idx, total - 2));
-            else { const float2 a = A.Z[min(idx, total - 1)], b = A.Z[min(idx + 1, total - 1)]; v = make_float4(a.x, a.y, b.x, b.y); }
-            ld[m] = make_float4(ok0 ? v.x : 0.f, ok0 ? v.y : 0.f, ok1 ? v.z : 0.f, ok1 ? v.w : 0.f);
-        }
-    };
-
-    // Interior blocks -- all 64 streams of the group exist and the block lies inside every stream's range (all but the
-    // first W samples of a row and its ragged end) -- need no range tests at all: one uniform base pointer and a
-    // 32-bit lane offset per piece.  The general path's clamps, masks and 64-bit addresses cost as many VALU
-    // instructions per block as sixteen warm-up steps.
-    const bool group_full = PAIRS && sbase + 64u <= A.nseg;
-    const int64_t t_first = (int64_t)sbase * A.L - (int64_t)A.W;                    // stream 0's sample at k = 0
-    const int64_t t_lastend = (int64_t)(sbase + 63u) * A.L - (int64_t)A.W + 15;     // stream 63's last sample at k = 0
-    const char *wbase = reinterpret_cast<const char *>(A.Z + row) + t_first * 8;    // uniform; dereferenced on interior blocks only
-    const uint32_t voff0 = ((uint32_t)(lane >> 3) * A.L + 2u * (uint32_t)pc) * 8u;  // bytes: my piece of stream lane >> 3
-    const uint32_t mstep = 64u * A.L;                                               // bytes: eight streams further
-    auto is_inner = [&](uint32_t k) { return group_full && t_first + 16 * (int64_t)k >= 0 && t_lastend + 16 * (int64_t)k < (int64_t)A.nf; };
-    // block k's eight pieces -> registers (not waited for here on interior blocks: nothing touches the data)
-    auto fetch = [&](uint32_t k, float4 (&ld)[8]) {
-        if (is_inner(k)) {
-#pragma unroll
-            for (int m = 0; m < 8; m++) ld[m] = *reinterpret_cast<const float4 *>(wbase + (voff0 + (uint32_t)m * mstep + 128u * ((CSDR_AGC_ABLATE & 2) ? (k >= kreal ? kreal : 0u) : k)));
-        } else load_block(k, ld);
-    };
-
-    // outputs of block k (>= kreal) leave as whole lines
-    auto store_block = [&](uint32_t k, const float4 *buf) {
-        if ((CSDR_AGC_ABLATE & 4) && A.nf != 0xffffffffu) return;
-        const uint32_t tb = 16 * (k - kreal);
-        if (is_inner(k) && (!FM || (row & 3) == 0)) {
-            // interior block, 16-byte aligned rows: the same uniform-base addressing as the loads
-            if (FM) {
-                char *obase = reinterpret_cast<char *>((float *)A.out + row + (size_t)sbase * A.L + tb);
-                const uint32_t off = ((uint32_t)(lane >> 2) * A.L + 4u * (uint32_t)(lane & 3)) * 4u;
-#pragma unroll
-                for (int m = 0; m < 4; m++)
-                    *reinterpret_cast<float4 *>(obase + (off + (uint32_t)m * mstep)) = buf[slot8(16 * m + (lane >> 2), lane & 3)];
-            } else {
-                char *obase = reinterpret_cast<char *>((float2 *)A.out + row + (size_t)sbase * A.L + tb);
-#pragma unroll
-                for (int m = 0; m < 8; m++)
-                    *reinterpret_cast<float4 *>(obase + (voff0 + (uint32_t)m * mstep)) = buf[slot8(8 * m + (lane >> 3), pc)];
-            }
-            return;
-        }
-        if (FM) {
-            float *outp = (float *)A.out;
-#pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const int j = 16 * m + (lane >> 2), p4 = lane & 3;
-                const uint32_t ss = sbase + j;
-                if (ss < A.nseg) {
-                    const uint32_t t = ss * A.L + tb + 4 * p4, e = min(A.nf, ss * A.L + A.L);
-                    const float4 v = buf[slot8(j, p4)];
-                    const size_t idx = row + t;
-                    float *dst = outp + idx;
-                    if (t + 4 <= e && (idx & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
-                    else {
-                        if (t < e) dst[0] = v.x;
-                        if (t + 1 < e) dst[1] = v.y;
-                        if (t + 2 < e) dst[2] = v.z;
-                        if (t + 3 < e) dst[3] = v.w;
-                    }
-                }
-            }
-        } else {
-            float2 *outp = (float2 *)A.out;
-#pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const uint32_t ss = sbase + 8 * m + (lane >> 3);
-                if (ss < A.nseg) {
-                    const uint32_t t = ss * A.L + tb + 2 * pc, e = min(A.nf, ss * A.L + A.L);
-                    const float4 v = buf[slot8(8 * m + (lane >> 3), pc)];
-                    const size_t idx = row + t;
-                    float2 *dst = outp + idx;
-                    if (t + 2 <= e && (idx & 1) == 0) *reinterpret_cast<float4 *>(dst) = v;
-                    else {
-                        if (t < e) dst[0] = make_float2(v.x, v.y);
-                        if (t + 1 < e) dst[1] = make_float2(v.z, v.w);
-                    }
-                }
-            }
-        }
-    };
-
-    // the worker's stream
-    const uint32_t sg = sbase + lane;
-    const bool mine = sg < A.nseg;
-    const uint32_t endv = mine ? min(A.nf, sg * A.L + A.L) : 0u;
-    AgcSeg q;
-    {
-        // segments that begin <= W samples into the call run from sample 0 and from the TRUE state; the others warm up from st_spec
-        const AgcState s0 = ((uint64_t)sg * A.L > A.W) ? A.st_spec[c] : A.st_in[c];
-        q.g = s0.g; q.y2 = s0.y2; q.mode = (int32_t)s_encode(s0.mode, s0.timer); q.timer = 0;
-        const float2 r0 = FM ? A.rp_in[c] : make_float2(0.f, 0.f);
-        q.rx = r0.x; q.ry = r0.y; q.pad0 = q.pad1 = 0;
-    }
-    auto work_block = [&](uint32_t k, float4 *buf) {
-        const int32_t t0 = (int32_t)(sg * A.L) - (int32_t)A.W + (int32_t)(16 * k);
-        if (mine && k == kreal) A.seg_start[(size_t)c * A.nseg + sg] = q;       // state at the segment start, after the warm-up
-        const bool inner = is_inner(k);
-        const bool live = inner || (t0 >= 0 && (uint32_t)t0 < endv);
-        const bool full = inner || !live || (uint32_t)t0 + 16 <= endv;
-        if ((CSDR_AGC_ABLATE & 16)) return;
-        if (k < kreal) {
-            // warm-up block (always whole): only the state matters -- no freqdem, nothing stored
-            if (live) {
-#pragma unroll 1
-                for (int h = 0; h < 4; h++) {
-                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
-                    float4 oa, ob;
-                    agc_quad<false, false>(va, vb, q, A.p, A.ref, 0u, 0u, oa, ob);
-                    if (FM) { q.rx = ob.z; q.ry = ob.w; }       // r' = the last (possibly muted) AGC output
-                }
-            }
-        } else if (__builtin_amdgcn_ballot_w64(!full) == 0ull) {
-            if (live) {
-#pragma unroll 1
-                for (int h = 0; h < 4; h++) {
-                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
-                    float4 oa, ob;
-                    agc_quad<FM, false>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, endv, oa, ob);
-                    // in place: output piece h (F32) / pieces 2h, 2h+1 (CF32) over input pieces already consumed
-                    if (FM) buf[slot8(lane, h)] = oa;
-                    else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
-                }
-            }
-        } else if (live) {
-#pragma unroll 1
-            for (int h = 0; h < 4; h++) {
-                const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
-                float4 oa, ob;
-                agc_quad<FM, true>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, endv, oa, ob);
-                if (FM) buf[slot8(lane, h)] = oa;
-                else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
-            }
-        }
-    };
-
-    // iteration `it`: the mover fills slot it % 3 with block it and empties slot (it - 2) % 3, the worker is on
-    // block it - 1 in slot (it - 1) % 3.  The mover keeps TWO blocks in flight (it + 1 and it + 2, two register sets
-    // used alternately -- hence the loop runs in pairs): with one, an iteration lasted a memory round trip.
-    float4 lda[8], ldb[8];
-    uint32_t s_in = 0, s_wk = 2, s_out = 1;                     // it % 3, (it - 1) % 3, (it - 2) % 3
-    if (mover) { fetch(0, lda); if (1 < nblk) fetch(1, ldb); }
-    auto iteration = [&](uint32_t it, float4 (&ld)[8]) {       // ld holds block it (mover)
-        if (mover) {
-            if (it < nblk) {
-                if (CSDR_AGC_ABLATE & 32) {
-#pragma unroll
-                    for (int m = 0; m < 8; m++) { const float t0 = ld[m].x, t1 = ld[m].w; asm volatile("" :: "v"(t0), "v"(t1)); }
-                } else {
-#pragma unroll
-                    for (int m = 0; m < 8; m++) ring[s_in][slot8(8 * m + (lane >> 3), pc)] = ld[m];
-                }
-                if (it + 2 < nblk) fetch(it + 2, ld);
-            }
-            if (it >= 2 && it - 2 >= kreal && it - 2 < nblk) store_block(it - 2, ring[s_out]);
-        } else if (it >= 1 && it - 1 < nblk) work_block(it - 1, ring[s_wk]);
-        if (!(CSDR_AGC_ABLATE & 64)) lds_barrier();
-        s_out = s_wk; s_wk = s_in; s_in = s_in == 2 ? 0 : s_in + 1;
-    };
-    for (uint32_t it = 0; it < nblk + 2; it += 2) {
-        iteration(it, lda);
-        iteration(it + 1, ldb);                                 // it + 1 may be nblk + 2: nothing left to do but the barrier
-    }
-    if (!mover && mine) A.seg_end[(size_t)c * A.nseg + sg] = q;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// k_agc_spec_tm (round 4): the same speculation on a TILE-MAJOR channelizer plane.
-//
-// k_agc_spec's 64 streams are 64 segments of one channel: every block iteration fetches 64 lines that lie a segment (8 KiB)
-// apart, one DRAM page each (4.1 TB/s however many were in flight), through registers, and the worker wave pays ~33
-// instructions per sample for the freqdem with VCC selects.  Here the fused run kernels write the CF32 plane tile-major -- block
-// B of 16 frames holds the 128-byte lines of all C channels back to back, i.e. a tile's whole output is ONE contiguous 32 KiB --
-// and a workgroup's 64 streams are 64 CHANNELS at the same segment: every lane is at the same time position, block kk of the
-// workgroup is one contiguous 8 KiB, and nothing in the kernel depends on the lane any more except the state.
-//   * mover wave: eight global_load_lds_dwordx4 per block (HBM -> LDS ring without registers, XOR swizzle on the source address as
-//     in k_run256v2), TM_DEPTH blocks ahead; its vmcnt queue holds the DMA plus a few state records (the seg_start record at the end of the warm-up and a
-//     checkpoint every TM_CK samples are global stores inside the loop, and stores count in vmcnt on gfx9), so `s_waitcnt vmcnt(8 n)` can only
-//     wait for MORE than the n youngest blocks: always safe, exact in the iterations without such a store (ADVICE r04);
-//   * worker wave: the recurrence out of the ring, freqdem as fm_quad_rn (packed, SGPR-mask selects, bit-identical to
-//     fm_sample_rn), and the outputs straight from its registers as 64-byte (F32) / 128-byte (CF32) row pieces -- nothing goes back
-//     through the ring;
-//   * one LDS-only barrier per block.
-// Channels per workgroup Cw = min(C, 64); for C < 64 (interleaved shards of eight) a workgroup takes 64 / C segments.
-// Same records, same verification (k_agc_fix), same bits as k_agc_spec.
-#ifndef TM_ABLATE
-#define TM_ABLATE 0          // timing experiments only: 1 post wave without the freqdem arithmetic, 2 gain wave without the recurrence, 4 no output stores
-#endif
-#ifndef TM_DEPTH_N
-#define TM_DEPTH_N 3
-#endif
-constexpr int TM_DEPTH = TM_DEPTH_N;        // blocks in flight
-static_assert(TM_DEPTH >= 1 && TM_DEPTH <= 6, "vmcnt immediates above");
-constexpr int TM_SLOTS = TM_DEPTH + 2;      // ring slots of 8 KiB: TM_DEPTH in flight, one with the gain wave, one with the post wave
-
 typedef float tm_v2f __attribute__((ext_vector_type(2)));
 
 // Four consecutive samples of one stream through the gain recurrence + squelch (bit for bit agc_tail_step x 4).  WANT_Y: also the
@@ -463,6 +229,292 @@ __device__ __forceinline__ void agc_gain_quad(const float4 va, const float4 vb, 
         q.mode = (int32_t)S;
     }
 }
+
+// One lane per (channel, segment) stream; a workgroup is 64 consecutive segments of ONE channel (grid = channels x
+// segment groups, so every address is the uniform row plus a lane-derived segment) -- or, when a row has fewer than 33
+// segments (many channels, short calls: 4096 channels x the reference's 4096-frame chunk is 11 segments of 384), spw = 8,
+// 16 or 32 segments of 64 / spw neighbouring channels each, so that the lanes are not left idle (round 5: such calls ran
+// one 11-lane workgroup per channel, four rounds of workgroups deep) -- served by TWO waves:
+//   * the worker (wave 0) runs the recurrence: block k of 16 samples per stream comes out of an LDS ring slot one line
+//     per lane, four samples at a time, and the outputs go back over the stream's own consumed input pieces;
+//   * the mover (wave 1) does everything that waits for memory: while block k is worked on it writes block k + 1
+//     (fetched during the previous iteration, 8 lanes per 128-byte line) into the next ring slot, issues the loads of
+//     block k + 2 and stores the outputs of block k - 1 as whole lines.
+// One LDS-only barrier per block (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() would drain the loads in
+// flight).  With a single wave doing load -> LDS -> arithmetic -> LDS -> store one after the other nothing overlapped:
+// at the segment lengths that keep the warm-up re-reads low there are too few streams for the other waves of a SIMD
+// to cover for it (0.44 ms per 67 M samples however the arithmetic was trimmed; data path alone 0.36, arithmetic
+// alone 0.33).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool FM, bool PAIRS>
+__global__ __launch_bounds__(128, 2) void k_agc_spec(TailArgs A, uint32_t groups, uint32_t ls)   // <= 256 VGPRs
+{
+    __shared__ float4 ring[3][64 * 8];
+    const int lane = threadIdx.x & 63;
+    const bool mover = threadIdx.x >= 64;                       // wave-uniform
+    // stream j of the workgroup: channel c + (j >> ls), segment sbase + (j & (spw - 1)); ls = 6: 64 segments of one channel
+    const uint32_t spw = 1u << ls, cpw = 64u >> ls;
+    const uint32_t c = (blockIdx.x / groups) * cpw, sbase = (blockIdx.x % groups) * spw;   // uniform: first channel, first segment
+    const size_t row = (size_t)c * A.nf;
+    const uint32_t nblk = (A.W + A.L) / 16u, kreal = A.W / 16u;
+    const int pc = lane & 7;
+    auto seg_of = [&](uint32_t j) { return sbase + (j & (spw - 1u)); };
+    auto chr_of = [&](uint32_t j) { return j >> ls; };          // channel of stream j, relative to c
+
+    // block k: instruction m of the cooperative access handles stream 8m + (lane >> 3).  Branch-free (clamped
+    // address) so that the eight loads are in flight together: with a branch per load the compiler waits for each one
+    // before the next and the block pays eight memory latencies in a row.  The halves that lie outside the stream are
+    // zeroed by mask_block when the block goes into the ring, two iterations later: masking here made the mover wait for
+    // the loads it had just issued -- a full memory round trip per block on the groups that start inside the first W
+    // samples of a row, which is EVERY block of a quarter of the workgroups at the reference's chunk size (round 5,
+    // TM_TRACE: 3200 of the mover's 4800 cycles per block, the worker waiting for it 40 % of the time).
+    const size_t total = (size_t)A.C * A.nf;
+    auto load_block = [&](uint32_t k, float4 (&ld)[8]) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const uint32_t jj = 8 * m + (lane >> 3), ss = seg_of(jj);
+            const int32_t t = (int32_t)(ss * A.L) - (int32_t)A.W + (int32_t)(16 * k) + 2 * pc;   // first of the piece's two samples
+            const size_t idx = (size_t)min(c + chr_of(jj), A.C - 1u) * A.nf + (uint32_t)max(t, 0);
+            if (PAIRS) ld[m] = *reinterpret_cast<const float4 *>(A.Z + min(idx, total - 2));
+            else { const float2 a = A.Z[min(idx, total - 1)], b = A.Z[min(idx + 1, total - 1)]; ld[m] = make_float4(a.x, a.y, b.x, b.y); }
+        }
+    };
+    auto mask_block = [&](uint32_t k, float4 (&ld)[8]) {
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const uint32_t jj = 8 * m + (lane >> 3), ss = seg_of(jj);
+            const int32_t t = (int32_t)(ss * A.L) - (int32_t)A.W + (int32_t)(16 * k) + 2 * pc;
+            const uint32_t e = min(A.nf, ss * A.L + A.L);
+            const bool there = ss < A.nseg && c + chr_of(jj) < A.C;
+            const bool ok0 = there && t >= 0 && (uint32_t)t < e, ok1 = there && t >= 0 && (uint32_t)t + 1 < e;
+            const float4 v = ld[m];
+            ld[m] = make_float4(ok0 ? v.x : 0.f, ok0 ? v.y : 0.f, ok1 ? v.z : 0.f, ok1 ? v.w : 0.f);
+        }
+    };
+
+    // Interior blocks -- all 64 streams of the group exist and the block lies inside every stream's range (all but the
+    // first W samples of a row and its ragged end) -- need no range tests at all: one uniform base pointer and a
+    // 32-bit lane offset per piece.  The general path's clamps, masks and 64-bit addresses cost as many VALU
+    // instructions per block as sixteen warm-up steps.
+    const bool group_full = PAIRS && sbase + spw <= A.nseg && c + cpw <= A.C;
+    const int64_t t_first = (int64_t)sbase * A.L - (int64_t)A.W;                    // the first segment's sample at k = 0
+    const int64_t t_lastend = (int64_t)(sbase + spw - 1u) * A.L - (int64_t)A.W + 15;    // the last segment's last sample at k = 0
+    const char *wbase = reinterpret_cast<const char *>(A.Z + row) + t_first * 8;    // uniform; dereferenced on interior blocks only
+    // bytes from the workgroup's first sample to my piece of stream 8m + (lane >> 3) (mover only; the launcher keeps cpw rows inside 32 bits)
+    uint32_t voff[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < 8 && mover; m++) {
+        const uint32_t jj = 8 * m + (lane >> 3);
+        voff[m] = (chr_of(jj) * A.nf + (jj & (spw - 1u)) * A.L + 2u * (uint32_t)pc) * 8u;
+    }
+    auto is_inner = [&](uint32_t k) { return group_full && t_first + 16 * (int64_t)k >= 0 && t_lastend + 16 * (int64_t)k < (int64_t)A.nf; };
+    // block k's eight pieces -> registers (not waited for here on interior blocks: nothing touches the data)
+    auto fetch = [&](uint32_t k, float4 (&ld)[8]) {
+        if (is_inner(k)) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) ld[m] = *reinterpret_cast<const float4 *>(wbase + (voff[m] + 128u * ((CSDR_AGC_ABLATE & 2) ? (k >= kreal ? kreal : 0u) : k)));
+        } else load_block(k, ld);
+    };
+
+    // outputs of block k (>= kreal) leave as whole lines
+    auto store_block = [&](uint32_t k, const float4 *buf) {
+        if ((CSDR_AGC_ABLATE & 4) && A.nf != 0xffffffffu) return;
+        const uint32_t tb = 16 * (k - kreal);
+        if (is_inner(k) && (!FM || ((row & 3) == 0 && (cpw == 1u || (A.nf & 3u) == 0)))) {
+            // interior block, 16-byte aligned rows: the same uniform-base addressing as the loads
+            if (FM) {
+                char *obase = reinterpret_cast<char *>((float *)A.out + row + (size_t)sbase * A.L + tb);
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const uint32_t jj = 16 * m + (lane >> 2);
+                    const uint32_t off = (chr_of(jj) * A.nf + (jj & (spw - 1u)) * A.L + 4u * (uint32_t)(lane & 3)) * 4u;
+                    *reinterpret_cast<float4 *>(obase + off) = buf[slot8((int)jj, lane & 3)];
+                }
+            } else {
+                char *obase = reinterpret_cast<char *>((float2 *)A.out + row + (size_t)sbase * A.L + tb);
+#pragma unroll
+                for (int m = 0; m < 8; m++)
+                    *reinterpret_cast<float4 *>(obase + voff[m]) = buf[slot8(8 * m + (lane >> 3), pc)];
+            }
+            return;
+        }
+        if (FM) {
+            float *outp = (float *)A.out;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int j = 16 * m + (lane >> 2), p4 = lane & 3;
+                const uint32_t ss = seg_of((uint32_t)j), cc = c + chr_of((uint32_t)j);
+                if (ss < A.nseg && cc < A.C) {
+                    const uint32_t t = ss * A.L + tb + 4 * p4, e = min(A.nf, ss * A.L + A.L);
+                    const float4 v = buf[slot8(j, p4)];
+                    const size_t idx = (size_t)cc * A.nf + t;
+                    float *dst = outp + idx;
+                    if (t + 4 <= e && (idx & 3) == 0) *reinterpret_cast<float4 *>(dst) = v;
+                    else {
+                        if (t < e) dst[0] = v.x;
+                        if (t + 1 < e) dst[1] = v.y;
+                        if (t + 2 < e) dst[2] = v.z;
+                        if (t + 3 < e) dst[3] = v.w;
+                    }
+                }
+            }
+        } else {
+            float2 *outp = (float2 *)A.out;
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const uint32_t jj = 8 * m + (lane >> 3), ss = seg_of(jj), cc = c + chr_of(jj);
+                if (ss < A.nseg && cc < A.C) {
+                    const uint32_t t = ss * A.L + tb + 2 * pc, e = min(A.nf, ss * A.L + A.L);
+                    const float4 v = buf[slot8(8 * m + (lane >> 3), pc)];
+                    const size_t idx = (size_t)cc * A.nf + t;
+                    float2 *dst = outp + idx;
+                    if (t + 2 <= e && (idx & 1) == 0) *reinterpret_cast<float4 *>(dst) = v;
+                    else {
+                        if (t < e) dst[0] = make_float2(v.x, v.y);
+                        if (t + 1 < e) dst[1] = make_float2(v.z, v.w);
+                    }
+                }
+            }
+        }
+    };
+
+    // the worker's stream
+    const uint32_t sg = seg_of((uint32_t)lane), cw = min(c + chr_of((uint32_t)lane), A.C - 1u);     // the worker's segment and channel
+    const bool mine = sg < A.nseg && c + chr_of((uint32_t)lane) < A.C;
+    const uint32_t endv = mine ? min(A.nf, sg * A.L + A.L) : 0u;
+    AgcSeg q;
+    {
+        // segments that begin <= W samples into the call run from sample 0 and from the TRUE state; the others warm up from st_spec
+        const AgcState s0 = ((uint64_t)sg * A.L > A.W) ? A.st_spec[cw] : A.st_in[cw];
+        q.g = s0.g; q.y2 = s0.y2; q.mode = (int32_t)s_encode(s0.mode, s0.timer); q.timer = 0;
+        const float2 r0 = FM ? A.rp_in[cw] : make_float2(0.f, 0.f);
+        q.rx = r0.x; q.ry = r0.y; q.pad0 = q.pad1 = 0;
+    }
+    auto work_block = [&](uint32_t k, float4 *buf) {
+        const int32_t t0 = (int32_t)(sg * A.L) - (int32_t)A.W + (int32_t)(16 * k);
+        if (mine && k == kreal) A.seg_start[(size_t)cw * A.nseg + sg] = q;      // state at the segment start, after the warm-up
+        const bool inner = is_inner(k);
+        const bool live = inner || (t0 >= 0 && (uint32_t)t0 < endv);
+        const bool full = inner || !live || (uint32_t)t0 + 16 <= endv;
+        if ((CSDR_AGC_ABLATE & 16)) return;
+        if (k < kreal) {
+            // warm-up block (always whole): only the state matters -- no freqdem, nothing stored
+            if (live && k + 1 < kreal) {
+                // (round 5) the whole block out of the ring at once and the state-only quad of the tile-major kernel: the four LDS round trips of
+                // the loop below and its unpacked arithmetic were a third of a warm-up block, and a call of the reference's chunk size is all warm-up
+                float4 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] = buf[slot8(lane, i)];
+#pragma unroll
+                for (int h = 0; h < 4; h++) { float2 y[4]; agc_gain_quad<false>(v[2 * h], v[2 * h + 1], q, A.p, y); }
+            } else if (live) {
+                // the last warm-up block also leaves r', the (possibly muted) AGC output in front of the segment
+#pragma unroll 1
+                for (int h = 0; h < 4; h++) {
+                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
+                    float4 oa, ob;
+                    agc_quad<false, false>(va, vb, q, A.p, A.ref, 0u, 0u, oa, ob);
+                    if (FM) { q.rx = ob.z; q.ry = ob.w; }       // r' = the last (possibly muted) AGC output
+                }
+            }
+        } else if (__builtin_amdgcn_ballot_w64(!full) == 0ull) {
+            if (live) {
+#pragma unroll 1
+                for (int h = 0; h < 4; h++) {
+                    const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
+                    float4 oa, ob;
+                    agc_quad<FM, false>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, endv, oa, ob);
+                    // in place: output piece h (F32) / pieces 2h, 2h+1 (CF32) over input pieces already consumed
+                    if (FM) buf[slot8(lane, h)] = oa;
+                    else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
+                }
+            }
+        } else if (live) {
+#pragma unroll 1
+            for (int h = 0; h < 4; h++) {
+                const float4 va = buf[slot8(lane, 2 * h)], vb = buf[slot8(lane, 2 * h + 1)];
+                float4 oa, ob;
+                agc_quad<FM, true>(va, vb, q, A.p, A.ref, (uint32_t)t0 + 4 * h, endv, oa, ob);
+                if (FM) buf[slot8(lane, h)] = oa;
+                else { buf[slot8(lane, 2 * h)] = oa; buf[slot8(lane, 2 * h + 1)] = ob; }
+            }
+        }
+    };
+
+    // iteration `it`: the mover fills slot it % 3 with block it and empties slot (it - 2) % 3, the worker is on
+    // block it - 1 in slot (it - 1) % 3.  The mover keeps TWO blocks in flight (it + 1 and it + 2, two register sets
+    // used alternately -- hence the loop runs in pairs): with one, an iteration lasted a memory round trip.
+    float4 lda[8], ldb[8];
+    uint32_t s_in = 0, s_wk = 2, s_out = 1;                     // it % 3, (it - 1) % 3, (it - 2) % 3
+    if (mover) { fetch(0, lda); if (1 < nblk) fetch(1, ldb); }
+    [[maybe_unused]] unsigned long long r_bar = 0, r_a = 0, r_b = 0, r_c = 0, r_t0 = TM_TRACE ? __builtin_amdgcn_s_memtime() : 0ull, r_t = 0;
+#define RM_STAMP(acc) do { if (TM_TRACE) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - r_t; r_t = n_; } } while (0)
+    auto iteration = [&](uint32_t it, float4 (&ld)[8]) {       // ld holds block it (mover)
+        if (TM_TRACE) r_t = __builtin_amdgcn_s_memtime();
+        if (mover) {
+            if (it < nblk) {
+                if (CSDR_AGC_ABLATE & 32) {
+#pragma unroll
+                    for (int m = 0; m < 8; m++) { const float t0 = ld[m].x, t1 = ld[m].w; asm volatile("" :: "v"(t0), "v"(t1)); }
+                } else {
+                    if (!is_inner(it)) mask_block(it, ld);
+#pragma unroll
+                    for (int m = 0; m < 8; m++) ring[s_in][slot8(8 * m + (lane >> 3), pc)] = ld[m];
+                }
+                if (TM_TRACE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RM_STAMP(r_a);                                  // mover: wait for block it + ring writes
+                if (it + 2 < nblk) fetch(it + 2, ld);
+                RM_STAMP(r_b);                                  // mover: issue of the loads of block it + 2
+            }
+            if (it >= 2 && it - 2 >= kreal && it - 2 < nblk) store_block(it - 2, ring[s_out]);
+            RM_STAMP(r_c);                                      // mover: stores
+        } else if (it >= 1 && it - 1 < nblk) { work_block(it - 1, ring[s_wk]); if (TM_TRACE) asm volatile("" :: "v"(q.g), "v"(q.y2)); RM_STAMP(r_a); }
+        if (!(CSDR_AGC_ABLATE & 64)) lds_barrier();
+        RM_STAMP(r_bar);
+        s_out = s_wk; s_wk = s_in; s_in = s_in == 2 ? 0 : s_in + 1;
+    };
+    for (uint32_t it = 0; it < nblk + 2; it += 2) {
+        iteration(it, lda);
+        iteration(it + 1, ldb);                                 // it + 1 may be nblk + 2: nothing left to do but the barrier
+    }
+#if TM_TRACE
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1))
+        printf("rm trace wg %u %s: total %llu cycles over %u blocks (%u warm-up), barrier %llu, %s %llu, load issue %llu, stores %llu\n", blockIdx.x, mover ? "mover" : "worker",
+               (unsigned long long)(__builtin_amdgcn_s_memtime() - r_t0), nblk, kreal, r_bar, mover ? "wait for the block + ring writes" : "work", r_a, r_b, r_c);
+#endif
+    if (!mover && mine) A.seg_end[(size_t)cw * A.nseg + sg] = q;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_agc_spec_tm (round 4): the same speculation on a TILE-MAJOR channelizer plane.
+//
+// k_agc_spec's 64 streams are 64 segments of one channel: every block iteration fetches 64 lines that lie a segment (8 KiB)
+// apart, one DRAM page each (4.1 TB/s however many were in flight), through registers, and the worker wave pays ~33
+// instructions per sample for the freqdem with VCC selects.  Here the fused run kernels write the CF32 plane tile-major -- block
+// B of 16 frames holds the 128-byte lines of all C channels back to back, i.e. a tile's whole output is ONE contiguous 32 KiB --
+// and a workgroup's 64 streams are 64 CHANNELS at the same segment: every lane is at the same time position, block kk of the
+// workgroup is one contiguous 8 KiB, and nothing in the kernel depends on the lane any more except the state.
+//   * mover wave: eight global_load_lds_dwordx4 per block (HBM -> LDS ring without registers, XOR swizzle on the source address as
+//     in k_run256v2), TM_DEPTH blocks ahead; its vmcnt queue holds the DMA plus a few state records (the seg_start record at the end of the warm-up and a
+//     checkpoint every TM_CK samples are global stores inside the loop, and stores count in vmcnt on gfx9), so `s_waitcnt vmcnt(8 n)` can only
+//     wait for MORE than the n youngest blocks: always safe, exact in the iterations without such a store (ADVICE r04);
+//   * worker wave: the recurrence out of the ring, freqdem as fm_quad_rn (packed, SGPR-mask selects, bit-identical to
+//     fm_sample_rn), and the outputs straight from its registers as 64-byte (F32) / 128-byte (CF32) row pieces -- nothing goes back
+//     through the ring;
+//   * one LDS-only barrier per block.
+// Channels per workgroup Cw = min(C, 64); for C < 64 (interleaved shards of eight) a workgroup takes 64 / C segments.
+// Same records, same verification (k_agc_fix), same bits as k_agc_spec.
+#ifndef TM_DEPTH_N
+#define TM_DEPTH_N 3
+#endif
+constexpr int TM_DEPTH = TM_DEPTH_N;        // blocks in flight
+static_assert(TM_DEPTH >= 1 && TM_DEPTH <= 6, "vmcnt immediates above");
+constexpr int TM_SLOTS = TM_DEPTH + 2;      // ring slots of 8 KiB: TM_DEPTH in flight, one with the gain wave, one with the post wave
 
 // Gain wave (wave 0): tile DMA TM_DEPTH blocks ahead, the recurrence out of the ring, y back in place (blocks >= kreal - 1).
 // Post wave (wave 1): block it - 1's y -> freqdem (FM: fm_quad_rn) -> row pieces straight to HBM; its vmcnt queue holds stores only.
@@ -521,8 +573,11 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
                 }
             }
         };
+        [[maybe_unused]] unsigned long long p_bar = 0, p_lds = 0, p_fm = 0, p_st = 0, p_t0 = TM_TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
         for (uint32_t it = 0; it <= nblk; it++) {
+            const unsigned long long pb0 = TM_TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
             lds_barrier();                                      // block it - 1's y is in its slot; the gain wave is on block it
+            if (TM_TRACE) p_bar += __builtin_amdgcn_s_memtime() - pb0;
             if (it == 0) continue;
             const uint32_t k = it - 1;
             if (k + 1 < kreal) continue;                        // warm-up blocks leave nothing here, except the last one: r' of the segment
@@ -531,10 +586,12 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
             if (k < kreal) { if (FM && lv) { const float4 v7 = buf[slot8(lane, 7)]; rp = make_float2(v7.z, v7.w); } continue; }
             if (!FM) { coop_store(buf, k, false); continue; }
             float4 mq[4];
+            [[maybe_unused]] unsigned long long pq = TM_TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
             if (lv) {
                 float4 v[8];
 #pragma unroll
                 for (int pc = 0; pc < 8; pc++) v[pc] = buf[slot8(lane, pc)];
+                if (TM_TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); p_lds += n_ - pq; pq = n_; }
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
                     const float2 y[4] = {make_float2(v[2 * h].x, v[2 * h].y), make_float2(v[2 * h].z, v[2 * h].w),
@@ -550,6 +607,7 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
 #pragma unroll
                 for (int h = 0; h < 4; h++) mq[h] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (TM_TRACE) { asm volatile("" :: "v"(mq[0].x), "v"(mq[3].w)); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); p_fm += n_ - pq; pq = n_; }
             const bool odd = ((k - kreal) & 1u) != 0u;
             if (!odd) {
 #pragma unroll
@@ -569,8 +627,14 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
                 coop_store(buf, k - 1, true);
                 held = false;
             }
+            if (TM_TRACE) p_st += __builtin_amdgcn_s_memtime() - pq;
         }
         (void)held;
+#if TM_TRACE
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1))
+            printf("tm trace wg %u post: total %llu cycles over %u blocks (%u warm-up), at the barrier %llu, ring reads %llu, freqdem %llu, ring writes + row stores %llu\n", blockIdx.x,
+                   (unsigned long long)(__builtin_amdgcn_s_memtime() - p_t0), nblk, kreal, p_bar, p_lds, p_fm, p_st);
+#endif
         return;
     }
 
@@ -612,8 +676,14 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
         q.rx = r0.x; q.ry = r0.y; q.pad0 = q.pad1 = 0;
     }
     for (uint32_t d = 0; d < (uint32_t)TM_DEPTH && d < nblk; d++) dma(d);
+    [[maybe_unused]] unsigned long long g_vm = 0, g_bar = 0, g_dma = 0, g_lds = 0, g_cmp = 0, g_cwu = 0, g_wu = 0, g_t0 = TM_TRACE ? __builtin_amdgcn_s_memtime() : 0ull, g_t;
+#define TM_STAMP(acc) do { if (TM_TRACE) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - g_t; g_t = n_; } } while (0)
     for (uint32_t it = 0; it <= nblk; it++) {
+        if (TM_TRACE) { g_t = __builtin_amdgcn_s_memtime(); if (it == kreal) g_wu = g_t - g_t0; }
         if (it < nblk) {
+            // (Round 5 tried a third wave that owns the DMA and its wait -- they cost this wave 725 of its ~3200 cycles per warm-up block, TM_TRACE --
+            // and found that the blocks then simply arrive later: 16 MiB in flight at the ~4 TB/s this read + scattered-write mix reaches IS
+            // the ~4 us a block takes to land.  The kernel is bound by its bytes, not by who issues them: 528 against 510 us per step, not kept.)
             // block `it` has landed once at most min(TM_DEPTH - 1, nblk - 1 - it) younger blocks (8 instructions each) are in flight:
             // this wave's vmcnt queue holds the DMA and nothing else (the state records below are stored after the loop)
             const uint32_t younger = min((uint32_t)TM_DEPTH - 1u, nblk - 1u - it);
@@ -624,9 +694,12 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
             else if (younger == 1u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        TM_STAMP(g_vm);
         lds_barrier();                                          // the post wave has left block it - 2's slot, and takes block it - 1's y
+        TM_STAMP(g_bar);
         if (it >= nblk) break;
         if (it + TM_DEPTH < nblk) dma(it + TM_DEPTH);           // into the slot block it - 2 had
+        TM_STAMP(g_dma);
         if (it == kreal) {
             // state at the segment start, after the warm-up: kept in registers until the loop is over (a store here would sit in the
             // vmcnt queue in front of the DMA counts above)
@@ -636,9 +709,11 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
         float4 v[8];
 #pragma unroll
         for (int pc = 0; pc < 8; pc++) v[pc] = buf[slot8(lane, pc)];
+        if (TM_TRACE) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); TM_STAMP(g_lds); }
         if (it + 1 < kreal) {
 #pragma unroll
             for (int h = 0; h < 4; h++) { float2 y[4]; agc_gain_quad<false>(v[2 * h], v[2 * h + 1], q, A.p, y); }
+            if (TM_TRACE) { asm volatile("" :: "v"(q.g), "v"(q.y2)); TM_STAMP(g_cwu); }
         } else {
             if (it == kreal) A.seg_start[(size_t)ch * A.nseg + sg] = q;     // (one 32-byte store per stream and launch)
 #pragma unroll
@@ -653,8 +728,14 @@ __global__ __launch_bounds__(128, 2) void k_agc_spec_tm(TailArgs A, uint32_t ncg
             // bit for bit, everything behind it is already what the sequential recurrence produces
             const uint32_t done = 16u * (it - kreal + 1u);
             if (it >= kreal && done % TM_CK == 0u && done < A.L) A.ckpt[((size_t)ch * A.nseg + sg) * A.nck + (done / TM_CK - 1u)] = q;
+            if (TM_TRACE) { asm volatile("" :: "v"(q.g), "v"(q.y2)); TM_STAMP(g_cmp); }
         }
     }
+#if TM_TRACE
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1))
+        printf("tm trace wg %u gain: total %llu cycles over %u blocks (warm-up %u blocks: %llu), vmcnt wait %llu, barrier %llu, dma issue %llu, lds reads %llu, recurrence of the warm-up blocks %llu, recurrence + y + ring writes of the others %llu\n",
+               blockIdx.x, (unsigned long long)(__builtin_amdgcn_s_memtime() - g_t0), nblk, kreal, g_wu, g_vm, g_bar, g_dma, g_lds, g_cwu, g_cmp);
+#endif
     if (mine) A.seg_end[(size_t)ch * A.nseg + sg] = q;
 }
 
@@ -814,8 +895,9 @@ struct AgcTailPlan {
     AgcSeg *d_start = nullptr, *d_end = nullptr, *d_ckpt = nullptr;
     size_t ckpt_cap = 0;
     AgcState *d_st_tmp = nullptr;    // [C] settled state of the pilot (first call of a stream)
-    bool fresh = true;               // the AGC state is the create-time one: the next call runs the pilot
+    bool fresh = true;               // the AGC state is still inside its create-time transient: the next call runs the pilot
     uint32_t pilot_n = 4096;
+    uint64_t seen = 0;               // samples per channel since create / reset
     unsigned *d_stats = nullptr;
     uint32_t wg_slots = 1024;            // workgroups the device holds at once
 };
@@ -861,7 +943,7 @@ void agc_tail_destroy(AgcTailPlan *p)
     delete p;
 }
 
-void agc_tail_reset(AgcTailPlan *p) { if (p) p->fresh = true; }
+void agc_tail_reset(AgcTailPlan *p) { if (p) { p->fresh = true; p->seen = 0; } }
 uint32_t agc_tail_tm_calls(const AgcTailPlan *p) { return p ? p->tm_calls : 0u; }
 
 int agc_tail_stats(AgcTailPlan *p, unsigned *checked, unsigned *redone)
@@ -912,8 +994,9 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     if (tm && L < p->Lmin) L = p->Lmin;                          // (CSDR_AGC_L_TM below the plan's bounds: the checkpoint table is sized for L >= Lmin)
     if (tm && (L % 32u)) L = (L + 31u) / 32u * 32u;
     if (!L) {
-        const uint32_t gmax = p->wg_slots / p->C ? p->wg_slots / p->C : 1u;
-        const uint64_t nseg_t = 64ull * gmax;
+        // as many segments per row as the device has lanes for (the kernel packs the segments of several channels into a workgroup when
+        // a row has few)
+        const uint64_t nseg_t = 64ull * p->wg_slots / p->C ? 64ull * p->wg_slots / p->C : 1ull;
         L = (uint32_t)((nf + nseg_t - 1) / nseg_t);
         L = (L + 15u) / 16u * 16u;
         // Lmin bounds the warm-up re-reads ((W + L) / L times the plane) of a bandwidth-bound call.  A call whose whole plane sits in the
@@ -937,23 +1020,30 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
         hipLaunchKernelGGL(k_agc_pilot, dim3((p->C + 63u) / 64u), dim3(64), 0, s, A, n, p->d_st_tmp);
         A.st_spec = p->d_st_tmp;
     }
-    if (nf >= p->pilot_n) p->fresh = false;      // (a stream that starts with short calls keeps piloting: each is cheap)
+    // the create-time transient is over once the stream has seen pilot_n samples, however many calls that took (round 5: a stream of
+    // 1024- or 2048-frame calls used to pilot for ever -- one serial lane per channel over the whole call, 180 / 267 us per call)
+    p->seen += nf;
+    if (p->seen >= p->pilot_n) p->fresh = false;
     // PAIRS: nf even, so every row starts on a 16-byte boundary and ends on one (t is always even): a piece is one
     // 16-byte load that never reaches past the buffer
     const bool pairs = (nf & 1u) == 0 && (uint64_t)p->C * nf >= 2;
-    const uint32_t groups = (nseg + 63u) / 64u;
-    const dim3 grid(p->C * groups), block(128);
+    // row-major kernel: spw segments x cpw channels per workgroup (cpw > 1 needs whole-piece rows and 32-bit offsets inside its rows)
+    uint32_t ls = 6;
+    if (nseg <= 32u && pairs && (nf & 3u) == 0 && p->C >= 8u && (uint64_t)nf * 64ull < (1ull << 32)) { ls = 3; while ((1u << ls) < nseg) ls++; }
+    const uint32_t spw = 1u << ls, cpw = 64u >> ls;
+    const uint32_t groups = (nseg + spw - 1u) / spw;
+    const dim3 grid(((p->C + cpw - 1u) / cpw) * groups), block(128);
     if (tm) {
         p->tm_calls++;
         const dim3 gtm(ncg * ((nseg + nsub - 1) / nsub)), btm(128);
         if (fm) hipLaunchKernelGGL((k_agc_spec_tm<true>), gtm, btm, 0, s, A, ncg, Cw, nsub);
         else hipLaunchKernelGGL((k_agc_spec_tm<false>), gtm, btm, 0, s, A, ncg, Cw, nsub);
     } else if (pairs) {
-        if (fm) hipLaunchKernelGGL((k_agc_spec<true, true>), grid, block, 0, s, A, groups);
-        else hipLaunchKernelGGL((k_agc_spec<false, true>), grid, block, 0, s, A, groups);
+        if (fm) hipLaunchKernelGGL((k_agc_spec<true, true>), grid, block, 0, s, A, groups, ls);
+        else hipLaunchKernelGGL((k_agc_spec<false, true>), grid, block, 0, s, A, groups, ls);
     } else {
-        if (fm) hipLaunchKernelGGL((k_agc_spec<true, false>), grid, block, 0, s, A, groups);
-        else hipLaunchKernelGGL((k_agc_spec<false, false>), grid, block, 0, s, A, groups);
+        if (fm) hipLaunchKernelGGL((k_agc_spec<true, false>), grid, block, 0, s, A, groups, ls);
+        else hipLaunchKernelGGL((k_agc_spec<false, false>), grid, block, 0, s, A, groups, ls);
     }
     // the fix-up reads st_in through the segment records only, so st can be overwritten in place
     if (fm) hipLaunchKernelGGL(k_agc_fix<true>, dim3(p->C), dim3(256), 0, s, A, st, rp_out, p->d_stats);
