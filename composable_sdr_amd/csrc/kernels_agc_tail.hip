@@ -922,7 +922,7 @@ int agc_tail_create(uint32_t C, uint32_t max_nf, AgcTailPlan **out)
     }
     p->max_seg = (max_nf + 15u) / 16u + 1;                      // L >= 16
     const size_t n = (size_t)C * p->max_seg;
-    p->ckpt_cap = (size_t)C * ((size_t)max_nf / TM_CK + (size_t)max_nf / 384u + 64u);
+    p->ckpt_cap = (size_t)C * ((size_t)max_nf / 128u + 64u);    // >= nseg x ceil(L / TM_CK) for every L >= 128 of the tile-major route
     if (hipMalloc(&p->d_start, n * sizeof(AgcSeg)) != hipSuccess || hipMalloc(&p->d_end, n * sizeof(AgcSeg)) != hipSuccess ||
         hipMalloc(&p->d_ckpt, p->ckpt_cap * sizeof(AgcSeg)) != hipSuccess ||
         hipMalloc(&p->d_st_tmp, (size_t)C * sizeof(AgcState)) != hipSuccess || hipMalloc(&p->d_stats, 2 * sizeof(unsigned)) != hipSuccess) {
@@ -980,6 +980,10 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
     if (tm && !agc_tail_tm_supported(p, nf)) { set_error("agc tail: internal: tile-major plane for a call the tile-major kernel does not take"); return CSDR_ERR_INVALID; }
     const uint32_t Cw = p->C < 64u ? p->C : 64u, nsub = 64u / Cw, ncg = p->C / Cw;     // tile-major: channels per workgroup, segments per workgroup, channel groups
     uint32_t L = tm ? p->L_tm : p->L;
+    // tile-major route: the two-thirds rule below gives L >= 384 on its own once the plane passes ~128 MiB; below that the device is
+    // under-filled and the re-reads come out of the L2s / the MALL, so shorter segments pay (round 5, profiles/r05_call_size_sweeps.txt:
+    // 256 channels x 16 384 frames 153 -> 137 us, 1024 x 4096 151 -> 136 us with 128 against 384; nothing below 128)
+    const uint32_t lmin_tm = 128u;
     if (!L && tm) {
         // two thirds of the workgroups the device holds at once (ncg channel groups x nseg / nsub segment groups): measured optimum
         // between the warm-up re-reads ((W + L) / L times the plane, shorter segments) and the blocks a workgroup walks (longer ones);
@@ -988,10 +992,10 @@ int agc_tail_process(AgcTailPlan *p, const float2 *Z, void *out, bool fm, uint32
         if (nseg_t < 2) nseg_t = 2;
         L = (uint32_t)((nf + nseg_t - 1) / nseg_t);
         L = (L + 31u) / 32u * 32u;                               // F32 rows leave as whole 128-byte lines per block pair
-        if (L < p->Lmin) L = p->Lmin;
+        if (L < lmin_tm) L = lmin_tm;
         if (L > 8160u) L = 8160u;
     }
-    if (tm && L < p->Lmin) L = p->Lmin;                          // (CSDR_AGC_L_TM below the plan's bounds: the checkpoint table is sized for L >= Lmin)
+    if (tm && L < lmin_tm) L = lmin_tm;                          // (CSDR_AGC_L_TM below the plan's bounds: the checkpoint table is sized for L >= Lmin)
     if (tm && (L % 32u)) L = (L + 31u) / 32u * 32u;
     if (!L) {
         // as many segments per row as the device has lanes for (the kernel packs the segments of several channels into a workgroup when
