@@ -885,9 +885,17 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
         if (agc_on) {
             // d_A: channel-major CF32 from the channelizer; d_B: per-channel tail output in front of --mix
             // (the fused M = 256 plans may write it tile-major for k_agc_spec_tm, which reads up to a segment in front of / behind the plane)
-            h->a_guard = (h->fused || h->big) ? agc_tail_tm_guard(C) : 0;
+            // The guards (2 x 64 KiB per channel: 128 MiB at 1024 channels) exist only where a call can take that route: a time-parallel
+            // tail (not CSDR_FLAG_AGC_SEQUENTIAL), a channel count k_agc_spec_tm takes, calls of >= 4 W = 4096 frames
+            const bool tm_possible = (h->fused || h->big) && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL) && h->max_nf >= 4096u &&
+                                     (C % 64u == 0 || (C < 64u && 64u % C == 0));
+            h->a_guard = tm_possible ? agc_tail_tm_guard(C) : 0;
             if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf + 2 * h->a_guard))) return fail(r);
-            if (h->a_guard) CSDR_HIP_CLEAN(hipMemset(h->d_A, 0, sizeof(float2) * ((size_t)C * h->max_nf + 2 * h->a_guard)), csdr_chain_destroy(h));
+            if (h->a_guard) {
+                // only the guards need defined contents (the warm-ups of the first and last segments read them, masked by position)
+                CSDR_HIP_CLEAN(hipMemset(h->d_A, 0, sizeof(float2) * h->a_guard), csdr_chain_destroy(h));
+                CSDR_HIP_CLEAN(hipMemset(h->d_A + h->a_guard + (size_t)C * h->max_nf, 0, sizeof(float2) * h->a_guard), csdr_chain_destroy(h));
+            }
             if (cfg->mix && (r = dev_alloc(&h->d_B, (size_t)C * h->max_nf))) return fail(r);
         }
     } else {
@@ -1221,7 +1229,7 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         float2 *Z = (agc_on && (fm || mixo || h->agc_tail)) ? h->d_A + h->a_guard : (float2 *)d_out;
         FusedCall fcall{};
         // AGC tail behind the fused M = 256 / M = 1024 chains, run-sized calls of whole tiles: the plane between the two kernels is tile-major
-        const bool tm = agc_on && h->agc_tail && Z != (float2 *)d_out && agc_tail_tm_supported(h->agc_tail, nf) &&
+        const bool tm = agc_on && h->agc_tail && h->a_guard && Z != (float2 *)d_out && agc_tail_tm_supported(h->agc_tail, nf) &&
                         (h->fused ? fused_tile_major_ok(h->fused, nf) : (h->big && big_tile_major_ok(h->big, nf)));
         fcall.tile_major = tm;
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;

@@ -484,7 +484,7 @@ static uint32_t huge_runs(uint32_t nf, uint32_t cus)
 {
     uint32_t nruns = cus / 4;                           // 4 siblings per run, one 512-thread workgroup per CU
     if (const char *e = diag_env("CSDR_RUN4096_RUNS")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1) nruns = v; }
-    while (nruns > 1 && nf / nruns < 96) nruns >>= 1;
+    while (nruns > 1 && nf / nruns < 48) nruns >>= 1;    // (a run pays 20 cold-start frames: the reference chunk of 4096 frames is 64 runs of 64)
     if (nruns > 8) nruns &= ~7u;                        // the XCD-friendly workgroup -> (run, sibling) map wants a multiple of 8
     return nruns ? nruns : 1;
 }
