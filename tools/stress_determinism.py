@@ -18,7 +18,10 @@ side = torch.cuda.Stream()
 junk = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 bad = 0
 for M, nf, demod, agc in ((1024, 65536, "fm", 0.0), (1024, 65536, "none", 0.0), (1024, 4096, "fm", 0.0), (1024, 16384, "fm", 10.0), (256, 262144, "fm", 0.0),
-                          (256, 262144, "fm", 10.0), (256, 4096, "fm", 0.0), (64, 1048576, "none", 0.0), (64, 4096, "none", 0.0)):
+                          (256, 262144, "fm", 10.0), (256, 4096, "fm", 0.0), (64, 1048576, "none", 0.0), (64, 4096, "none", 0.0),
+                          # round 5: the fused 4096-channel route, the channel-packed row-major AGC tail, short AGC calls
+                          (4096, 16384, "none", 0.0), (4096, 16384, "fm", 0.0), (4096, 4096, "fm", 10.0), (256, 4096, "fm", 10.0), (256, 1024, "none", 10.0),
+                          (1024, 4096, "fm", 10.0)):
     xs = [synth_cf32_torch(M * nf, M, dev, seed=900 + i) for i in range(3)]
     width = 1 if demod == "fm" else 2
     oa = torch.empty(M * nf * width, dtype=torch.float32, device=dev); ob = torch.empty_like(oa)
