@@ -46,6 +46,8 @@ def parse():
                          "ownership k = rank (mod N) with a pruned DFT per rank (strong scaling; --mix adds one RCCL all-reduce per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agc-variant", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short side measurements of the other BASELINE shapes (\"other_configs\"; the default N = 1 run only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--preheat-ms", type=float, default=2500.0,
                     help="back-to-back steps in front of the W warm-up steps, for at least this long, with one synchronisation at the end: "
@@ -567,6 +569,52 @@ def main():
                                           "frac": round(nx * alg_bytes_per_sample / (d2 / reps) / 1e9 / HBM_PEAK_GBS, 4),
                                           "traffic": (ta + tb) if (ta and tb) else None}
         ch2.close()
+
+    if world == 1 and not a.no_other_configs and not a.no_agc_variant and a.agc == 0.0 and M == 256 and a.demod == "fm" and not a.mix and nf == 262144:
+        # The other BASELINE shapes, each for ~0.5 s on the same (hot) board and the same 67.1 M input samples per step, so that a driver-run line
+        # carries them too (verdict r04: "none of cfg2/cfg4/cfg5 figures is driver-run").  Whole-step figures (host clock around a back-to-back
+        # loop); the kernels behind them are profiled under profiles/rNN_*.  Not the headline: `value` above is.
+        out2 = torch.empty(nx * 2, dtype=torch.float32, device=dev)
+        others = []
+        def side(tag, workload, M2, nf2, demod2, agc2, mix2, bps):
+            try:
+                c2 = cs.Chain(channels=M2, demod=demod2, kf=a.kf, agc=agc2, mix=mix2, max_frames=nf2, device=local, flags=_lib.FLAG_QUIET)
+                n2 = M2 * nf2
+                for i in range(6):
+                    c2.process_device(xs[i & 1].data_ptr(), n2, out2.data_ptr(), stream)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                c2.process_device(xs[0].data_ptr(), n2, out2.data_ptr(), stream)
+                torch.cuda.synchronize()
+                one = max(time.perf_counter() - t1, 1e-5)
+                reps = max(5, int(0.5 / one))
+                t1 = time.perf_counter()
+                for i in range(reps):
+                    c2.process_device(xs[(i + 1) & 1].data_ptr(), n2, out2.data_ptr(), stream)
+                torch.cuda.synchronize()
+                d = (time.perf_counter() - t1) / reps
+                e = {"tag": tag, "workload": workload, "channels": M2, "frames_per_step": nf2, "demod": demod2, "agc_db": agc2, "mix": bool(mix2),
+                     "route": c2.path, "kernel": c2.kernel_time()[0], "steps": reps, "ms_per_step": round(d * 1e3, 4), "value": round(n2 / d / 1e6, 1), "unit": "MS/s",
+                     "alg_bytes_per_sample": bps}
+                if n2 * bps >= (64 << 20):
+                    e["hbm_roofline_frac_whole_step"] = round(n2 * bps / d / 1e9 / HBM_PEAK_GBS, 4)
+                c2.close()
+            except Exception as ex:        # a side measurement never takes the line down
+                e = {"tag": tag, "workload": workload, "error": str(ex)[:200]}
+            others.append(e)
+        side("cfg2", "64-ch PFB, DeNo (BASELINE configs[1] shape)", 64, 1048576, "none", 0.0, False, 16)
+        side("cfg3_deno", "256-ch PFB, DeNo", 256, 262144, "none", 0.0, False, 16)
+        side("cfg4_shape_1gpu", "1024-ch PFB + FM, all channels on one GPU (BASELINE configs[3] shape)", 1024, 65536, "fm", 0.0, False, 12)
+        side("m1024_deno", "1024-ch PFB, DeNo", 1024, 65536, "none", 0.0, False, 16)
+        side("cfg5_shape_1gpu", "4096-ch PFB, DeNo --mix over all channels = the mix identity (BASELINE configs[4] shape)", 4096, 16384, "none", 0.0, True, 8)
+        side("m4096_deno", "4096-ch PFB, per-channel DeNo (fused 4096 route)", 4096, 16384, "none", 0.0, False, 16)
+        side("m4096_fm", "4096-ch PFB + FM per channel (fused 4096 route)", 4096, 16384, "fm", 0.0, False, 12)
+        side("m4096_fm_mix", "4096-ch PFB + FM --mix (fused 4096 route)", 4096, 16384, "fm", 0.0, True, 8)
+        side("ref_chunk_m256_fm", "the reference's own chunk: 256 ch x 4096 frames per call, FM", 256, 4096, "fm", 0.0, False, 12)
+        side("ref_chunk_m256_fm_agc", "the reference's own chunk: 256 ch x 4096 frames per call, AGC (-a 10) + FM", 256, 4096, "fm", 10.0, False, 12)
+        side("ref_chunk_m4096_deno", "the reference's own chunk: 4096 ch x 4096 frames per call, DeNo", 4096, 4096, "none", 0.0, False, 16)
+        res["other_configs"] = others
+        del out2
 
     if world == 1 and not a.no_cpu_baseline:
         x_host = xs[0][: 4096 * M * 4].cpu().numpy().view(np.complex64).reshape(-1)

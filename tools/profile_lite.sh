@@ -8,7 +8,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 # keep only what tools/collect_profile.py reads (gpurun copies back at most 64 MiB)
 prune() { find $OUT -type f ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" ! -name "*.log" ! -name "args.txt" -delete; find $OUT -name "*.log" -size +200k -delete; }
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --preheat-ms 100 $*"
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-other-configs --preheat-ms 100 $*"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python3 bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "k_" -f csv -d $OUT/pmc3 -o p -- python3 bench.py $ARGS > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "k_" -f csv -d $OUT/pmc4 -o p -- python3 bench.py $ARGS > $OUT/pmc4.log 2>&1
