@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Per-phase timeline of the fused tile kernel (CSDR_TRACE=1): runs a few bench-sized steps and
-prints the median cycles between consecutive s_memtime stamps of thread 0, over all tiles."""
+prints the median cycles between consecutive s_memtime stamps of thread 0, over all tiles.
+Since round 5 the stamps are compiled out of the product kernel (they cost k_run256v2 the SGPRs its no-warm-up start needs): build the
+variant first and point CSDR_LIB at it --
+    tools/build_variant.sh trace kernels_fused_v2.hip -DV2_TRACE=1
+    CSDR_LIB=$PWD/composable_sdr_amd/variants/libcsdr_trace.so python tools/trace_tiles.py"""
 import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")   # tools are diagnostics: the library's A/B knobs are live here
 import os
 import sys
