@@ -848,6 +848,26 @@ def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
     assert r["config"]["path"].endswith("|" + r["roofline"]["kernel"])
 
 
+def test_bench_side_measurements_cannot_cost_the_line():
+    """The N > 1 side measurements (channel_shard / hybrid: the only data-path collectives of a default run, never run on N > 1 hardware)
+    sit behind the contract's numbers under a watchdog: with a limit they cannot meet the line is still printed -- without them, with
+    `side_error` -- and both ranks leave with status 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CSDR_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", CSDR_BENCH_SIDE_TIMEOUT="0.001")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29573", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "8192",
+           "--demod", "none", "--no-cpu-baseline", "--no-agc-variant", "--preheat-ms", "300"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["roofline"]["launches"] == 3 and r["sustained_long"]["value"] > 0
+    assert "did not finish" in r["side_error"] and "channel_shard" not in r and "hybrid" not in r
+
+
 def test_seek_frames_sets_premix_phase():
     M = 256
     x = synth_cf32(M * 80, M, seed=23)
