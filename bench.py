@@ -475,11 +475,18 @@ def main():
             sys.stdout.flush()
             os._exit(0)
 
+    finish_lock = threading.Lock()
+    finished = [False]
+
     def finish(from_watchdog=False):
         nonlocal chan2, hyb
-        if from_watchdog:
-            chan2, hyb = None, None
-        _finish(from_watchdog)
+        with finish_lock:                       # the line is printed once: by the main thread, or by the watchdog while the main thread is stuck
+            if finished[0]:
+                return
+            finished[0] = True
+            if from_watchdog:
+                chan2, hyb = None, None
+            _finish(from_watchdog)
 
     def _finish(no_collectives):
         if rank == 0:
