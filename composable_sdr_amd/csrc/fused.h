@@ -95,12 +95,19 @@ struct Run64v2Host {
     const float2 *x; float2 *out;
     const float *taps; const float2 *tw, *wpre;
     const float2 *uhist_in; float2 *uhist_out; const float2 *vend_in; float2 *vend_out;
+    // runs without warm-up windows (round 5, as k_run256v2: DESIGN 4.1e): cpre [nruns + 1] DC state in front of every run's halo tile,
+    // rt [2 parities][RUN64_DCFIX_F][4] the chain's response to a unit state at the channels 30..33; both null: warm-up windows
+    float2 *cpre = nullptr; const float2 *rt = nullptr;
     uint32_t nf, nruns, parity0;
     uint32_t G = 1, g = 0;      // interleaved shard g of G (tables rotated by the plan)
     bool dc_block;
     double beta;
 };
+constexpr int RUN64_DCFIX_F = 448;                      // output frames of a run the state correction covers (7 tiles: 32 768 samples behind the halo tile's start)
 uint32_t run64_v2_runs(uint32_t nf, uint32_t cus);      // 0: not a call for the kernel
+// Response of the chain (pre-mix table wpre [2][M], taps, forward DFT), at the channels k0 .. k0 + 3, to a DC-blocker state of 1 in
+// front of a tile: frames f0 .. f0 + nfr - 1 behind the tile's start, both parities of the tile's first frame; rt [2][nfr][4], f64 inside
+void dc_state_response(const FusedConfig &cfg, const float2 *wpre, uint32_t f0, uint32_t nfr, uint32_t k0, float2 *rt);
 int run64_v2_launch(const Run64v2Host &h, hipStream_t s, KernelTimer *timer);
 
 // k_run1024v2 (kernels_run1024_v2.hip): whole-band M = 1024 calls with nf % 4 == 0; same state buffers as k_run1024

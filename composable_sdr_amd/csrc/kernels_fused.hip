@@ -395,6 +395,43 @@ struct FusedPlan {
 
 bool fused_supported(uint32_t M, uint32_t p) { return M == 256 && p == P; }
 
+void dc_state_response(const FusedConfig &cfg, const float2 *wpre, uint32_t f0, uint32_t nfr, uint32_t k0, float2 *rt)
+{
+    // the blocker's output carries -alpha beta^n of the state at sample n behind the tile's start; that goes through the pre-mix, the
+    // polyphase FIR and the DFT like any input
+    const uint32_t M = cfg.M, T = f0 + nfr;
+    const double beta = (double)cfg.dc.beta, alpha = 1.0 - beta, tp = -2.0 * 3.14159265358979323846;
+    std::vector<double> ur((size_t)T * M), ui((size_t)T * M), xr(M), xi(M);
+    for (uint32_t par = 0; par < 2; par++) {
+        for (uint32_t f = 0; f < T; f++)
+            for (uint32_t j = 0; j < M; j++) {
+                const double e = -alpha * std::pow(beta, (double)f * M + j);
+                const float2 wv = wpre[((par + f) & 1u) * M + j];
+                ur[(size_t)f * M + j] = e * (double)wv.x; ui[(size_t)f * M + j] = e * (double)wv.y;
+            }
+        for (uint32_t t = 0; t < nfr; t++) {
+            const uint32_t f = f0 + t;
+            for (uint32_t j = 0; j < M; j++) {
+                double ar = 0.0, ai = 0.0;
+                for (uint32_t n = 0; n < cfg.p && n <= f; n++) {
+                    const double hh = (double)cfg.taps[(M - 1 - j) + n * M];
+                    ar += hh * ur[(size_t)(f - n) * M + j]; ai += hh * ui[(size_t)(f - n) * M + j];
+                }
+                xr[j] = ar; xi[j] = ai;
+            }
+            for (uint32_t ch = 0; ch < 4; ch++) {
+                const uint32_t k = k0 + ch;
+                double yr = 0.0, yi = 0.0;
+                for (uint32_t j = 0; j < M; j++) {
+                    const double a = tp * (double)((j * k) % M) / (double)M, cr = std::cos(a), ci = std::sin(a);
+                    yr += xr[j] * cr - xi[j] * ci; yi += xr[j] * ci + xi[j] * cr;
+                }
+                rt[((size_t)par * nfr + t) * 4 + ch] = make_float2((float)yr, (float)yi);
+            }
+        }
+    }
+}
+
 int fused_create(const FusedConfig &cfg, FusedPlan **out)
 {
     FusedPlan *p = new FusedPlan();
@@ -452,38 +489,8 @@ int fused_create(const FusedConfig &cfg, FusedPlan **out)
         // input.  Frames 15 .. 127 behind the tile's start = frame -1 .. 111 of the run that started its halo tile without its state;
         // by then the step's edge (13 frames of FIR, every channel) has left the filter and what remains sits around DC.  Both parities of
         // the tile's first frame; f64 throughout.
-        const uint32_t M = cfg.M, T = 15 + DCFIX_F;
-        const double beta = (double)cfg.dc.beta, alpha = 1.0 - beta, tp = -2.0 * 3.14159265358979323846;
         std::vector<float2> rt((size_t)2 * DCFIX_F * 4);
-        std::vector<double> ur((size_t)T * M), ui((size_t)T * M), xr(M), xi(M);
-        for (uint32_t par = 0; par < 2; par++) {
-            for (uint32_t f = 0; f < T; f++)
-                for (uint32_t j = 0; j < M; j++) {
-                    const double e = -alpha * std::pow(beta, (double)f * M + j);
-                    const float2 wv = wpre[((par + f) & 1u) * M + j];
-                    ur[(size_t)f * M + j] = e * (double)wv.x; ui[(size_t)f * M + j] = e * (double)wv.y;
-                }
-            for (uint32_t t = 0; t < (uint32_t)DCFIX_F; t++) {
-                const uint32_t f = 15 + t;
-                for (uint32_t j = 0; j < M; j++) {
-                    double ar = 0.0, ai = 0.0;
-                    for (uint32_t n = 0; n < cfg.p && n <= f; n++) {
-                        const double hh = (double)cfg.taps[(M - 1 - j) + n * M];
-                        ar += hh * ur[(size_t)(f - n) * M + j]; ai += hh * ui[(size_t)(f - n) * M + j];
-                    }
-                    xr[j] = ar; xi[j] = ai;
-                }
-                for (uint32_t ch = 0; ch < 4; ch++) {
-                    const uint32_t k = 126 + ch;
-                    double yr = 0.0, yi = 0.0;
-                    for (uint32_t j = 0; j < M; j++) {
-                        const double a = tp * (double)((j * k) % M) / (double)M, cr = std::cos(a), ci = std::sin(a);
-                        yr += xr[j] * cr - xi[j] * ci; yi += xr[j] * ci + xi[j] * cr;
-                    }
-                    rt[((size_t)par * DCFIX_F + t) * 4 + ch] = make_float2((float)yr, (float)yi);
-                }
-            }
-        }
+        dc_state_response(cfg, wpre.data(), 15u, (uint32_t)DCFIX_F, 126u, rt.data());
         CSDR_HIP(hipMemcpy(p->d_rt, rt.data(), sizeof(float2) * rt.size(), hipMemcpyHostToDevice));
     }
     CSDR_HIP(hipMemset(p->d_status, 0, sizeof(unsigned)));

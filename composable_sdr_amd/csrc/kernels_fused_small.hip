@@ -344,6 +344,7 @@ struct SmallPlan {
     float2 *d_tw = nullptr, *d_wpre = nullptr;
     float2 *d_yhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
     float2 *d_yfirst = nullptr, *d_ylast = nullptr;
+    float2 *d_cpre = nullptr, *d_rt = nullptr;      // k_run64v2 without warm-up windows (Run64v2Host::cpre / rt)
     void *d_premix = nullptr;
     int cur = 0;
     TileArgs proto;
@@ -355,7 +356,7 @@ void small_destroy(SmallPlan *p)
 {
     if (!p) return;
     void *ptrs[] = {p->d_taps, p->d_tw, p->d_wpre, p->d_yhist[0], p->d_yhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0],
-                    p->d_rp[1], p->d_yfirst, p->d_ylast, p->d_premix};
+                    p->d_rp[1], p->d_yfirst, p->d_ylast, p->d_premix, p->d_cpre, p->d_rt};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -414,6 +415,16 @@ int small_create(const FusedConfig &cfg, SmallPlan **out)
         p->cus = (uint32_t)cus;
         p->v2_ok = !cfg.fm && cfg.c0 == 0 && cfg.C == (uint32_t)MS && !diag_env("CSDR_RUN64_V1");
     }
+    if (p->v2_ok && cfg.dc_block && !(diag_env("CSDR_NOWU") && atoi(diag_env("CSDR_NOWU")) == 0)) {
+        // k_run64v2 without warm-up windows: the state hand-over array and the chain's response to a unit DC state at the channels 30..33,
+        // frames 64 .. 64 + RUN64_DCFIX_F - 1 behind a halo tile's start (= the run's first output frames)
+        hipError_t e1 = hipMalloc((void **)&p->d_cpre, sizeof(float2) * 1026), e2 = hipMalloc((void **)&p->d_rt, sizeof(float2) * 2 * RUN64_DCFIX_F * 4);
+        if (e1 != hipSuccess || e2 != hipSuccess) return fail(hip_fail(e1 != hipSuccess ? e1 : e2, "hipMalloc", __FILE__, __LINE__));
+        CSDR_HIP(hipMemset(p->d_cpre, 0, sizeof(float2) * 1026));
+        std::vector<float2> rt((size_t)2 * RUN64_DCFIX_F * 4);
+        dc_state_response(cfg, wpre.data(), 64u, (uint32_t)RUN64_DCFIX_F, 30u, rt.data());
+        CSDR_HIP(hipMemcpy(p->d_rt, rt.data(), sizeof(float2) * rt.size(), hipMemcpyHostToDevice));
+    }
     *out = p;
     return 0;
 }
@@ -446,6 +457,7 @@ int small_process(SmallPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         H.uhist_in = p->d_yhist[p->cur]; H.uhist_out = p->d_yhist[p->cur ^ 1];
         H.vend_in = p->d_vend[p->cur]; H.vend_out = p->d_vend[p->cur ^ 1];
         H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
+        H.cpre = v2runs <= 1024u ? p->d_cpre : nullptr; H.rt = p->d_rt;
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0;
         if ((r = run64_v2_launch(H, s, timer))) return r;
         p->cur ^= 1;

@@ -204,7 +204,6 @@ int launch_dc_mix(const float2 *x, float2 *y, uint32_t n, bool do_dc, const DcPa
 // One thread = one polyphase branch j x FIR_F consecutive frames: the p+FIR_F-1 window samples
 // are loaded once (coalesced along j) and slide through registers.
 constexpr int FIR_F = 8;
-constexpr int FIR_PMAX = 32;
 __global__ __launch_bounds__(256) void k_pfb_fir(const float2 *__restrict__ u, const float *__restrict__ taps,
                                                  float2 *__restrict__ X, uint32_t M, uint32_t p, uint32_t nf)
 {

@@ -1187,6 +1187,37 @@ def test_run64_v2_matches_first_generation_kernel_and_oracle(monkeypatch):
     a.close(); b.close()
 
 
+def test_run64_v2_without_warm_up_windows_matches_the_warm_up_build(monkeypatch):
+    """Round 5: k_run64v2's runs read no warm-up window either (as k_run256v2): a run starts its halo tile from DC state 0 and
+    k_run64_dcfix adds what the true state contributes to the channels 30..33 over the run's first 448 frames.  Against the same library
+    with the windows (CSDR_NOWU=0) on a strong DC offset, 16 + 14 runs in two calls (odd frame parity in the second through a 5-frame
+    call between them), every channel and the corrected ones on their own; against the oracle behind an f64 DC blocker."""
+    from scipy.signal import lfilter
+    M = 64
+    frames = [64 * 256, 5, 64 * 224]
+    x = synth_cf32(M * sum(frames), M, seed=164, dc=0.3 - 0.2j)
+    knob(monkeypatch, "CSDR_RUN64_V2_ALL", "1")
+    a = cs.Chain(channels=M, demod="none", max_frames=max(frames))
+    knob(monkeypatch, "CSDR_NOWU", "0")
+    b = cs.Chain(channels=M, demod="none", max_frames=max(frames))
+    monkeypatch.delenv("CSDR_NOWU")
+    beta = float(np.float32(1) - np.float32(0.0005))
+    yd = lfilter([1.0, -1.0], [1.0, -beta], x.astype(np.complex128)).astype(np.complex64)
+    orc = O.Chain(M, demod="none", dc_block=False)
+    pos, near = 0, slice(30, 34)
+    for nf in frames:
+        c = x[pos:pos + nf * M]
+        ga, gb, w = a.process(c), b.process(c), orc.process(yd[pos:pos + nf * M])
+        pos += nf * M
+        kn = a.kernel_time()[0]
+        e_all, e_near = rel_rms(ga, gb), rel_rms(ga[near], gb[near])
+        print(f"M=64 no-warm-up vs warm-up nf={nf} [{kn}]: all {e_all:.2e}, channels 30..33 {e_near:.2e}; vs oracle (f64 dc) {rel_rms(ga, w):.2e} (warm-up build {rel_rms(gb, w):.2e})")
+        assert kn == ("k_run64v2" if nf % 64 == 0 else "k_run64<CF32>")
+        assert e_all < 2e-6 and e_near < 2e-5
+        assert rel_rms(ga, w) < 1.2 * rel_rms(gb, w) + 1e-6 and max_abs_err(ga, w) < 1e-4 * np.abs(w).max()
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("M,demod,env,frames,extra", [
     (64, "none", "CSDR_RUN64_V1", [8192, 2048], {}),
     (64, "none", "CSDR_RUN64_V1", [8192], {"mix": True}),
