@@ -120,6 +120,10 @@ struct Run1024v2Host {
     uint32_t nf, nruns, parity0;
     uint32_t G = 1, g = 0;      // interleaved shard g of G (tables rotated by the plan)
     bool tile_major = false;    // k_run1024v3<CF32>: the lines of a 16-frame block back to back ([block][1024][128 B]) instead of row-major [1024][nf]
+    // k_run1024v3 without warm-up windows (round 5, as k_run256v2: DESIGN 4.1e): cpre [nruns + 1] DC state four tiles in front of every run's
+    // first tile, side [nruns][4][RUN1024_DCFIX_F] uncorrected Y of the channels 510..513 (FM), rt [2][RUN1024_DCFIX_F][4] the chain's
+    // response to a unit state there; null: warm-up windows
+    float2 *cpre = nullptr, *side = nullptr; const float2 *rt = nullptr;
     bool dc_block;
     double beta;
     float fm_ref;
@@ -128,6 +132,7 @@ uint32_t run1024_v2_runs(uint32_t nf, uint32_t cus);    // 0: call too short for
 int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTimer *timer);
 // third-generation FM kernel (kernels_run1024_v3.hip): one 512-thread workgroup per CU, output lines staged in registers (no staging
 // block); whole band, calls of whole output lines (nf = 0 mod 32 frames F32 / 16 frames CF32)
+constexpr int RUN1024_DCFIX_F = 17;                     // frame -1 of a run (freqdem history) + its first four tiles: 32 768 samples behind the cold start
 uint32_t run1024_v3_runs(uint32_t nf, bool fm, uint32_t cus);    // 0: the call is not for this kernel
 int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_t s, KernelTimer *timer);
 

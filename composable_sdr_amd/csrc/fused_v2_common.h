@@ -167,4 +167,32 @@ template <int CTRL> __device__ __forceinline__ float dpp_keep(float old, float v
 }
 
 }  // namespace
+// The run kernels re-read a few arguments from the kernarg segment right where they use them (k_run256v2, k_run1024v3: the state arrays of
+// the launches without warm-up windows): as loop invariants they cost the tile loop
+// SGPRs it does not have (the asm stores rely on a kernel without SGPR spills: tests/test_build_invariants.py).  A hand-written SCALAR
+// load: a pointer fetched through the vector memory path would be waited for with an s_waitcnt vmcnt(N) that hipcc computes without
+// knowing about the asm DMA / stores in flight (first version: the pointer was used before it had arrived).
+template <size_t OFF> __device__ __forceinline__ unsigned kernarg_u32_s()
+{
+    unsigned v = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const char *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "n"(OFF) : "memory");
+#endif
+    return v;
+}
+template <size_t OFF> __device__ __forceinline__ float2 *kernarg_ptr_s()
+{
+    float2 *p = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const char *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "n"(OFF) : "memory");
+    p = reinterpret_cast<float2 *>(v);
+#endif
+    return p;
+}
+
 }  // namespace csdr

@@ -87,32 +87,6 @@ struct V2Args {
     RunArgs r;
 };
 
-// k_run256v2 re-reads two pointer arguments from the kernarg segment right where it uses them: as loop invariants they cost the tile loop
-// SGPRs it does not have (the asm stores rely on a kernel without SGPR spills: tests/test_build_invariants.py).  A hand-written SCALAR
-// load: a pointer fetched through the vector memory path would be waited for with an s_waitcnt vmcnt(N) that hipcc computes without
-// knowing about the asm DMA / stores in flight (first version: the pointer was used before it had arrived).
-template <size_t OFF> __device__ __forceinline__ unsigned kernarg_u32_s()
-{
-    unsigned v = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(4))) const char *kptr;
-    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "n"(OFF) : "memory");
-#endif
-    return v;
-}
-template <size_t OFF> __device__ __forceinline__ float2 *kernarg_ptr_s()
-{
-    float2 *p = nullptr;
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(4))) const char *kptr;
-    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned long long v;
-    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ka), "n"(OFF) : "memory");
-    p = reinterpret_cast<float2 *>(v);
-#endif
-    return p;
-}
 // G > 1: INTERLEAVED CHANNEL SHARD g = A.c0 of G (rank g of G owns the channels g, g + G, ...; G | 16).  With
 // k = k1 + 16 k2 ownership only depends on k1, and W16^(a k1) = W16^(a g) W16^(a k1'), k1 = g + k1': the factor W16^(a g) is a
 // constant of polyphase branch j = 16 a + b1 and rides on its pre-mix phasor for free, after which the shard needs the pass-1

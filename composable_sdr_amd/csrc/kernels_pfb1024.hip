@@ -467,6 +467,7 @@ struct BigPlan {
     char *d_stage = nullptr;         // (k_run1024v2's whole-band staging blocks: no longer built, never allocated)
     void *d_full = nullptr;          // interleaved shard, calls k_run1024v2 does not take: whole-band result [1024][max_nf] (allocated on first use)
     void *d_premix = nullptr;
+    float2 *d_cpre = nullptr, *d_side = nullptr, *d_rt = nullptr;       // k_run1024v3 without warm-up windows (Run1024v2Host::cpre / side / rt)
     int cur = 0;
 };
 
@@ -476,7 +477,7 @@ void big_destroy(BigPlan *p)
 {
     if (!p) return;
     void *ptrs[] = {p->d_taps, p->d_taps_t, p->d_taps_q, p->d_tw, p->d_wpre, p->d_uhist[0], p->d_uhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0], p->d_rp[1],
-                    p->d_scratch, p->d_premix, p->d_stage, p->d_full};
+                    p->d_scratch, p->d_premix, p->d_stage, p->d_full, p->d_cpre, p->d_side, p->d_rt};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -557,6 +558,21 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         p->v3_last = p->v3_ok && run1024_v3_runs(cfg.max_nf, cfg.fm, p->cus) != 0;
         if (p->v3_last) p->v2_last = false;
     }
+    if (p->v3_ok) {
+        // k_run1024v3's state hand-over and the side copies of the four channels around DC (510..513): the kernel always writes them (a few
+        // hundred bytes per run); launches without warm-up windows (dc_block, not CSDR_NOWU=0) also get the chain's response to a unit DC state
+        // at those channels, frames 15 .. 31 behind a cold start (= frame -1 .. 15 of the run)
+        hipError_t e1 = hipMalloc((void **)&p->d_cpre, sizeof(float2) * (p->cus + 2)), e2 = hipMalloc((void **)&p->d_side, sizeof(float2) * (size_t)(p->cus + 1) * 4 * RUN1024_DCFIX_F);
+        if (e1 != hipSuccess || e2 != hipSuccess) return fail(hip_fail(e1 != hipSuccess ? e1 : e2, "hipMalloc", __FILE__, __LINE__));
+        CSDR_HIP(hipMemset(p->d_cpre, 0, sizeof(float2) * (p->cus + 2)));
+    }
+    if (p->v3_ok && cfg.dc_block && !(diag_env("CSDR_NOWU") && atoi(diag_env("CSDR_NOWU")) == 0)) {
+        hipError_t e3 = hipMalloc((void **)&p->d_rt, sizeof(float2) * 2 * RUN1024_DCFIX_F * 4);
+        if (e3 != hipSuccess) return fail(hip_fail(e3, "hipMalloc", __FILE__, __LINE__));
+        std::vector<float2> rt((size_t)2 * RUN1024_DCFIX_F * 4);
+        dc_state_response(cfg, wpre.data(), 15u, (uint32_t)RUN1024_DCFIX_F, 510u, rt.data());
+        CSDR_HIP(hipMemcpy(p->d_rt, rt.data(), sizeof(float2) * rt.size(), hipMemcpyHostToDevice));
+    }
     *out = p;
     return 0;
 }
@@ -608,6 +624,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.G = c.G; H.g = c.G > 1 ? c.c0 : 0u;
         H.tile_major = call.tile_major && v3runs && !c.fm;
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
+        if (v3runs) { H.cpre = p->d_cpre; H.side = p->d_side; H.rt = v3runs <= p->cus ? p->d_rt : nullptr; }
         if (v3runs) { if ((r = run1024_v3_launch(H, c.fm, v3runs, s, timer))) return r; }
         else if ((r = run1024_v2_launch(H, c.fm, s, timer))) return r;
         p->cur ^= 1;

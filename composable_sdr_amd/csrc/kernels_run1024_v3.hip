@@ -71,6 +71,8 @@ struct Run1024v3Args {
     float b16[16];              // beta^(16 r)
     float b256[17];             // beta^(256 g)
     PhaseK pk;
+    uint32_t nowu;              // 1: a run starts cold from DC state 0 (no read-only warm-up tiles), leaves the state in front of tile last - 4 in
+    float2 *cpre, *side;        //    cpre[w + 1] and (FM) the uncorrected Y of the channels 510..513 of its frames -1 .. 15 in side; k_run1024_dcfix
 };
 
 // run w: blocks of TB tiles, evenly; the call's last block may be a partial one (nb % TB tiles: its rows get the front part of a line)
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
 {
     constexpr unsigned B3_TB = FM ? B3_TBF : B3_TBC;
     __shared__ __attribute__((aligned(16))) float2 L[B3_F2];
+    __shared__ float2 cpre_s[8];                        // the DC state in front of the last eight steps' tiles: the one in front of tile last - 4 is the next run's cold start
     __shared__ unsigned long long trc[B3_TRACE ? 1536 : 1];            // debug stamps (8 KiB): collected in LDS, written out when the run is over (a global store per stamp would sit in the traced wave's vmcnt queue)
     float2 *tw1 = L + B3_TW1, *ST = L + B3_ST, *Tt = L + B3_TT, *red = ST;
     const int tid = threadIdx.x;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     float2 c = make_float2(0.f, 0.f);                   // DC state v before the next tile (same in every lane)
     {
         float2 acc = make_float2(0.f, 0.f);
-        if (w > 0 && !back) {
+        if (w > 0 && !back && !A.nowu) {
             // read-only warm-up (as k_run1024v2): the DC state before tile_begin from the six tiles in front of it, one batch of loads.  A run
             // that starts fewer than six tiles into the call (short calls: runs of one block) folds the tiles there are -- zeros stand for the
             // others -- and takes the rest from the stream's state below, which is then exact
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
         const int q = lt, sw = (q >> 1) & 7;
         const unsigned raw_a = (unsigned)q * 128u + ((unsigned)sw << 4);         // slot i of my run: raw_a ^ (i << 4)
 
+        const unsigned nsteps = n_items + 2;
         auto fstep = [&](const unsigned s, auto phc) {
             constexpr int PH = decltype(phc)::value;    // s & 3
             const bool have = s < n_items;
@@ -215,6 +219,11 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
             if (tr) trc[8 * s + 6] = __builtin_amdgcn_s_memtime();
             bar();                                      // P
             if (tr) trc[8 * s + 0] = __builtin_amdgcn_s_memtime();
+            // no warm-up windows: the state in front of tile last - 4 is the next run's cold start (my own start error is beta^(>= 12 x 4096) of it)
+            // the DC state in front of item s, parked in an LDS ring every step by every lane (the same value): a conditional global store, or
+            // only a lane mask kept across the loop, costs the FM kernel an SGPR it does not have; the entry in front of tile last - 4 is
+            // picked when the run is over
+            cpre_s[s & 7u] = c;
             if (have) load_taps(tq0, wo0, 0);           // (the taps of branches 0 and 1 fly during pass 1 and the DC scan)
             asm volatile("" ::: "memory");
             if (s >= 1 + nwarm && s - 1 < n_items && !(B3_ABLATE & 16)) {
@@ -333,7 +342,6 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
             for (int qq = 0; qq < 4; qq++) ring[4 * ((4 * PH + 3) & 15) + qq] = n3[qq];
 #undef NW
         };
-        const unsigned nsteps = n_items + 2;
         for (unsigned s0 = 0; s0 < nsteps; s0 += 4) {
             fstep(s0, std::integral_constant<int, 0>());
             if (s0 + 1 < nsteps) fstep(s0 + 1, std::integral_constant<int, 1>());
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
             if (s0 + 3 < nsteps) fstep(s0 + 3, std::integral_constant<int, 3>());
         }
         if (B3_TRACE && A.trace && w == 1 && tid == 0) for (int i = 0; i < 1024; i++) A.trace[i] = trc[i];
+        if (lt == 0 && n_items >= (unsigned)B3_HALO) A.cpre[w + 1] = cpre_s[(n_items - (unsigned)B3_HALO) & 7u];     // (same thread wrote it)
         if (last == A.nb) {
             if (lt == 0) A.vend_out[0] = c;
             // the next call's window: frame -d behind the last item (phase (n_items - 1) & 3) sits in slot (4 (n_items & 3) - d) & 15
@@ -413,6 +422,18 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
             }
             const unsigned ts = b & (B3_TB - 1u);
             bool keep = true;
+            if (FM && w > 0 && b + 1u >= first && b < first + 4u) {     // (always: a launch with warm-up windows just does not read them)
+                // the uncorrected Y of the four channels around DC, frames -1 .. 15 of the run, for k_run1024_dcfix (channel kk + 256 k3:
+                // 510, 511 = threads 254, 255 at k3 = 1; 512, 513 = threads 0, 1 at k3 = 2)
+                const int chs = lt >= 254 ? lt - 254 : (lt < 2 ? lt + 2 : -1);
+                if (chs >= 0) {
+                    float2 *sd = kernarg_ptr_s<offsetof(Run1024v3Args, side)>() + ((size_t)w * 4 + (unsigned)chs) * RUN1024_DCFIX_F;
+                    const int i0 = 4 * (int)(b + 1u - first) - 3;          // frame f of this tile -> slot i0 + f (slot 0 = frame -1)
+#pragma unroll
+                    for (int f = 0; f < 4; f++)
+                        if (i0 + f >= 0) sd[i0 + f] = lt >= 254 ? to_f2(y[f][1]) : to_f2(y[f][2]);
+                }
+            }
             if (FM) {
                 char *stp = reinterpret_cast<char *>(ST) + 32u * (unsigned)lt;    // my 32 bytes of the stash: [kk][k3], halves swapped like Z2's
                 const unsigned sth = 16u * (unsigned)((lt >> 3) & 1);
@@ -509,6 +530,37 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     }
 }
 
+// What the DC state a run started without contributes to the channels 510..513 over the run's first 16 frames: Y += cpre[w] x R (the chain
+// is linear up to Y).  CF32: in place on the rows (row-major or the tile-major plane); FM: freqdem of the corrected side copies.
+template <bool FM>
+__global__ __launch_bounds__(64) void k_run1024_dcfix(Run1024v3Args A, const float2 *__restrict__ rt)
+{
+    constexpr unsigned B3_TB = FM ? B3_TBF : B3_TBC;
+    const unsigned w = blockIdx.x + 1u, ch = threadIdx.x >> 4, fr = threadIdx.x & 15u;
+    unsigned first, last;
+    run3_bounds(A.nb, A.nruns, w, B3_TB, first, last);
+    const float2 c = A.cpre[w];
+    const unsigned par = A.parity0 & 1u;                // a tile is 4 frames: every cold start begins on the call's parity
+    const float2 *R = rt + (size_t)par * RUN1024_DCFIX_F * 4;
+    auto corr = [&](unsigned i) { const float2 r = R[i * 4u + ch]; return make_float2(c.x * r.x - c.y * r.y, c.x * r.y + c.y * r.x); };
+    const size_t t = (size_t)4 * first + fr;            // the frame in the call
+    if (t >= A.nf) return;
+    const unsigned k = 510u + ch;
+    if (FM) {
+        const float2 *sd = A.side + ((size_t)w * 4 + ch) * RUN1024_DCFIX_F;
+        const float2 p0 = sd[fr], p1 = sd[fr + 1u], d0 = corr(fr), d1 = corr(fr + 1u);
+        const FmK fk = {A.tiny, A.fm_ref, A.pk.hp, A.pk.pi};
+        reinterpret_cast<float *>(A.out)[(size_t)k * A.nf + t] =
+            fm_sample(make_float2(p0.x + d0.x, p0.y + d0.y), make_float2(p1.x + d1.x, p1.y + d1.y), fk);
+    } else {
+        float2 *o = reinterpret_cast<float2 *>(A.out) + (A.tile_major ? ((t >> 4) * 1024u + k) * 16u + (t & 15u) : (size_t)k * A.nf + t);
+        const float2 d1 = corr(fr + 1u);
+        float2 y = *o;
+        y.x += d1.x; y.y += d1.y;
+        *o = y;
+    }
+}
+
 }  // namespace
 
 int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_t s, KernelTimer *timer)
@@ -531,9 +583,17 @@ int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream
     if (trace_file) { CSDR_HIP(hipMemsetAsync(d_trace, 0, 1536 * sizeof(unsigned long long), s)); A.trace = d_trace; }
     int r;
     if (timer && (r = timer->begin(s))) return r;
+    // no warm-up windows: whole runs of >= 16 tiles (a cold start is 4 tiles deep and the correction covers 4 more), the state arrays there
+    if (!h.cpre || !h.side) { set_error("run1024_v3_launch: internal: no state arrays"); return -1; }
+    A.nowu = (h.rt && h.dc_block && nruns >= 2 && A.nb / nruns >= 16u) ? 1u : 0u;
+    A.cpre = h.cpre; A.side = h.side;
     if (fm) hipLaunchKernelGGL((k_run1024v3<true>), dim3(nruns), dim3(512), 0, s, A);
     else hipLaunchKernelGGL((k_run1024v3<false>), dim3(nruns), dim3(512), 0, s, A);
     if (timer && (r = timer->end(s))) return r;
+    if (A.nowu) {
+        if (fm) hipLaunchKernelGGL((k_run1024_dcfix<true>), dim3(nruns - 1u), dim3(64), 0, s, A, h.rt);
+        else hipLaunchKernelGGL((k_run1024_dcfix<false>), dim3(nruns - 1u), dim3(64), 0, s, A, h.rt);
+    }
     CSDR_HIP(hipGetLastError());
     if (trace_file) {                                   // debug: the last launch's stamps, raw uint64: front [128][8], back [128][4]
         std::vector<unsigned long long> hbuf(1536);

@@ -1218,6 +1218,54 @@ def test_run64_v2_without_warm_up_windows_matches_the_warm_up_build(monkeypatch)
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("demod,agc", [("fm", 0.0), ("none", 0.0), ("fm", 10.0)])
+def test_run1024_v3_without_warm_up_windows_matches_the_warm_up_build(demod, agc, monkeypatch):
+    """Round 5: k_run1024v3's runs start cold from DC state 0 as well (no read-only warm-up tiles); k_run1024_dcfix adds what the true state
+    contributes to the channels 510..513 over a run's first 16 frames (FM: freqdem of the corrected side copies; CF32: in place, row-major
+    or on the tile-major plane of the AGC route).  Against the same library with the windows (CSDR_NOWU=0) on a strong DC offset, 8 runs of
+    128 / 32 tiles, a 5-frame call in between (other kernel, odd parity behind it); FM / DeNo also against the oracle behind an f64 blocker."""
+    from scipy.signal import lfilter
+    M, kf = 1024, 0.3
+    frames = [4096, 5, 1024]
+    x = synth_cf32(M * sum(frames), M, seed=1024, dc=0.3 - 0.2j)
+    knob(monkeypatch, "CSDR_RUN1024_V3_RUNS", "8")
+    kw = dict(channels=M, demod=demod, kf=kf, agc=agc, max_frames=max(frames))
+    a = cs.Chain(**kw)
+    knob(monkeypatch, "CSDR_NOWU", "0")
+    b = cs.Chain(**kw)
+    monkeypatch.delenv("CSDR_NOWU")
+    beta = float(np.float32(1) - np.float32(0.0005))
+    yd = lfilter([1.0, -1.0], [1.0, -beta], x.astype(np.complex128)).astype(np.complex64)
+    orc = O.Chain(M, demod=demod, kf=kf, dc_block=False) if agc == 0.0 else None
+    pos, near = 0, slice(510, 514)
+    for nf in frames:
+        c = x[pos:pos + nf * M]
+        ga, gb = a.process(c), b.process(c)
+        w = orc.process(yd[pos:pos + nf * M]) if orc else None
+        pos += nf * M
+        kn = a.kernel_time()[0]
+        if nf % 4 == 0:
+            assert kn.startswith("k_run1024v3"), kn
+        if agc:
+            assert np.array_equal(ga == 0, gb == 0)                         # the same squelch decisions
+            d = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / kf))
+            print(f"M=1024 AGC+FM no-warm-up vs warm-up nf={nf} [{kn}]: median {np.median(d):.2e}, p99.9 {np.quantile(d, 0.999):.2e}, 510..513 median {np.median(d[near]):.2e}")
+            assert np.median(d) < 2e-6 and np.quantile(d, 0.999) < 1e-3 and np.median(d[near]) < 2e-5
+        elif demod == "none":
+            e_all, e_near = rel_rms(ga, gb), rel_rms(ga[near], gb[near])
+            print(f"M=1024 DeNo no-warm-up vs warm-up nf={nf} [{kn}]: all {e_all:.2e}, 510..513 {e_near:.2e}; vs oracle (f64 dc) {rel_rms(ga, w):.2e} (warm-up build {rel_rms(gb, w):.2e})")
+            assert e_all < 2e-6 and e_near < 2e-5
+            assert rel_rms(ga, w) < 1.2 * rel_rms(gb, w) + 1e-6
+        else:
+            d = np.abs(wrap_pm(ga.astype(np.float64) - gb, 1.0 / kf))
+            dw = np.abs(wrap_pm(ga.astype(np.float64) - w, 1.0 / kf))
+            tone = np.arange(M) % 4 == 1
+            print(f"M=1024 FM no-warm-up vs warm-up nf={nf} [{kn}]: median {np.median(d):.2e}, tone max {d[tone].max():.2e}, 510..513 median {np.median(d[near]):.2e}; vs oracle tone max {dw[tone].max():.2e}")
+            assert np.median(d) < 2e-6 and d[tone].max() < 1e-5 and np.median(d[near]) < 2e-5
+            assert dw[tone].max() < 3e-5
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("M,demod,env,frames,extra", [
     (64, "none", "CSDR_RUN64_V1", [8192, 2048], {}),
     (64, "none", "CSDR_RUN64_V1", [8192], {"mix": True}),
