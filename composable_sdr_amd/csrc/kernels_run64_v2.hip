@@ -319,16 +319,17 @@ __global__ __launch_bounds__(256) void k_run64_dcfix(Run64v2Args A, const float2
     run64_bounds(A, w, first, last);
     const float2 c = A.cpre[w];
     const unsigned par = A.parity0 & 1u;                // a tile is 64 frames: every halo tile starts on the call's parity
-    for (unsigned e = threadIdx.x; e < 4u * RUN64_DCFIX_F; e += 256u) {
-        const unsigned ch = e / RUN64_DCFIX_F, t = e % RUN64_DCFIX_F;
-        const size_t fr = (size_t)64 * first + t;
-        if (fr >= (size_t)64 * last) continue;          // (runs are >= 14 tiles: never)
-        float2 *o = A.out + (size_t)(30u + ch) * A.out_stride + fr;
-        const float2 r = rt[((size_t)par * RUN64_DCFIX_F + t) * 4u + ch];
-        float2 y = *o;
-        y.x += c.x * r.x - c.y * r.y; y.y += c.x * r.y + c.y * r.x;
-        *o = y;
-    }
+    // one element per thread (grid.y = 7 slices of 256): a loop of read-modify-writes ran one memory round trip after the other (8 us)
+    const unsigned e = blockIdx.y * 256u + threadIdx.x;
+    if (e >= 4u * RUN64_DCFIX_F) return;
+    const unsigned ch = e / RUN64_DCFIX_F, t = e % RUN64_DCFIX_F;
+    const size_t fr = (size_t)64 * first + t;
+    if (fr >= (size_t)64 * last) return;                // (runs are >= 14 tiles: never)
+    float2 *o = A.out + (size_t)(30u + ch) * A.out_stride + fr;
+    const float2 r = rt[((size_t)par * RUN64_DCFIX_F + t) * 4u + ch];
+    float2 y = *o;
+    y.x += c.x * r.x - c.y * r.y; y.y += c.x * r.y + c.y * r.x;
+    *o = y;
 }
 
 }  // namespace
@@ -367,7 +368,7 @@ int run64_v2_launch(const Run64v2Host &h, hipStream_t s, KernelTimer *timer)
     A.cpre = h.cpre;
     hipLaunchKernelGGL(k_run64v2, dim3(h.nruns), dim3(256), 0, s, A);
     if (timer && (r = timer->end(s))) return r;
-    if (A.nowu) hipLaunchKernelGGL(k_run64_dcfix, dim3(h.nruns - 1u), dim3(256), 0, s, A, h.rt);
+    if (A.nowu) hipLaunchKernelGGL(k_run64_dcfix, dim3(h.nruns - 1u, (4u * RUN64_DCFIX_F + 255u) / 256u), dim3(256), 0, s, A, h.rt);
     CSDR_HIP(hipGetLastError());
     return 0;
 }
