@@ -132,7 +132,10 @@ uint32_t run1024_v2_runs(uint32_t nf, uint32_t cus);    // 0: call too short for
 int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTimer *timer);
 // third-generation FM kernel (kernels_run1024_v3.hip): one 512-thread workgroup per CU, output lines staged in registers (no staging
 // block); whole band, calls of whole output lines (nf = 0 mod 32 frames F32 / 16 frames CF32)
-constexpr int RUN1024_DCFIX_F = 17;                     // frame -1 of a run (freqdem history) + its first four tiles: 32 768 samples behind the cold start
+// frame -1 of a run (freqdem history) + its first eight tiles.  The first frame NOT corrected (32) has a window that reaches back to frame
+// 35 behind the cold start: alpha |c| beta^35840 = 1.6e-8 alpha |c| of the missing state is left in it (with four tiles it was 5.9e-5:
+// ~1e-5 of a unit signal at the strongest DC offset the tests use)
+constexpr int RUN1024_DCFIX_F = 33;
 uint32_t run1024_v3_runs(uint32_t nf, bool fm, uint32_t cus);    // 0: the call is not for this kernel
 int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_t s, KernelTimer *timer);
 

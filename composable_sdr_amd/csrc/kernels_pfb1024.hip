@@ -561,7 +561,7 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
     if (p->v3_ok) {
         // k_run1024v3's state hand-over and the side copies of the four channels around DC (510..513): the kernel always writes them (a few
         // hundred bytes per run); launches without warm-up windows (dc_block, not CSDR_NOWU=0) also get the chain's response to a unit DC state
-        // at those channels, frames 15 .. 31 behind a cold start (= frame -1 .. 15 of the run)
+        // at those channels, frames 15 .. 47 behind a cold start (= frame -1 .. 31 of the run)
         hipError_t e1 = hipMalloc((void **)&p->d_cpre, sizeof(float2) * (p->cus + 2)), e2 = hipMalloc((void **)&p->d_side, sizeof(float2) * (size_t)(p->cus + 1) * 4 * RUN1024_DCFIX_F);
         if (e1 != hipSuccess || e2 != hipSuccess) return fail(hip_fail(e1 != hipSuccess ? e1 : e2, "hipMalloc", __FILE__, __LINE__));
         CSDR_HIP(hipMemset(p->d_cpre, 0, sizeof(float2) * (p->cus + 2)));

@@ -72,7 +72,7 @@ struct Run1024v3Args {
     float b256[17];             // beta^(256 g)
     PhaseK pk;
     uint32_t nowu;              // 1: a run starts cold from DC state 0 (no read-only warm-up tiles), leaves the state in front of tile last - 4 in
-    float2 *cpre, *side;        //    cpre[w + 1] and (FM) the uncorrected Y of the channels 510..513 of its frames -1 .. 15 in side; k_run1024_dcfix
+    float2 *cpre, *side;        //    cpre[w + 1] and (FM) the uncorrected Y of the channels 510..513 of its frames -1 .. 31 in side; k_run1024_dcfix
 };
 
 // run w: blocks of TB tiles, evenly; the call's last block may be a partial one (nb % TB tiles: its rows get the front part of a line)
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
             }
             const unsigned ts = b & (B3_TB - 1u);
             bool keep = true;
-            if (FM && w > 0 && b + 1u >= first && b < first + 4u) {     // (always: a launch with warm-up windows just does not read them)
-                // the uncorrected Y of the four channels around DC, frames -1 .. 15 of the run, for k_run1024_dcfix (channel kk + 256 k3:
+            if (FM && w > 0 && b + 1u >= first && b < first + 8u) {     // (always: a launch with warm-up windows just does not read them)
+                // the uncorrected Y of the four channels around DC, frames -1 .. 31 of the run, for k_run1024_dcfix (channel kk + 256 k3:
                 // 510, 511 = threads 254, 255 at k3 = 1; 512, 513 = threads 0, 1 at k3 = 2)
                 const int chs = lt >= 254 ? lt - 254 : (lt < 2 ? lt + 2 : -1);
                 if (chs >= 0) {
@@ -530,13 +530,13 @@ __global__ __launch_bounds__(512) void k_run1024v3(Run1024v3Args A)
     }
 }
 
-// What the DC state a run started without contributes to the channels 510..513 over the run's first 16 frames: Y += cpre[w] x R (the chain
+// What the DC state a run started without contributes to the channels 510..513 over the run's first 32 frames: Y += cpre[w] x R (the chain
 // is linear up to Y).  CF32: in place on the rows (row-major or the tile-major plane); FM: freqdem of the corrected side copies.
 template <bool FM>
-__global__ __launch_bounds__(64) void k_run1024_dcfix(Run1024v3Args A, const float2 *__restrict__ rt)
+__global__ __launch_bounds__(128) void k_run1024_dcfix(Run1024v3Args A, const float2 *__restrict__ rt)
 {
     constexpr unsigned B3_TB = FM ? B3_TBF : B3_TBC;
-    const unsigned w = blockIdx.x + 1u, ch = threadIdx.x >> 4, fr = threadIdx.x & 15u;
+    const unsigned w = blockIdx.x + 1u, ch = threadIdx.x >> 5, fr = threadIdx.x & 31u;
     unsigned first, last;
     run3_bounds(A.nb, A.nruns, w, B3_TB, first, last);
     const float2 c = A.cpre[w];
@@ -591,8 +591,8 @@ int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream
     else hipLaunchKernelGGL((k_run1024v3<false>), dim3(nruns), dim3(512), 0, s, A);
     if (timer && (r = timer->end(s))) return r;
     if (A.nowu) {
-        if (fm) hipLaunchKernelGGL((k_run1024_dcfix<true>), dim3(nruns - 1u), dim3(64), 0, s, A, h.rt);
-        else hipLaunchKernelGGL((k_run1024_dcfix<false>), dim3(nruns - 1u), dim3(64), 0, s, A, h.rt);
+        if (fm) hipLaunchKernelGGL((k_run1024_dcfix<true>), dim3(nruns - 1u), dim3(128), 0, s, A, h.rt);
+        else hipLaunchKernelGGL((k_run1024_dcfix<false>), dim3(nruns - 1u), dim3(128), 0, s, A, h.rt);
     }
     CSDR_HIP(hipGetLastError());
     if (trace_file) {                                   // debug: the last launch's stamps, raw uint64: front [128][8], back [128][4]

@@ -1221,7 +1221,7 @@ def test_run64_v2_without_warm_up_windows_matches_the_warm_up_build(monkeypatch)
 @pytest.mark.parametrize("demod,agc", [("fm", 0.0), ("none", 0.0), ("fm", 10.0)])
 def test_run1024_v3_without_warm_up_windows_matches_the_warm_up_build(demod, agc, monkeypatch):
     """Round 5: k_run1024v3's runs start cold from DC state 0 as well (no read-only warm-up tiles); k_run1024_dcfix adds what the true state
-    contributes to the channels 510..513 over a run's first 16 frames (FM: freqdem of the corrected side copies; CF32: in place, row-major
+    contributes to the channels 510..513 over a run's first 32 frames (FM: freqdem of the corrected side copies; CF32: in place, row-major
     or on the tile-major plane of the AGC route).  Against the same library with the windows (CSDR_NOWU=0) on a strong DC offset, 8 runs of
     128 / 32 tiles, a 5-frame call in between (other kernel, odd parity behind it); FM / DeNo also against the oracle behind an f64 blocker."""
     from scipy.signal import lfilter
