@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, batch 21: whole GPU suite, smoke, every profile again (sources changed), default bench, M = 4096 + AGC at the reference chunk
-O=gpurun_out/r6j; mkdir -p $O
+O=gpurun_out/r6k; mkdir -p $O
 ( time timeout 1500 python -m pytest tests -q -m gpu ) > $O/tests.txt 2>&1
 tail -6 $O/tests.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
