@@ -36,6 +36,13 @@
 extern "C" {
 #endif
 
+/* libcsdr_hip.so is built with -fvisibility=hidden: the declarations between this push and the
+ * pop at the end of the file are the library's whole dynamic symbol table (what a Haskell
+ * `foreign import ccall` can bind); the C++ internals behind them are not exported. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define CSDR_OK            0
 #define CSDR_ERR_INVALID  (-1)  /* bad argument / configuration                         */
 #define CSDR_ERR_HIP      (-2)  /* HIP runtime error (text in csdr_last_error)          */
@@ -363,6 +370,10 @@ int csdr_chain_process_mix(csdr_chain *h, csdr_comm *c, const float *in_cf32, ui
  * chan_per_rank * sum_{q<p} stripe_frames[q].  One grouped ncclSend / ncclRecv per peer (every xGMI link carries one block each way). */
 int csdr_hybrid_exchange(csdr_comm *c, const void *d_plane, void *d_recv, uint32_t chan_per_rank, const uint32_t *stripe_frames,
                          uint32_t elem_bytes, void *stream);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,20 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_library_exports_nothing_but_the_header():
+    """What a Haskell `foreign import ccall` can see (Liquid.chs:730-780 binds liquid's C symbols the same way) is the header:
+    the dynamic symbol table holds the declared csdr_* functions and no C++ internal, kernel handle or template instance
+    (-fvisibility=hidden + csrc/exports.map)."""
+    import subprocess
+    import composable_sdr_amd as cs
+    if not os.path.exists(cs.lib_path()):
+        cs.build_library()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", cs.lib_path()], text=True)
+    defined = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert defined == _declared_symbols(), sorted(set(defined) ^ set(_declared_symbols()))
+    assert not [n for n in defined if n.startswith("_Z")]
+
+
 def test_cfg_struct_matches_header_layout():
     from composable_sdr_amd import _lib
     cfg = _lib.ChainCfg()
