@@ -312,6 +312,7 @@ def main():
     dt_cold, _ = timed(a.steps, a.warmup)
     # (1) >= preheat_ms of back-to-back steps, one synchronisation at the end: `sustained_long`, and the state `value` is measured in
     preheat_steps, sus_long, smi = 0, None, None
+    kms_l, klaunches_l = 0.0, 0
     if a.preheat_ms > 0:
         est = max(dt_cold / a.steps, 1e-5)
         preheat_steps = max(10, int(a.preheat_ms * 1e-3 / est) + 1)
@@ -323,11 +324,13 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 preheat_steps = int(t.item())
             barrier()
+            chain.kernel_time()                 # (reset: the region events below bracket exactly this run's launches)
             t_a = time.perf_counter()
             for i in range(preheat_steps):
                 step(i)
             torch.cuda.synchronize()
             t_b = time.perf_counter()
+            _, kms_l, klaunches_l = chain.kernel_time()     # ONE hipEvent in front of the run's first launch, one behind its last, on the launch stream
             el = t_b - t_a
             if use_dist:
                 t = torch.tensor([el], dtype=torch.float64, device=dev)
@@ -341,7 +344,8 @@ def main():
             smi.stop = True                     # no join here: an idle gap of 0.1 s in front of the timed region would put the board back
                                                 # into its idle state (first run of this file: 295 us per step behind a 0.3 s join)
         sus_long = {"steps": preheat_steps, "seconds": round(t_b - t_a, 3), "ms_per_step": round(d_l * 1e3, 4),
-                    "value": round(nx * (1 if chan else world) / d_l / 1e6, 1), "unit": "MS/s"}
+                    "value": round(nx * (1 if chan else world) / d_l / 1e6, 1), "unit": "MS/s",
+                    "launch_ms_events": round(kms_l / klaunches_l, 4) if klaunches_l else None, "launches": klaunches_l}
     # (2) the contract: W warm-up steps, then EXACTLY K timed steps between barrier + synchronize
     dt, (kname_r, kms_r, klaunches_r) = timed(a.steps, a.warmup)
     # (3) the same step over 400 further launches (`sustained`), still back to back
@@ -464,6 +468,14 @@ def main():
             del plane, recv
 
 
+    def side_exit():
+        """Leave a run whose SIDE measurements hung or raised (the other ranks may sit in a collective: no barrier with them).  The contract's
+        line has been printed by then and carries `side_error`; the failure also goes to stderr.  Exit status: 0 by default -- the driver's
+        N > 1 runs are the only multi-GPU numbers there are, and a launcher that sees a non-zero child discards the line with them -- and
+        3 under CSDR_BENCH_SIDE_STRICT=1, for a CI that wants a hung RCCL side path to fail the job."""
+        print(f"bench.py: rank {rank}: side measurements failed: {side_state['error']}", file=sys.stderr, flush=True)
+        os._exit(3 if os.environ.get("CSDR_BENCH_SIDE_STRICT") == "1" else 0)
+
     def watchdog(limit):
         if side_done.wait(limit):
             return
@@ -473,7 +485,7 @@ def main():
                 finish(True)
         finally:
             sys.stdout.flush()
-            os._exit(0)
+            side_exit()
 
     finish_lock = threading.Lock()
     finished = [False]
@@ -502,8 +514,15 @@ def main():
         value = total_samples / dt / 1e6
         alg_bytes_per_sample = 8 + (out_elem / M if a.mix else out_elem)   # read CF32 once + write W
         kavg_ms = kms / max(klaunches, 1)
-        achieved = (nx * alg_bytes_per_sample) / (kavg_ms * 1e-3) / 1e9 if klaunches else None
+        achieved_pairs = (nx * alg_bytes_per_sample) / (kavg_ms * 1e-3) / 1e9 if klaunches else None
         kreg_ms = kms_r / max(klaunches_r, 1)
+        # `roofline.achieved` / `frac` are what a STREAM sees: the launch cadence of the dominant kernel (+ its correction kernel) over the long
+        # back-to-back run (`sustained_long`: >= preheat_ms at the board's power cap), from one hipEvent in front of that run's first launch
+        # and one behind its last on the launch stream.  The K-step window behind a barrier (`frac_k_step_window`) and the K event-paired
+        # launches (`frac_event_pairs`) run 2-3 % faster -- the board has just idled for the barrier -- and are reported beside it.
+        ksus_ms = kms_l / klaunches_l if klaunches_l else None
+        roof_ms = ksus_ms if ksus_ms else kavg_ms
+        achieved = (nx * alg_bytes_per_sample) / (roof_ms * 1e-3) / 1e9 if (ksus_ms or klaunches) else None
         # HBM bytes per launch from the committed PMC passes of this very configuration (tools/profile_all.sh +
         # tools/collect_all.sh: FETCH_SIZE x 2 + WRITE_SIZE, separate --pmc runs); null when it has not been profiled
         tj = {}
@@ -528,18 +547,21 @@ def main():
         traffic = traffic_of(kname)
         cfg_name = {(64, "none", False): "cfg2", (256, "fm", False): "cfg3", (1024, "fm", False): "cfg4 shape (one GPU)" if world == 1 else "cfg4",
                     (4096, "none", True): "cfg5 shape (one GPU)" if world == 1 else "cfg5"}.get((M, a.demod, bool(a.mix)), "custom")
+        # which partition `value` is -- first key of `config`, so that a truncated copy of the line still says it
+        sharding_txt = ("none (1 GPU)" if world == 1 else
+                        (f"channel shards (north_star's partition): rank g owns channels g + {world} m of the SAME stream, samples counted once, pruned DFT; "
+                         f"collective: {'one RCCL all-reduce per step (--mix)' if a.mix else 'none'}" if chan else
+                         f"independent time stripes, no collective: each of the {world} ranks runs the whole {M}-channel chain on its own stretch of the stream "
+                         "(weak scaling: linear by construction); north_star's channel-shard partition of ONE stream is `value_channel_shard` (strong scaling)"))
         res = {
             "metric": f"MS/s CF32 throughput, {M}-ch PFB{'+FM' if a.demod == 'fm' else ''}{'+AGC' if a.agc else ''}{' --mix' if a.mix else ''} pipeline", "value": round(value, 1), "unit": "MS/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if chan else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg_name}: {M}-ch firpfbch(m=7,As=80)+dcBlocker{f'+freqdem(kf={a.kf})' if a.demod == 'fm' else ' (DeNo)'}{' --mix' if a.mix else ''} on synthetic CF32, "
+            "config": {"sharding": sharding_txt, "workload": f"{cfg_name}: {M}-ch firpfbch(m=7,As=80)+dcBlocker{f'+freqdem(kf={a.kf})' if a.demod == 'fm' else ' (DeNo)'}{' --mix' if a.mix else ''} on synthetic CF32, "
                                    f"AGC {'off (-a 0)' if a.agc == 0 else a.agc}, {nf} frames/step "
                                    f"({nx * 8 / 2**20:.0f} MiB in, {M * nf * out_elem / 2**20:.0f} MiB out), HBM-resident",
                        "channels": M, "frames_per_step": nf, "demod": a.demod, "kf": a.kf, "agc_db": a.agc, "mix": bool(a.mix),
                        "path": f"{chain.path.split('|')[0]}|{kname}", "route": chain.path, "preheat_steps": preheat_steps,
-                       "sharding": ("none" if world == 1 else
-                                    (f"channel-interleaved: rank g owns channels g + {world} m, pruned DFT (fold + {M // world}-point)" if chan
-                                     else "time stripes, 1 per rank")),
                        "collective": (f"RCCL all-reduce(SUM) of {nf} {'F32' if a.demod == 'fm' else 'CF32'} per step" if (chan and a.mix) else "none"),
                        "collective_api": (("csdr_chain_process_device_mix (C ABI, RCCL)" if comm is not None else "torch.distributed (gloo test hook)")
                                           if (chan and a.mix) else None),
@@ -548,19 +570,24 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4) if achieved else None,
-                         "traffic": traffic, "launch_ms": round(kavg_ms, 4), "launches": klaunches,
+                         "traffic": traffic, "launch_ms": round(roof_ms, 4), "launches": klaunches_l if ksus_ms else klaunches,
+                         "launch_ms_source": ("hipEvents around the sustained_long run's launches on the launch stream (region / launches): the steady state at the power cap"
+                                              if ksus_ms else "hipEvent pairs around K launches (no sustained run: --preheat-ms 0)"),
+                         "launch_ms_event_pairs": round(kavg_ms, 4), "launches_event_pairs": klaunches,
+                         "frac_event_pairs": round(achieved_pairs / HBM_PEAK_GBS, 4) if achieved_pairs else None,
                          "traffic_source": ("profiles/traffic.json: rocprofv3 --pmc passes of this configuration (FETCH_SIZE x 2 + WRITE_SIZE per launch, "
                                             "tools/profile_all.sh + tools/collect_all.sh), not re-measured in this run; kernel sources unchanged since "
                                             f"(src_sha16 {src_sha})") if not stale else
                                            f"null: profiles/traffic.json was collected on other kernel sources than today's (src_sha16 {src_sha}); re-run tools/profile_all.sh",
-                         "launch_ms_timed_region": round(kreg_ms, 4) if klaunches_r else None,
-                         "frac_timed_region": round(nx * alg_bytes_per_sample / (kreg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if klaunches_r else None,
+                         "launch_ms_k_step_window": round(kreg_ms, 4) if klaunches_r else None,
+                         "frac_k_step_window": round(nx * alg_bytes_per_sample / (kreg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if klaunches_r else None,
                          "alg_bytes_per_sample": alg_bytes_per_sample, "samples_per_launch": nx},
             "cold_window": {"steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt_cold / a.steps * 1e3, 4),
                             "value": round(total_samples / dt_cold / 1e6, 1), "unit": "MS/s",
                             "note": "the same W + K steps started on an idle board (no pre-heat): inside the board's power transient"},
         }
         if sus_long:
+            res["value_sustained"] = sus_long["value"]      # the same metric over the long run: what a stream sees (`value` is the contract's K-step window)
             sus_long["hbm_roofline_frac_whole_step"] = round(sus_long["value"] * 1e6 * alg_bytes_per_sample / 1e9 / (HBM_PEAK_GBS * (1 if chan else world)), 4)
             res["sustained_long"] = sus_long
 
@@ -620,9 +647,10 @@ def main():
             # loop); the kernels behind them are profiled under profiles/rNN_*.  Not the headline: `value` above is.
             out2 = torch.empty(nx * 2, dtype=torch.float32, device=dev)
             others = []
-            def side(tag, workload, M2, nf2, demod2, agc2, mix2, bps):
+            def side(tag, workload, M2, nf2, demod2, agc2, mix2, bps, G2=0, g2=0):
                 try:
-                    c2 = cs.Chain(channels=M2, demod=demod2, kf=a.kf, agc=agc2, mix=mix2, max_frames=nf2, device=local, flags=_lib.FLAG_QUIET)
+                    c2 = cs.Chain(channels=M2, demod=demod2, kf=a.kf, agc=agc2, mix=mix2, max_frames=nf2, device=local, flags=_lib.FLAG_QUIET,
+                                  chan_first=g2, chan_stride=G2)
                     n2 = M2 * nf2
                     for i in range(6):
                         c2.process_device(xs[i & 1].data_ptr(), n2, out2.data_ptr(), stream)
@@ -640,6 +668,12 @@ def main():
                     e = {"tag": tag, "workload": workload, "channels": M2, "frames_per_step": nf2, "demod": demod2, "agc_db": agc2, "mix": bool(mix2),
                          "route": c2.path, "kernel": c2.kernel_time()[0], "steps": reps, "ms_per_step": round(d * 1e3, 4), "value": round(n2 / d / 1e6, 1), "unit": "MS/s",
                          "alg_bytes_per_sample": bps}
+                    if G2 > 1:
+                        # ONE rank of an N = G2 channel-shard run, timed alone on this GPU: `value` is the rate at which that rank gets through the
+                        # COMMON input stream (every rank reads all of it: 8 B per sample, plus its 1 / G2 of the output), which is also the whole
+                        # job's rate when the G2 ranks run side by side on G2 GPUs (the samples are counted once)
+                        e.update({"chan_stride": G2, "chan_first": g2, "owned_channels": M2 // G2, "per_rank": True, "us_per_step": round(d * 1e6, 2),
+                                  "input_gs_per_s": round(n2 / d / 1e9, 2)})
                     if n2 * bps >= (64 << 20):
                         e["hbm_roofline_frac_whole_step"] = round(n2 * bps / d / 1e9 / HBM_PEAK_GBS, 4)
                     c2.close()
@@ -654,6 +688,14 @@ def main():
             side("m4096_deno", "4096-ch PFB, per-channel DeNo (fused 4096 route)", 4096, 16384, "none", 0.0, False, 16)
             side("m4096_fm", "4096-ch PFB + FM per channel (fused 4096 route)", 4096, 16384, "fm", 0.0, False, 12)
             side("m4096_fm_mix", "4096-ch PFB + FM --mix (fused 4096 route)", 4096, 16384, "fm", 0.0, True, 8)
+            # BASELINE configs[3] / north_star's partition, per rank: rank 0 of 8 (channels 0, 8, 16, ...: Trans.hs:124-129, SoapySDR.hs:223-225), alone on this GPU
+            side("shard_g8_m256_fm", "rank 0 of 8, interleaved channel shard of the 256-ch PFB + FM chain (32 owned channels)", 256, 262144, "fm", 0.0, False, 8 + 4 / 8, 8, 0)
+            side("shard_g8_m256_fm_agc", "rank 0 of 8, interleaved channel shard of the 256-ch PFB + AGC (-a 10) + FM chain", 256, 262144, "fm", 10.0, False, 8 + 4 / 8, 8, 0)
+            side("shard_g8_m1024_fm", "rank 0 of 8, interleaved channel shard of the 1024-ch PFB + FM chain (128 owned channels): BASELINE configs[3] per rank", 1024, 65536, "fm", 0.0, False, 8 + 4 / 8, 8, 0)
+            side("shard_g8_m1024_fm_agc", "rank 0 of 8, interleaved channel shard of the 1024-ch PFB + AGC (-a 10) + FM chain", 1024, 65536, "fm", 10.0, False, 8 + 4 / 8, 8, 0)
+            side("shard_g2_m1024_fm", "rank 0 of 2, interleaved channel shard of the 1024-ch PFB + FM chain", 1024, 65536, "fm", 0.0, False, 8 + 4 / 2, 2, 0)
+            side("cfg2_agc", "64-ch PFB + AGC (-a 10), DeNo (configs[1] shape with the AGC on)", 64, 1048576, "none", 10.0, False, 16)
+            side("cfg4_shape_1gpu_agc", "1024-ch PFB + AGC (-a 10) + FM, all channels on one GPU", 1024, 65536, "fm", 10.0, False, 12)
             side("ref_chunk_m256_fm", "the reference's own chunk: 256 ch x 4096 frames per call, FM", 256, 4096, "fm", 0.0, False, 12)
             side("ref_chunk_m256_fm_agc", "the reference's own chunk: 256 ch x 4096 frames per call, AGC (-a 10) + FM", 256, 4096, "fm", 10.0, False, 12)
             side("ref_chunk_m4096_deno", "the reference's own chunk: 4096 ch x 4096 frames per call, DeNo", 4096, 4096, "none", 0.0, False, 16)
@@ -683,7 +725,7 @@ def main():
     finish(False)
     if side_state["error"] and use_dist:
         sys.stdout.flush()
-        os._exit(0)                             # the other ranks may be stuck in a collective: no barrier with them
+        side_exit()                             # the other ranks may be stuck in a collective: no barrier with them
 
 
 if __name__ == "__main__":

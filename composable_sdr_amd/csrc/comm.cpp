@@ -230,14 +230,19 @@ int csdr_hybrid_exchange(csdr_comm *c, const void *d_plane, void *d_recv, uint32
     if (blk) CSDR_HIP(hipMemcpyAsync(dst + roff[g], src + (size_t)g * blk, blk, hipMemcpyDeviceToDevice, s));   // my own block
     if (G == 1) return CSDR_OK;
     CSDR_NCCL(g_rccl.GroupStart(), "ncclGroupStart");
-    for (int d = 1; d < G; d++) {
+    // a failing send / receive must not leave the group open on this thread (every later collective of any communicator would be
+    // queued into it instead of failing): remember the first error, always close the group, then report
+    ncclResult_t first = ncclSuccess; const char *where = nullptr;
+    for (int d = 1; d < G && first == ncclSuccess; d++) {
         // pair schedule: in step d rank g sends to g + d and receives from g - d (every xGMI link carries one block each way)
         const int to = (g + d) % G, from = (g - d + G) % G;
-        if (blk) CSDR_NCCL(g_rccl.Send(src + (size_t)to * blk, blk, ncclUint8, to, c->comm, s), "ncclSend");
+        if (blk) { first = g_rccl.Send(src + (size_t)to * blk, blk, ncclUint8, to, c->comm, s); where = "ncclSend"; }
         const size_t rb = roff[from + 1] - roff[from];
-        if (rb) CSDR_NCCL(g_rccl.Recv(dst + roff[from], rb, ncclUint8, from, c->comm, s), "ncclRecv");
+        if (rb && first == ncclSuccess) { first = g_rccl.Recv(dst + roff[from], rb, ncclUint8, from, c->comm, s); where = "ncclRecv"; }
     }
-    CSDR_NCCL(g_rccl.GroupEnd(), "ncclGroupEnd");
+    const ncclResult_t closed = g_rccl.GroupEnd();
+    if (first != ncclSuccess) return nccl_fail(first, where);
+    if (closed != ncclSuccess) return nccl_fail(closed, "ncclGroupEnd");
     return CSDR_OK;
 }
 

@@ -647,8 +647,8 @@ int fused_process(FusedPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         else if (v3) { if ((r = run256_v3_launch(&RA, c.fm, nruns, s))) return r; }
 #endif
         else if ((r = run256_v2_launch(&RA, c.fm, c.G, nruns, s))) return r;
-        if (timer && (r = timer->end(s))) return r;
         if (RA.nowu && nb_full && (r = run256_dcfix_launch(&RA, c.fm, nruns, p->d_rt, s))) return r;
+        if (timer && (r = timer->end(s))) return r;             // the bracket covers k_run256_dcfix: it is part of every no-warm-up step
         const uint32_t rem = nf - nb_full * NB;
         if (rem) {
             if (nb_full) p->cur ^= 1;                            // the tail starts from the run kernel's state

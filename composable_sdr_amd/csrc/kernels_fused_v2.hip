@@ -677,7 +677,7 @@ __global__ __launch_bounds__(128) void k_run256_dcfix(V2Args VA, const float2 *_
     unsigned first, last;
     run_range(RA.split, w, first, last);
     if (RA.pair_align) { first &= ~1u; if (last != A.nb) last &= ~1u; }
-    if (first >= last || first == 0) return;            // (a run whose halo tile is the call's first tile started from the carried state: exact)
+    if (first >= last || first <= 1) return;            // first == 1: the halo tile is the call's first tile, the run started from the carried state (h0 == 0 folds vend_in in): exact, and cpre[1] holds that same state -- correcting would add it twice
     const int t = threadIdx.x;
     const float2 c = RA.cpre[w];
     const float2 *R = Rt + (size_t)(A.parity0 & 1u) * DCFIX_F * 4;

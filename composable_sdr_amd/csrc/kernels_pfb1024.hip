@@ -592,7 +592,7 @@ void big_seek(BigPlan *p, uint64_t frames) { p->frames_done = frames; }
 const char *big_name(const BigPlan *p)
 {
     if (p->v3_last) return p->cfg.fm ? "k_run1024v3<FM>" : "k_run1024v3<CF32>";
-    if (p->v2_last) return "k_run1024v2<FM>";
+    if (p->v2_last) return p->cfg.G == 8 ? "k_run1024v2<FM>/G8" : p->cfg.G == 4 ? "k_run1024v2<FM>/G4" : p->cfg.G == 2 ? "k_run1024v2<FM>/G2" : "k_run1024v2<FM>";
     return p->cfg.fm ? "k_run1024<FM>" : "k_run1024<CF32>";
 }
 

@@ -23,6 +23,7 @@
 #include <memory>
 #include <stdexcept>
 #include <time.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -249,29 +250,58 @@ struct ChainOpts {
 
 // csdr_comm bootstrap through a file (RCCL's unique id is 128 opaque bytes that rank 0 makes and every rank needs): rank 0 writes
 // `path` atomically, the others wait for it.  device -1 = current.
-inline csdr_comm *commFromIdFile(const std::string &path, int rank, int world, int device = -1)
+// The file is  "CSDRID01" | uint64 nonce | id : a waiting rank accepts it only when the nonce is its own run's, so the id a crashed
+// earlier run left behind under the same path is never taken for this run's (ranks with different ids would block in
+// ncclCommInitRank for ever).  nonce 0 = the launcher's pid (getppid(): the ranks of one run are children of one launcher); pass an
+// explicit one (soapy_sdr_file --id-nonce N, a launcher pid or a timestamp) when the ranks do not share a parent.  Rank 0 removes
+// the file once csdr_comm_create has returned -- that call is collective, so every rank has read the id by then.
+inline uint64_t commRunNonce(uint64_t nonce) { return nonce ? nonce : (uint64_t)getppid(); }
+inline bool commReadIdFile(const std::string &path, uint64_t nonce, unsigned char *id)
+{
+    unsigned char rec[16 + CSDR_COMM_ID_BYTES];
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    const size_t got = std::fread(rec, 1, sizeof rec, f);
+    std::fclose(f);
+    uint64_t have = 0;
+    if (got != sizeof rec || std::memcmp(rec, "CSDRID01", 8) != 0) return false;
+    std::memcpy(&have, rec + 8, 8);
+    if (have != nonce) return false;                       // another run's id (stale file): keep waiting for ours
+    std::memcpy(id, rec + 16, CSDR_COMM_ID_BYTES);
+    return true;
+}
+inline void commWriteIdFile(const std::string &path, uint64_t nonce, const unsigned char *id)
+{
+    unsigned char rec[16 + CSDR_COMM_ID_BYTES];
+    std::memcpy(rec, "CSDRID01", 8);
+    std::memcpy(rec + 8, &nonce, 8);
+    std::memcpy(rec + 16, id, CSDR_COMM_ID_BYTES);
+    std::remove(path.c_str());                             // a stale id must not be readable while ours is being written
+    const std::string tmp = path + ".tmp";
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    const bool ok = f && std::fwrite(rec, 1, sizeof rec, f) == sizeof rec;
+    if (f) std::fclose(f);
+    if (!ok) throw std::runtime_error("cannot write " + tmp);
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+}
+inline csdr_comm *commFromIdFile(const std::string &path, int rank, int world, int device = -1, uint64_t nonce = 0)
 {
     unsigned char id[CSDR_COMM_ID_BYTES];
+    nonce = commRunNonce(nonce);
     if (rank == 0) {
         check(csdr_comm_unique_id(id));
-        const std::string tmp = path + ".tmp";
-        FILE *f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) throw std::runtime_error("cannot write " + tmp);
-        std::fclose(f);
-        if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("cannot rename " + tmp);
+        commWriteIdFile(path, nonce, id);
     } else {
-        for (int tries = 0;; tries++) {
-            FILE *f = std::fopen(path.c_str(), "rb");
-            size_t got = 0;
-            if (f) { got = std::fread(id, 1, sizeof id, f); std::fclose(f); }
-            if (got == sizeof id) break;
-            if (tries > 6000) throw std::runtime_error("no communicator id in " + path + " after 60 s");
+        for (int tries = 0; !commReadIdFile(path, nonce, id); tries++) {
+            if (tries > 6000) throw std::runtime_error("no communicator id of this run (nonce " + std::to_string(nonce) + ") in " + path + " after 60 s");
             struct timespec ts = {0, 10 * 1000 * 1000};
             nanosleep(&ts, nullptr);
         }
     }
     csdr_comm *c = nullptr;
-    check(csdr_comm_create(rank, world, id, device, &c));
+    const int rc = csdr_comm_create(rank, world, id, device, &c);
+    if (rank == 0) std::remove(path.c_str());              // every rank has joined (or the create failed): the id is spent
+    check(rc);
     return c;
 }
 

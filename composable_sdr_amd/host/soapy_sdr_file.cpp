@@ -1,7 +1,7 @@
 // soapy-sdr's file-input mode (apps/SoapySDR.hs:181-283) on the C-ABI chain:
 //   soapy_sdr_file --filename in.cf32 -n N -c M [--demod DeNo|DeNBFM kf|DeWBFM decim|DeAM] [-a dB] [-m] [-o output] [--chunksize 1024]
 //                  [-s samplerate] [-b bandwidth] [--offset Hz] [--audio AU|WAV]
-//                  [--world W --rank R --id-file PATH [--device D]]
+//                  [--world W --rank R --id-file PATH [--id-nonce N] [--device D]]
 // --world W: one process per GPU, each reading the same file; process R owns the channels R, R + W, ... (interleaved channel shard,
 // SURVEY 8e(A)) and writes only their <out>_ch<k+1> files (SoapySDR.hs:209-212); with --mix the partial sums of the W processes meet
 // in one RCCL all-reduce per chunk (csdr_chain_process_mix) and process 0 writes the one mixed file (SoapySDR.hs:217-222).
@@ -77,7 +77,7 @@ int main(int argc, char **argv)
     std::string in, out = "output", demod = "DeNo";
     ChainOpts o; o.flags = 0;
     size_t n = 1024, chunk = 1024;
-    std::string id_file; int device = -1;
+    std::string id_file; int device = -1; uint64_t id_nonce = 0;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::cerr << "missing value for " << a << "\n"; std::exit(2); } return argv[++i]; };
@@ -95,6 +95,7 @@ int main(int argc, char **argv)
         else if (a == "--world") o.world = (uint32_t)std::atoi(next());
         else if (a == "--rank") o.rank = (uint32_t)std::atoi(next());
         else if (a == "--id-file") id_file = next();
+        else if (a == "--id-nonce") id_nonce = std::strtoull(next(), nullptr, 10);
         else if (a == "--device") device = std::atoi(next());
         else if (a == "--demod") { demod = next(); if (demod == "DeNBFM") { o.fm = true; o.kf = (float)std::atof(next()); } else if (demod == "DeAM") o.am = true; else if (demod == "DeWBFM") { o.wbfm = true; o.decim = (uint32_t)std::atoi(next()); } }
         else { std::cerr << "unknown option " << a << "\n"; return 2; }
@@ -107,7 +108,7 @@ int main(int argc, char **argv)
         o.device = device;
         // the communicator exists only where the path has an exchange step: --mix over channel shards (also a world of one, which
         // then runs the same C entry points)
-        if (o.mix && o.channels > 1 && !id_file.empty()) o.comm = commFromIdFile(id_file, (int)o.rank, (int)o.world, device);
+        if (o.mix && o.channels > 1 && !id_file.empty()) o.comm = commFromIdFile(id_file, (int)o.rank, (int)o.world, device, id_nonce);
         if (o.wbfm) o.deemph_fc = (float)(5000.0 / (g_front.bandwidth != 0.0 ? g_front.bandwidth : g_front.samplerate));
         const int rc = (o.fm || o.am || o.wbfm) ? run<float>(in, o, n, out, chunk, ".f32") : run<cf32>(in, o, n, out, chunk, ".cf32");
         if (o.comm) check(csdr_comm_destroy(o.comm));

@@ -38,6 +38,21 @@ int main()
         assert(t.feed(b) && b.size() == 2);
         assert(!t.feed(c));
     }
+    {   // communicator bootstrap file: another run's id (stale file, other nonce), a short file and a foreign file are not accepted
+        const std::string path = "/tmp/csdr_test_host_" + std::to_string((long)getpid()) + ".id";
+        unsigned char id[CSDR_COMM_ID_BYTES], got[CSDR_COMM_ID_BYTES];
+        for (size_t i = 0; i < sizeof id; i++) id[i] = (unsigned char)(i * 7 + 1);
+        commWriteIdFile(path, 41, id);
+        assert(!commReadIdFile(path, 42, got));                       // the previous run's
+        assert(commReadIdFile(path, 41, got) && std::memcmp(id, got, sizeof id) == 0);
+        commWriteIdFile(path, 42, id);                                // rank 0 of the new run replaces it
+        assert(commReadIdFile(path, 42, got) && !commReadIdFile(path, 41, got));
+        { FILE *f = std::fopen(path.c_str(), "wb"); std::fwrite(id, 1, sizeof id, f); std::fclose(f); }     // round 5's format: 128 bare bytes
+        assert(!commReadIdFile(path, 42, got));
+        std::remove(path.c_str());
+        assert(!commReadIdFile(path, 42, got));
+        assert(commRunNonce(0) == (uint64_t)getppid() && commRunNonce(9) == 9);
+    }
     {   // mix = left fold (Trans.hs:119-122)
         std::vector<Array<float>> ch = {{1e8f, 1.f}, {-1e8f, 1.f}, {1.f, 1.f}};
         auto m = mix(ch);

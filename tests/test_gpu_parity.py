@@ -827,12 +827,20 @@ def test_bench_channel_shard_two_ranks_one_gpu(shard, mix):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["rccl_ranks"] == 2 and r["value"] > 0
     assert r["cold_window"]["value"] > 0 and r["sustained_long"]["seconds"] >= 0.25 and r["sustained_long"]["value"] > 0
-    assert r["roofline"]["launches"] == 3 and r["roofline"]["launch_ms"] > 0
+    # the roofline figure is the sustained run's launch cadence (hipEvents around that run), the K-step window and the event pairs sit beside it
+    rf = r["roofline"]
+    assert rf["launches_event_pairs"] == 3 and rf["launch_ms"] > 0 and rf["launches"] == r["sustained_long"]["launches"] >= 10
+    assert "sustained_long" in rf["launch_ms_source"] and rf["frac_k_step_window"] > 0 and rf["frac_event_pairs"] > 0
+    assert abs(rf["launch_ms"] - r["sustained_long"]["launch_ms_events"]) < 1e-9
+    assert r["value_sustained"] == r["sustained_long"]["value"]
+    # which partition `value` is: the FIRST key of config, inside the first 120 characters of its text
+    assert list(r["config"])[0] == "sharding"
     if shard == "channel":
-        assert r["scaling"] == "strong" and "channel-interleaved" in r["config"]["sharding"] and "interleaved-shard" in r["config"]["route"]
-        assert ("all-reduce" in r["config"]["collective"]) == mix
+        assert r["scaling"] == "strong" and r["config"]["sharding"].startswith("channel shards (north_star's partition)") and "interleaved-shard" in r["config"]["route"]
+        assert ("all-reduce" in r["config"]["collective"]) == mix and ("all-reduce" in r["config"]["sharding"]) == mix
     else:
-        assert r["scaling"] == "weak" and "time stripes" in r["config"]["sharding"] and r["config"]["collective"] == "none"
+        assert r["scaling"] == "weak" and r["config"]["sharding"].startswith("independent time stripes, no collective") and r["config"]["collective"] == "none"
+        assert "value_channel_shard" in r["config"]["sharding"]
         # the default partition's line also carries north_star's partition, measured in the same run
         cs2 = r["channel_shard"]
         assert cs2["value"] > 0 and cs2["scaling"] == "strong" and "channel-interleaved" in cs2["sharding"] and cs2["rccl_ranks"] == 2
@@ -864,8 +872,13 @@ def test_bench_side_measurements_cannot_cost_the_line():
     lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
     assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
     r = json.loads(lines[0])
-    assert r["n_gpus"] == 2 and r["value"] > 0 and r["roofline"]["launches"] == 3 and r["sustained_long"]["value"] > 0
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["roofline"]["launches_event_pairs"] == 3 and r["sustained_long"]["value"] > 0
     assert "did not finish" in r["side_error"] and "channel_shard" not in r and "hybrid" not in r
+    assert "side measurements failed" in p.stderr
+    # a CI that wants a hung side path to fail the job asks for it: the line is still printed, the status is 3
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(env, CSDR_BENCH_SIDE_STRICT="1"), cwd=root)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert p.returncode != 0 and len(lines) == 1 and "side_error" in json.loads(lines[0]), p.stderr[-2000:]
 
 
 def test_seek_frames_sets_premix_phase():
@@ -1076,7 +1089,13 @@ def test_cpp_soapy_sdr_file_channel_shards_and_mix_through_the_c_collectives(tmp
     r = subprocess.run(base + ["-m", "-o", str(tmp_path / "mix1"), "--world", "1", "--rank", "0", "--id-file", str(tmp_path / "id.bin")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert os.path.getsize(tmp_path / "id.bin") == 128
+    assert not os.path.exists(tmp_path / "id.bin")          # rank 0 removes the id once every rank has joined: nothing stale for the next run
+    # a stale id of an earlier (crashed) run under the same path is replaced, not read: the run still succeeds
+    (tmp_path / "id.bin").write_bytes(b"CSDRID01" + (12345).to_bytes(8, "little") + bytes(128))
+    r = subprocess.run(base + ["-m", "-o", str(tmp_path / "mix2"), "--world", "1", "--rank", "0", "--id-file", str(tmp_path / "id.bin"), "--id-nonce", "777"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert not os.path.exists(tmp_path / "id.bin")
     a, b = np.fromfile(tmp_path / "mix0.f32", dtype=np.float32), np.fromfile(tmp_path / "mix1.f32", dtype=np.float32)
     assert a.size == n // M and np.array_equal(a.view(np.uint32), b.view(np.uint32))
     # a sharded --mix without its bootstrap is refused
@@ -2272,6 +2291,9 @@ def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod, a
         if M == 256:                                     # the run-sized calls went through the fused shard kernel itself
             kwant = f"k_run256v2<{'FM' if (demod == 'fm' and not agc) else 'CF32'}>/G{G}"
             assert [knames[i] for i in (0, 3, 5, 6)] == [kwant] * 4, (knames, kwant)
+        elif demod == "fm" and not agc:                  # M = 1024: the run-sized calls of whole 4-frame tiles (12288, 12292, 8192 frames)
+            assert [knames[i] for i in (0, 3, 6)] == [f"k_run1024v2<FM>/G{G}"] * 3, knames
+            assert knames[5] == "k_run1024<FM>", knames   # 12289 frames: ragged -> whole band + row gather
         want = wf[g::G]
         assert got.shape == want.shape
         if agc:
@@ -2300,26 +2322,36 @@ def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod, a
             assert e < 2e-6, e
 
 
-def test_fused_interleaved_shard_run_sized_call_matches_oracle_rows():
+@pytest.mark.parametrize("M,nf,cases", [
+    (256, 40000, [(8, 3, "fm"), (2, 1, "none"), (4, 2, "fm")]),
+    # BASELINE configs[3] per rank: 1024 channels split over 8 GPUs, rank g owns g, g + 8, ... (Trans.hs:124-129, SoapySDR.hs:223-225)
+    (1024, 12288, [(8, 0, "fm"), (8, 3, "fm"), (8, 7, "fm"), (2, 1, "fm"), (4, 2, "fm")]),
+])
+def test_fused_interleaved_shard_run_sized_call_matches_oracle_rows(M, nf, cases):
     """One run-sized call of the fused shard kernels compared DIRECTLY with the oracle (not with the whole-band kernel):
-    k_run256v2<FM, 8> and k_run256v2<CF32, 2> on 40 000 frames x 256 channels against O.Chain(...)[g::G]; the kernel name is
-    taken from the launch timer, as the bench-layout tests do."""
+    k_run256v2<FM, 8> / k_run256v2<CF32, 2> on 40 000 frames x 256 channels, and k_run1024v2<FM, G> -- the kernel a rank of
+    BASELINE configs[3] runs -- on 12 288 frames x 1024 channels, against O.Chain(...)[g::G] with the tolerances of the
+    whole-band bench-layout tests (_fm_against_oracle); the kernel name is taken from the launch timer, so a silent change
+    of route fails the test."""
     import torch
     from composable_sdr_amd import _lib
     from synth import synth_cf32_torch
-    M, nf, kf = 256, 40000, 0.3
+    kf = 0.3
     x = synth_cf32_torch(M * nf, M, torch.device("cuda", 0), seed=611).cpu().numpy().view(np.complex64).reshape(-1)
     w_fm = O.Chain(M, demod="fm", kf=kf).process(x)
     w_cf = O.Chain(M).process(x)
     r = np.abs(w_cf)
-    for G, g, demod in [(8, 3, "fm"), (2, 1, "none"), (4, 2, "fm")]:
+    fam = "k_run256v2" if M == 256 else "k_run1024v2"
+    for G, g, demod in cases:
         ch = cs.Chain(channels=M, demod=demod, kf=kf, chan_first=g, chan_stride=G, max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
+        assert "interleaved-shard" in ch.path
         got = ch.process(x)
         kname = ch.kernel_time()[0]
         ch.close()
-        assert kname == f"k_run256v2<{'FM' if demod == 'fm' else 'CF32'}>/G{G}", kname
+        assert kname == f"{fam}<{'FM' if demod == 'fm' else 'CF32'}>/G{G}", kname
         if demod == "fm":
             want, rr = w_fm[g::G], r[g::G]
+            assert got.shape == want.shape == (M // G, nf)
             d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
             rmin = np.minimum(rr, np.concatenate([np.zeros((rr.shape[0], 1), rr.dtype), rr[:, :-1]], axis=1))
             ref = 1.0 / (2 * np.pi * kf)
