@@ -636,7 +636,8 @@ const RouteRow ROUTES[] = {
      "k_run64<CF32> -> k_agc_spec -> k_agc_fix [-> k_mix]"},
     {1024, ST1 | ST2 | ST4 | ST8, PLAN_BIG1024, "fused-k_run1024",
      "k_run1024v3<FM | CF32> (whole band, calls of whole 4-frame tiles; a call that ends inside a 128-byte line stores the front part of it); "
-     "k_run1024v2<FM, G> (interleaved shards G = 2, 4, 8, FM output, run-sized calls of whole tiles)",
+     "k_shard1024<FM | CF32, G> (interleaved shards G = 4, 8: fold of the aliasing branches behind the FIR + a (1024 / G)-point DFT across the lanes; run-sized calls of whole tiles); "
+     "k_run1024v2<FM, 2> (interleaved shards G = 2, FM output)",
      "k_run1024<FM | CF32> (ragged calls, contiguous shards, the other calls of interleaved shards) [+ k_pfb1024_fixup, k_shard_gather1024]", "k_run1024v3<CF32> -> CF32 plane (tile-major) -> k_agc_spec_tm | k_run1024<CF32> -> k_agc_spec; -> k_agc_fix [-> k_mix]"},
     {4096, ST1, PLAN_HUGE4096, "fused-4096",
      "k_front4096 (DC blocker + pre-mix + FIR, branch-tiled: four sibling workgroups per frame, radix-4 split of the DFT on the registers) -> z (8 B / sample) "

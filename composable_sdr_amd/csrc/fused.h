@@ -136,6 +136,10 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
 // 35 behind the cold start: alpha |c| beta^35840 = 1.6e-8 alpha |c| of the missing state is left in it (with four tiles it was 5.9e-5:
 // ~1e-5 of a unit signal at the strongest DC offset the tests use)
 constexpr int RUN1024_DCFIX_F = 33;
+// interleaved-shard run kernel (kernels_shard1024.hip, round 6): chan_stride G = 4, 8, F32 or CF32 rows of the owned channels; the fold of the
+// aliasing branches behind the FIR + a (1024 / G)-point DFT across the lanes of a wave; same state arrays and tables as the plan's other kernels
+uint32_t shard1024_runs(uint32_t nf, bool fm, uint32_t G, uint32_t cus);    // 0: the call is not for this kernel
+int shard1024_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_t s, KernelTimer *timer);
 uint32_t run1024_v3_runs(uint32_t nf, bool fm, uint32_t cus);    // 0: the call is not for this kernel
 int run1024_v3_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_t s, KernelTimer *timer);
 

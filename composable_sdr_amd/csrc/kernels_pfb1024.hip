@@ -461,6 +461,7 @@ struct BigPlan {
     float4 *d_taps_t = nullptr, *d_taps_q = nullptr;
     bool v3_ok = false, v3_last = false;      // k_run1024v3 (FM, whole band) selected; used by the last call
     bool v2_ok = false, v2_last = false;      // k_run1024v2 usable (whole band, not disabled); used by the last call
+    bool s1_ok = false, s1_last = false;      // k_shard1024<.., G> usable (interleaved shard, G = 4, 8); used by the last call
     float2 *d_tw = nullptr, *d_wpre = nullptr;
     float2 *d_uhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
     float2 *d_scratch = nullptr;     // yfirst | ylast
@@ -554,7 +555,9 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         p->v3_ok = cfg.c0 == 0 && cfg.C == (uint32_t)PM && cfg.G == 1 && !diag_env("CSDR_RUN1024_V1") && !(diag_env("CSDR_RUN1024_V3") && atoi(diag_env("CSDR_RUN1024_V3")) == 0);
         if (cfg.G > 1) p->v2_ok = cfg.fm && !diag_env("CSDR_RUN1024_V1");       // k_run1024v2<FM, G>; CF32 shards: whole band + row gather (below)
         // until the first call: the kernel a call of max_nf frames would take (csdr_chain_path names it)
-        p->v2_last = p->v2_ok && (cfg.max_nf & 3u) == 0 && run1024_v2_runs(cfg.max_nf, p->cus) != 0;
+        p->s1_ok = (cfg.G == 4 || cfg.G == 8) && !diag_env("CSDR_RUN1024_V1");      // k_shard1024<FM | CF32, G>: every run-sized call of whole tiles
+        p->s1_last = p->s1_ok && shard1024_runs(cfg.max_nf, cfg.fm, cfg.G, p->cus) != 0;
+        p->v2_last = !p->s1_last && p->v2_ok && (cfg.max_nf & 3u) == 0 && run1024_v2_runs(cfg.max_nf, p->cus) != 0;
         p->v3_last = p->v3_ok && run1024_v3_runs(cfg.max_nf, cfg.fm, p->cus) != 0;
         if (p->v3_last) p->v2_last = false;
     }
@@ -592,6 +595,7 @@ void big_seek(BigPlan *p, uint64_t frames) { p->frames_done = frames; }
 const char *big_name(const BigPlan *p)
 {
     if (p->v3_last) return p->cfg.fm ? "k_run1024v3<FM>" : "k_run1024v3<CF32>";
+    if (p->s1_last) return p->cfg.fm ? (p->cfg.G == 8 ? "k_shard1024<FM>/G8" : "k_shard1024<FM>/G4") : (p->cfg.G == 8 ? "k_shard1024<CF32>/G8" : "k_shard1024<CF32>/G4");
     if (p->v2_last) return p->cfg.G == 8 ? "k_run1024v2<FM>/G8" : p->cfg.G == 4 ? "k_run1024v2<FM>/G4" : p->cfg.G == 2 ? "k_run1024v2<FM>/G2" : "k_run1024v2<FM>";
     return p->cfg.fm ? "k_run1024<FM>" : "k_run1024<CF32>";
 }
@@ -607,13 +611,15 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     const uint32_t nf = call.nf;
     if (!nf) return 0;
     int r;
-    const uint32_t v2runs = (p->v2_ok && (nf & 3u) == 0 && (uint64_t)nf * 8192u < (1ull << 31)) ? run1024_v2_runs(nf, p->cus) : 0;
+    const uint32_t s1runs = (p->s1_ok && !call.tile_major) ? shard1024_runs(nf, c.fm, c.G, p->cus) : 0;
+    p->s1_last = s1runs != 0;
+    const uint32_t v2runs = (!s1runs && p->v2_ok && (nf & 3u) == 0 && (uint64_t)nf * 8192u < (1ull << 31)) ? run1024_v2_runs(nf, p->cus) : 0;
     p->v2_last = v2runs != 0;
     if (call.tile_major && !big_tile_major_ok(p, nf)) { set_error("big_process: tile-major output asked for a call k_run1024v3<CF32> does not take"); return CSDR_ERR_INVALID; }
     const uint32_t v3runs = (p->v3_ok && (uint64_t)nf * 8192u < (1ull << 31)) ? run1024_v3_runs(nf, c.fm, p->cus) : 0;
     p->v3_last = v3runs != 0;
     if (v3runs) p->v2_last = false;
-    if (v2runs || v3runs) {
+    if (v2runs || v3runs || s1runs) {
         Run1024v2Host H{};
         H.x = call.d_in; H.out = c.mix ? p->d_premix : call.d_out; H.taps_q = p->d_taps_q; H.tw = p->d_tw;
         H.uhist_in = p->d_uhist[p->cur]; H.uhist_out = p->d_uhist[p->cur ^ 1];
@@ -625,7 +631,8 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.tile_major = call.tile_major && v3runs && !c.fm;
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
         if (v3runs) { H.cpre = p->d_cpre; H.side = p->d_side; H.rt = v3runs <= p->cus ? p->d_rt : nullptr; }
-        if (v3runs) { if ((r = run1024_v3_launch(H, c.fm, v3runs, s, timer))) return r; }
+        if (s1runs) { if ((r = shard1024_launch(H, c.fm, s1runs, s, timer))) return r; }
+        else if (v3runs) { if ((r = run1024_v3_launch(H, c.fm, v3runs, s, timer))) return r; }
         else if ((r = run1024_v2_launch(H, c.fm, s, timer))) return r;
         p->cur ^= 1;
         p->frames_done += nf;

@@ -2255,7 +2255,8 @@ def test_submit_device_independent_launches_match_serial_calls(demod):
 
 
 @pytest.mark.parametrize("M,G,demod,agc", [(256, 2, "fm", 0.0), (256, 4, "none", 0.0), (256, 8, "fm", 0.0), (256, 8, "none", 0.0), (1024, 8, "fm", 0.0), (1024, 2, "fm", 0.0),
-                                           (1024, 4, "none", 0.0), (256, 8, "fm", 10.0), (256, 2, "fm", 10.0)])
+                                           (1024, 4, "none", 0.0), (1024, 4, "fm", 0.0), (1024, 8, "none", 0.0), (1024, 8, "fm", 10.0),
+                                           (256, 8, "fm", 10.0), (256, 2, "fm", 10.0)])
 def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod, agc):
     """k_run256v2<.., G> at run-kernel sizes (many runs with cold starts, paired F32 stores, ragged and tiny calls in between,
     state carried from call to call): every shard g must reproduce the rows g, g + G, ... of the whole-band fused chain on the
@@ -2291,9 +2292,10 @@ def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod, a
         if M == 256:                                     # the run-sized calls went through the fused shard kernel itself
             kwant = f"k_run256v2<{'FM' if (demod == 'fm' and not agc) else 'CF32'}>/G{G}"
             assert [knames[i] for i in (0, 3, 5, 6)] == [kwant] * 4, (knames, kwant)
-        elif demod == "fm" and not agc:                  # M = 1024: the run-sized calls of whole 4-frame tiles (12288, 12292, 8192 frames)
-            assert [knames[i] for i in (0, 3, 6)] == [f"k_run1024v2<FM>/G{G}"] * 3, knames
-            assert knames[5] == "k_run1024<FM>", knames   # 12289 frames: ragged -> whole band + row gather
+        elif not agc:                                    # M = 1024: the run-sized calls of whole 4-frame tiles (12288, 12292, 8192 frames)
+            kwant = f"k_shard1024<{'FM' if demod == 'fm' else 'CF32'}>/G{G}" if G >= 4 else ("k_run1024v2<FM>/G2" if demod == "fm" else "k_run1024<CF32>")
+            assert [knames[i] for i in (0, 3, 6)] == [kwant] * 3, knames
+            assert knames[5] == f"k_run1024<{'FM' if demod == 'fm' else 'CF32'}>", knames   # 12289 frames: ragged -> whole band + row gather
         want = wf[g::G]
         assert got.shape == want.shape
         if agc:
@@ -2325,7 +2327,7 @@ def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod, a
 @pytest.mark.parametrize("M,nf,cases", [
     (256, 40000, [(8, 3, "fm"), (2, 1, "none"), (4, 2, "fm")]),
     # BASELINE configs[3] per rank: 1024 channels split over 8 GPUs, rank g owns g, g + 8, ... (Trans.hs:124-129, SoapySDR.hs:223-225)
-    (1024, 12288, [(8, 0, "fm"), (8, 3, "fm"), (8, 7, "fm"), (2, 1, "fm"), (4, 2, "fm")]),
+    (1024, 12288, [(8, 0, "fm"), (8, 3, "fm"), (8, 7, "fm"), (2, 1, "fm"), (4, 2, "fm"), (8, 5, "none"), (4, 1, "none")]),
 ])
 def test_fused_interleaved_shard_run_sized_call_matches_oracle_rows(M, nf, cases):
     """One run-sized call of the fused shard kernels compared DIRECTLY with the oracle (not with the whole-band kernel):
@@ -2341,8 +2343,9 @@ def test_fused_interleaved_shard_run_sized_call_matches_oracle_rows(M, nf, cases
     w_fm = O.Chain(M, demod="fm", kf=kf).process(x)
     w_cf = O.Chain(M).process(x)
     r = np.abs(w_cf)
-    fam = "k_run256v2" if M == 256 else "k_run1024v2"
     for G, g, demod in cases:
+        # M = 1024: strides 4 and 8 run k_shard1024 (round 6: fold behind the FIR + short DFT across the lanes), stride 2 keeps k_run1024v2
+        fam = "k_run256v2" if M == 256 else ("k_shard1024" if G >= 4 else "k_run1024v2")
         ch = cs.Chain(channels=M, demod=demod, kf=kf, chan_first=g, chan_stride=G, max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
         assert "interleaved-shard" in ch.path
         got = ch.process(x)
