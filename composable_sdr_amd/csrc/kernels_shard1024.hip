@@ -17,14 +17,15 @@
 //   (v3: 72 KiB of L2 reads per 32 KiB tile).  A step = one tile of 4 frames, two workgroup barriers:
 //
 //     bar P  ------------------------------------------------------------------------------------------------------------------------
-//            waves 0-3 (rho = 0): DC scan of tile s                       waves 4-7 (rho = 1): freqdem + row stores of tile s - 2;
-//            (raw image -> y', 16 group totals)                           DMA of tile s + 2; fold + pruned DFT of tile s - 1 (wave f = frame f)
+//            waves 0-3 (rho = 0): DC scan of tile s (raw image -> y',     waves 4-7 (rho = 1): DMA of tile s + 2 (pieces between the DFT's stages);
+//            16 group totals); freqdem + row stores of tile s - 2         fold + pruned DFT of tile s - 1 (wave f = frame f)
 //     bar Q  ------------------------------------------------------------------------------------------------------------------------
 //            all eight waves: column layout + group carries, pre-mix, FIR of the own two branches, their sum (G >= 4: both alias onto
 //            the same n1) -> partial folds P[part][f][n1] in LDS
 //
 //   The pruned DFT runs ACROSS THE LANES of a wave: lane l holds Z[l + 64 a], a < NP / 64; a radix-(NP/64) step on the registers, then six
-//   radix-2 decimation-in-frequency stages whose partner values come through ds_bpermute (no LDS image, no barrier); lane l ends up with
+//   radix-2 decimation-in-frequency stages whose partner values come through DPP row operations (distances 1 .. 8), ds_swizzle (16) and
+//   ds_bpermute (32) (no LDS image, no barrier); lane l ends up with
 //   the bins a' + (NP/64) bitrev6(l), stored as one 16-byte piece per pair.  The tail thread m = channel g + G m reads its four frames,
 //   freqdem against the stash (fm_quad), one 16-byte store per tile and row: 128 rows x 256 runs keep 4 MiB of 128-byte lines open (G = 8),
 //   which the L2s hold.
@@ -36,6 +37,10 @@
 // (FM) the muted tile in front of the run for the freqdem history.
 #include "fused_v2_common.h"
 #include <type_traits>
+
+#ifndef S1_TRACE
+#define S1_TRACE 0       // 1: s_memtime stamps of run 1's wave 0 (role 0) / wave 4 (role 1) per phase, written to Shard1024Args::trace (CSDR_SHARD1024_TRACE=file)
+#endif
 
 namespace csdr {
 namespace {
@@ -71,7 +76,23 @@ struct Shard1024Args {
     float b16[16];              // beta^(16 r)
     float b256[17];             // beta^(256 g)
     PhaseK pk;
+    unsigned long long *trace;  // debug (S1_TRACE build): [role][step < 96][4] stamps
 };
+
+// value of lane l ^ D: DPP inside a row of 16 lanes (no LDS latency), ds_swizzle across the rows of a half, ds_bpermute across the halves
+template <int D> __device__ __forceinline__ float lane_xor(float x)
+{
+    const int v = __float_as_int(x);
+    if (D == 1) return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));        // quad_perm [1,0,3,2]
+    if (D == 2) return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));        // quad_perm [2,3,0,1]
+    if (D == 4) {
+        const int a = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xf, 0x5, false);                        // row_shl:4 into the banks 0, 2 (lane i <- i + 4)
+        return __int_as_float(__builtin_amdgcn_update_dpp(a, v, 0x114, 0xf, 0xA, false));               // row_shr:4 into the banks 1, 3 (lane i <- i - 4)
+    }
+    if (D == 8) return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));        // row_ror:8
+    if (D == 16) return __int_as_float(__builtin_amdgcn_ds_swizzle(v, 0x401F));                         // bit-mask mode: xor 16 inside 32 lanes
+    return __shfl_xor(x, 32);
+}
 
 // run w: whole blocks of TB tiles (a row's 128-byte line), evenly; the call's last block may be a partial one
 __host__ __device__ __forceinline__ void shard_bounds(uint32_t nb, uint32_t nruns, unsigned w, unsigned TB, unsigned &first, unsigned &last)
@@ -90,6 +111,7 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
     constexpr unsigned TB = FM ? 8u : 4u;
     __shared__ __attribute__((aligned(16))) float2 L[K::F2];
     float2 *Pb = L + K::PB, *Yb = L + K::YB, *ST = L + K::ST, *Tt = L + K::TT, *red = L + K::RED;
+    __shared__ unsigned long long trc[S1_TRACE ? 768 : 1];
     const int tid = threadIdx.x;
     const int rho = __builtin_amdgcn_readfirstlane(tid >> 8);          // wave-uniform role
     const int lt = tid & 255, j = lt;
@@ -186,8 +208,9 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
         tws[i] = (l6 & d) ? (v2f){t.x, t.y} : (v2f){1.f, 0.f};
     }
 
-    if (rho) {                                          // freqdem history of the owned channels
+    if (!rho) {                                         // freqdem history of the owned channels (the tail runs on the waves of role 0, behind the scan)
         for (int m = lt; m < NP; m += 256) ST[m] = (FM && w == 0) ? A.rp_in[G * m] : make_float2(0.f, 0.f);
+    } else {
         // the first image has landed (hipcc's own waits do not know about an asm DMA)
         if (AHEAD >= 2 && n_items > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -229,7 +252,10 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
         const unsigned bi = (unsigned)__builtin_amdgcn_readfirstlane((int)(s % (unsigned)NBUF));
         char *B = reinterpret_cast<char *>(L) + bi * (S1_BUF * 8u);           // item s's buffer
         float2 *Bf = reinterpret_cast<float2 *>(B);
+        const bool tr = S1_TRACE && A.trace && w == 1 && (tid & 255) == 0 && s < 96;
+        unsigned long long *tq = trc + 384 * rho + 4 * s;
         bar();                                          // P: the partial folds of item s - 1 and Y of item s - 2 are complete; image s has landed
+        if (tr) tq[0] = __builtin_amdgcn_s_memtime();
         if (!rho) {
             if (have) {
                 // ---- DC blocker inside a 256-sample group: thread q owns the run of 16 consecutive samples q (as k_run256v2)
@@ -261,7 +287,6 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                     *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = y;
                 }
             }
-        } else {
             // ---- tail of item s - 2: thread m = owned channel m (global channel g + G m): its four frames, freqdem against the stash, one
             // 16-byte (F32) / two 16-byte (CF32) stores into row m
             if (s >= 2 + nwarm && s - 2 < n_items) {
@@ -286,11 +311,13 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                     }
                 }
             }
-            asm volatile("" ::: "memory");
-            // ---- image s + AHEAD into the buffer item s - 1 left at barrier P
-            if (s + AHEAD < n_items)
-                dma_tile(x4 + (size_t)(tile_begin + s + AHEAD) * 2048, goff, lds_wave + (unsigned)((s + AHEAD) % (unsigned)NBUF) * (S1_BUF * 8u));
-            asm volatile("" ::: "memory");
+        } else {
+            // ---- image s + AHEAD into the buffer item s - 1 left at barrier P: two pieces here, the others between the stages of the DFT (the CU's
+            // address unit takes 16 cycles per 1 KiB instruction: eight in a row stall the wave for ~800)
+            const bool dma = s + AHEAD < n_items;
+            const float4 *dsrc = x4 + (size_t)(tile_begin + s + AHEAD) * 2048;
+            const unsigned ddst = lds_wave + (unsigned)((s + AHEAD) % (unsigned)NBUF) * (S1_BUF * 8u);
+            if (dma) { dma_piece(dsrc, goff, ddst, 0); dma_piece(dsrc, goff, ddst, 1); }
             // ---- fold + pruned DFT of item s - 1: wave f = frame f, lane l holds Z[l + 64 a]
             if (s >= 1 + nwarm && s - 1 < n_items) {
                 const int f = (int)wave_u;
@@ -311,26 +338,39 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                     for (int k = 1; k < PPL; k++) z[k] = cmul_v(z[k], tw0[k]);
                 }
                 // six radix-2 stages across the lanes: partner l ^ d; lower lane x + p, upper lane (p - x) W_2d^(l & (d - 1))
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const int d = 32 >> i;
-                    const unsigned sgn = (l6 & d) ? 0x80000000u : 0u;
+                auto stage = [&](auto dc, const int i) {
+                    constexpr int D = decltype(dc)::value;
+                    const unsigned sgn = (l6 & D) ? 0x80000000u : 0u;
 #pragma unroll
                     for (int k = 0; k < PPL; k++) {
-                        const v2f p = {__shfl_xor(z[k].x, d), __shfl_xor(z[k].y, d)};
+                        const v2f p = {lane_xor<D>(z[k].x), lane_xor<D>(z[k].y)};
                         const v2f xs = {__uint_as_float(__float_as_uint(z[k].x) ^ sgn), __uint_as_float(__float_as_uint(z[k].y) ^ sgn)};
                         v2f y = p + xs;
-                        if (i < 5) y = cmul_v(y, tws[i]);
+                        if (D > 1) y = cmul_v(y, tws[i]);
                         z[k] = y;
                     }
-                }
+                };
+                stage(std::integral_constant<int, 32>(), 0);
+                if (dma) { dma_piece(dsrc, goff, ddst, 2); dma_piece(dsrc, goff, ddst, 3); }
+                stage(std::integral_constant<int, 16>(), 1);
+                if (dma) { dma_piece(dsrc, goff, ddst, 4); dma_piece(dsrc, goff, ddst, 5); }
+                stage(std::integral_constant<int, 8>(), 2);
+                if (dma) { dma_piece(dsrc, goff, ddst, 6); dma_piece(dsrc, goff, ddst, 7); }
+                stage(std::integral_constant<int, 4>(), 3);
+                stage(std::integral_constant<int, 2>(), 4);
+                stage(std::integral_constant<int, 1>(), 5);
                 // lane l holds the bins k + PPL bitrev6(l), k < PPL: contiguous
                 float2 *Yw = Yb + ((s + 1u) & 1u) * (4 * NP) + f * NP + PPL * br6;
                 *reinterpret_cast<v4f *>(Yw) = (v4f){z[0].x, z[0].y, z[1].x, z[1].y};
                 if (PPL == 4) *reinterpret_cast<v4f *>(Yw + 2) = (v4f){z[2].x, z[2].y, z[3].x, z[3].y};
+            } else if (dma) {
+#pragma unroll
+                for (int it = 2; it < 8; it++) dma_piece(dsrc, goff, ddst, it);
             }
         }
+        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq[1] = __builtin_amdgcn_s_memtime(); }
         bar();                                          // Q: y' (group carry still missing) and the group totals of item s are visible
+        if (tr) tq[2] = __builtin_amdgcn_s_memtime();
         if (have) {
             // ---- column layout: sample of frame f, branch j + 256 (2 rho + qp) -> ring slot 4 PH + f (f < 3) / n3 (f = 3); group state chain V[g] (uniform)
             float2 n3[2];
@@ -387,6 +427,7 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
             for (int qp = 0; qp < 2; qp++) ring[2 * ((4 * PH + 3) & 15) + qp] = n3[qp];
 #undef NW
         }
+        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq[3] = __builtin_amdgcn_s_memtime(); }
         if (rho) {
             // image s + 1 has landed: everything older than the eight DMA instructions of image s + 2 (when there is one)
             if (s + AHEAD < n_items) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -399,6 +440,7 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
         if (s0 + 2 < nsteps) step(s0 + 2, std::integral_constant<int, 2>());
         if (s0 + 3 < nsteps) step(s0 + 3, std::integral_constant<int, 3>());
     }
+    if (S1_TRACE && A.trace && w == 1) { __syncthreads(); for (int i = tid; i < 768; i += 512) A.trace[i] = trc[i]; }
     if (last == A.nb) {
         if (tid == 0) A.vend_out[0] = c;
         // the next call's window: frame -d behind the last item (phase (n_items - 1) & 3) sits in slot (4 (n_items & 3) - d) & 15
@@ -415,7 +457,7 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
         case 2: put(std::integral_constant<int, 2>()); break;
         default: put(std::integral_constant<int, 3>()); break;
         }
-        if (FM && rho) {                                // a thread reads back what it wrote
+        if (FM && !rho) {                               // a thread reads back what it wrote
             for (int m = lt; m < NP; m += 256) A.rp_out[G * m] = ST[m];
         }
     }
@@ -451,6 +493,10 @@ int shard1024_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_
     A.fm_ref = h.fm_ref; A.tiny = 1e-37f;
     A.pk = phase_consts(1.0f);                          // unscaled polynomial (fm_quad scales a = min / max by ref)
     A.pk.hp *= h.fm_ref; A.pk.pi *= h.fm_ref; A.pk.ref = h.fm_ref;
+    static const char *trace_file = S1_TRACE ? diag_env("CSDR_SHARD1024_TRACE") : nullptr;
+    static unsigned long long *d_trace = nullptr;
+    if (trace_file && !d_trace) CSDR_HIP(hipMalloc(&d_trace, 768 * sizeof(unsigned long long)));
+    if (trace_file) { CSDR_HIP(hipMemsetAsync(d_trace, 0, 768 * sizeof(unsigned long long), s)); A.trace = d_trace; }
     int r;
     if (timer && (r = timer->begin(s))) return r;
     if (h.G == 8) {
@@ -462,6 +508,12 @@ int shard1024_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_
     } else { set_error("k_shard1024: chan_stride %u is not built (4, 8)", h.G); return -1; }
     if (timer && (r = timer->end(s))) return r;
     CSDR_HIP(hipGetLastError());
+    if (trace_file) {                                   // debug: the last launch's stamps, raw uint64 [role][96][4]
+        std::vector<unsigned long long> hbuf(768);
+        CSDR_HIP(hipStreamSynchronize(s));
+        CSDR_HIP(hipMemcpy(hbuf.data(), d_trace, 768 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(trace_file, "wb")) { fwrite(hbuf.data(), sizeof(unsigned long long), hbuf.size(), f); fclose(f); }
+    }
     return 0;
 }
 
