@@ -602,6 +602,7 @@ const char *big_name(const BigPlan *p)
 
 bool big_tile_major_ok(const BigPlan *p, uint32_t nf)
 {
+    if (p && p->s1_ok) return !p->cfg.fm && !p->cfg.mix && nf % 16u == 0 && shard1024_runs(nf, false, p->cfg.G, p->cus) != 0;      // interleaved shard: k_shard1024<CF32, G>
     return p && p->v3_ok && !p->cfg.fm && !p->cfg.mix && nf % 16u == 0 && (uint64_t)nf * 8192u < (1ull << 31) && run1024_v3_runs(nf, false, p->cus) != 0;
 }
 
@@ -611,7 +612,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
     const uint32_t nf = call.nf;
     if (!nf) return 0;
     int r;
-    const uint32_t s1runs = (p->s1_ok && !call.tile_major) ? shard1024_runs(nf, c.fm, c.G, p->cus) : 0;
+    const uint32_t s1runs = p->s1_ok ? shard1024_runs(nf, c.fm, c.G, p->cus) : 0;
     p->s1_last = s1runs != 0;
     const uint32_t v2runs = (!s1runs && p->v2_ok && (nf & 3u) == 0 && (uint64_t)nf * 8192u < (1ull << 31)) ? run1024_v2_runs(nf, p->cus) : 0;
     p->v2_last = v2runs != 0;
@@ -628,7 +629,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.stage = p->d_stage;
         H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
         H.G = c.G; H.g = c.G > 1 ? c.c0 : 0u;
-        H.tile_major = call.tile_major && v3runs && !c.fm;
+        H.tile_major = call.tile_major && (v3runs || s1runs) && !c.fm;
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
         if (v3runs) { H.cpre = p->d_cpre; H.side = p->d_side; H.rt = v3runs <= p->cus ? p->d_rt : nullptr; }
         if (s1runs) { if ((r = shard1024_launch(H, c.fm, s1runs, s, timer))) return r; }

@@ -72,6 +72,7 @@ struct Shard1024Args {
     const float2 *vend_in; float2 *vend_out;      // DC blocker state v1
     const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r', indexed by the primed channel k' = G m
     uint32_t nf, nb, nruns, parity0;
+    uint32_t tile_major;        // CF32: the 128-byte lines of a 16-frame block back to back, [block][1024 / G][128 B] (the plane k_agc_spec_tm reads), instead of rows
     float alpha, beta, l2beta, fm_ref, tiny;
     float b16[16];              // beta^(16 r)
     float b256[17];             // beta^(256 g)
@@ -306,8 +307,11 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){mq[0], mq[1], mq[2], mq[3]}), ors, (int)((unsigned)m * row_b), (int)(16u * b), 0);
                         }
                     } else {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){y[0].x, y[0].y, y[1].x, y[1].y}), ors, (int)((unsigned)m * row_b), (int)(32u * b), 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){y[2].x, y[2].y, y[3].x, y[3].y}), ors, (int)((unsigned)m * row_b), (int)(32u * b + 16u), 0);
+                        // row-major: 32 bytes of row m; tile-major: pieces 2 (b & 3), 2 (b & 3) + 1 of channel m's line in block b >> 2
+                        const unsigned vo = (unsigned)m * (A.tile_major ? 128u : row_b);
+                        const unsigned so = A.tile_major ? (b >> 2) * ((unsigned)NP * 128u) + 32u * (b & 3u) : 32u * b;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){y[0].x, y[0].y, y[1].x, y[1].y}), ors, (int)vo, (int)so, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){y[2].x, y[2].y, y[3].x, y[3].y}), ors, (int)vo, (int)(so + 16u), 0);
                     }
                 }
             }
@@ -485,7 +489,8 @@ int shard1024_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_
     A.x = h.x; A.out = h.out; A.taps_q = h.taps_q; A.tw = h.tw;
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
     A.rp_in = h.rp_in; A.rp_out = h.rp_out;
-    A.nf = h.nf; A.nb = h.nf / 4; A.nruns = nruns; A.parity0 = h.parity0;
+    A.nf = h.nf; A.nb = h.nf / 4; A.nruns = nruns; A.parity0 = h.parity0; A.tile_major = (!fm && h.tile_major) ? 1u : 0u;
+    if (A.tile_major && (h.nf & 15u)) { set_error("k_shard1024: a tile-major plane takes whole 16-frame blocks"); return -1; }
     const double beta = h.dc_block ? h.beta : 0.0;
     A.alpha = h.dc_block ? (float)(1.0 - beta) : 0.0f; A.beta = (float)beta; A.l2beta = h.dc_block ? (float)std::log2(beta) : -1000.0f;
     for (int i = 0; i < 16; i++) A.b16[i] = (float)std::pow(beta, 16.0 * i);
