@@ -45,6 +45,11 @@ def parse():
     ap.add_argument("--shard", default="time", choices=["time", "channel"],
                     help="multi-GPU partition: time stripes (weak scaling, no collective; default) or interleaved channel "
                          "ownership k = rank (mod N) with a pruned DFT per rank (strong scaling; --mix adds one RCCL all-reduce per step)")
+    ap.add_argument("--chan-stride", type=int, default=0,
+                    help="N = 1 only: run ONE rank's handle of an N = chan-stride channel-shard run (chan_first = --chan-first, default 0) alone on "
+                         "this GPU -- the per-rank kernel of BASELINE configs[3] for --channels 1024 --chan-stride 8; `value` is then the rate at which "
+                         "that rank gets through the common input stream (what profiles/rNN_shard_* are collected with)")
+    ap.add_argument("--chan-first", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-agc-variant", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -229,6 +234,9 @@ def main():
     # --shard channel: north_star's partition.  Also accepted on ONE GPU (a world of one rank): the step then still goes through the
     # C ABI's collective entry points (csdr_comm_* / csdr_chain_process_device_mix), which is how a one-GPU box exercises them
     chan = a.shard == "channel"
+    per_rank = a.chan_stride if (a.chan_stride > 1 and world == 1 and not chan) else 0      # one rank's shard handle, alone on this GPU
+    if per_rank and (M % per_rank or a.mix or not 0 <= a.chan_first < per_rank):
+        raise SystemExit("--chan-stride must divide --channels, --chan-first must be below it, and --mix needs the collective (use --shard channel)")
     if chan and M % world:
         raise SystemExit(f"--shard channel needs --gpus | --channels ({world} does not divide {M})")
     # time stripes: rank r's stripe is a different stretch of the stream (different seed offset);
@@ -257,14 +265,15 @@ def main():
                           mode="channel", interleave=True, rank=rank, world=world, comm=comm)
         chain = sc.chain
     else:
-        chain = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=flags)
+        chain = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=flags,
+                         chan_first=(a.chan_first if per_rank else 0), chan_stride=per_rank)
         chain.seek_frames(rank * a.steps * nf)      # rank r's stripe of one long stream
     stream = torch.cuda.current_stream().cuda_stream
     xv = [x.view(-1) for x in xs]
     # second handle for the per-launch kernel timing pass behind the timed region (created now: allocations between the two
     # would be an idle gap)
     kch = cs.Chain(channels=M, demod=a.demod, kf=a.kf, agc=a.agc, mix=a.mix, max_frames=nf, device=local, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS,
-                   chan_first=(rank if chan and world > 1 else 0), chan_stride=(world if chan and world > 1 else 0))
+                   chan_first=(rank if chan and world > 1 else (a.chan_first if per_rank else 0)), chan_stride=(world if chan and world > 1 else per_rank))
 
     def step(i):
         if chan and a.mix:
@@ -513,6 +522,8 @@ def main():
         total_samples = float(nx) * a.steps * (1 if chan else world)     # channel shards: every rank works on the same samples
         value = total_samples / dt / 1e6
         alg_bytes_per_sample = 8 + (out_elem / M if a.mix else out_elem)   # read CF32 once + write W
+        if per_rank:
+            alg_bytes_per_sample = 8 + out_elem / per_rank               # one rank of a channel-shard run: the whole stream in, its 1 / G of the rows out
         kavg_ms = kms / max(klaunches, 1)
         achieved_pairs = (nx * alg_bytes_per_sample) / (kavg_ms * 1e-3) / 1e9 if klaunches else None
         kreg_ms = kms_r / max(klaunches_r, 1)
@@ -547,19 +558,25 @@ def main():
         traffic = traffic_of(kname)
         cfg_name = {(64, "none", False): "cfg2", (256, "fm", False): "cfg3", (1024, "fm", False): "cfg4 shape (one GPU)" if world == 1 else "cfg4",
                     (4096, "none", True): "cfg5 shape (one GPU)" if world == 1 else "cfg5"}.get((M, a.demod, bool(a.mix)), "custom")
+        if per_rank:
+            cfg_name = (f"cfg4 per rank (rank {a.chan_first} of {per_rank})" if (M, a.demod) == (1024, "fm") else f"rank {a.chan_first} of {per_rank} of a channel-shard run")
         # which partition `value` is -- first key of `config`, so that a truncated copy of the line still says it
-        sharding_txt = ("none (1 GPU)" if world == 1 else
-                        (f"channel shards (north_star's partition): rank g owns channels g + {world} m of the SAME stream, samples counted once, pruned DFT; "
-                         f"collective: {'one RCCL all-reduce per step (--mix)' if a.mix else 'none'}" if chan else
-                         f"independent time stripes, no collective: each of the {world} ranks runs the whole {M}-channel chain on its own stretch of the stream "
-                         "(weak scaling: linear by construction); north_star's channel-shard partition of ONE stream is `value_channel_shard` (strong scaling)"))
+        if world == 1:
+            sharding_txt = ((f"ONE RANK (chan_first {a.chan_first}) of an N = {per_rank} channel-shard run, alone on this GPU: owns channels {a.chan_first} + {per_rank} m; "
+                             "`value` = the rate it gets through the common input stream") if per_rank else "none (1 GPU)")
+        elif chan:
+            sharding_txt = (f"channel shards (north_star's partition): rank g owns channels g + {world} m of the SAME stream, samples counted once, pruned DFT; "
+                            f"collective: {'one RCCL all-reduce per step (--mix)' if a.mix else 'none'}")
+        else:
+            sharding_txt = (f"independent time stripes, no collective: each of the {world} ranks runs the whole {M}-channel chain on its own stretch of the stream "
+                            "(weak scaling: linear by construction); north_star's channel-shard partition of ONE stream is `value_channel_shard` (strong scaling)")
         res = {
-            "metric": f"MS/s CF32 throughput, {M}-ch PFB{'+FM' if a.demod == 'fm' else ''}{'+AGC' if a.agc else ''}{' --mix' if a.mix else ''} pipeline", "value": round(value, 1), "unit": "MS/s",
+            "metric": f"MS/s CF32 throughput, {M}-ch PFB{'+FM' if a.demod == 'fm' else ''}{'+AGC' if a.agc else ''}{' --mix' if a.mix else ''} pipeline" + (f", one rank of {per_rank} (channel shard)" if per_rank else ""), "value": round(value, 1), "unit": "MS/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if chan else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"sharding": sharding_txt, "workload": f"{cfg_name}: {M}-ch firpfbch(m=7,As=80)+dcBlocker{f'+freqdem(kf={a.kf})' if a.demod == 'fm' else ' (DeNo)'}{' --mix' if a.mix else ''} on synthetic CF32, "
                                    f"AGC {'off (-a 0)' if a.agc == 0 else a.agc}, {nf} frames/step "
-                                   f"({nx * 8 / 2**20:.0f} MiB in, {M * nf * out_elem / 2**20:.0f} MiB out), HBM-resident",
+                                   f"({nx * 8 / 2**20:.0f} MiB in, {M * nf * out_elem / (per_rank or 1) / 2**20:.0f} MiB out), HBM-resident",
                        "channels": M, "frames_per_step": nf, "demod": a.demod, "kf": a.kf, "agc_db": a.agc, "mix": bool(a.mix),
                        "path": f"{chain.path.split('|')[0]}|{kname}", "route": chain.path, "preheat_steps": preheat_steps,
                        "collective": (f"RCCL all-reduce(SUM) of {nf} {'F32' if a.demod == 'fm' else 'CF32'} per step" if (chan and a.mix) else "none"),
@@ -603,7 +620,7 @@ def main():
         if hyb:
             res["hybrid"] = hyb
             res["value_hybrid"] = hyb["value"]               # SURVEY 8e(B) with the AGC on (weak scaling)
-        if world == 1 and not a.no_agc_variant and a.agc == 0.0 and M == 256 and not a.mix:
+        if world == 1 and not per_rank and not a.no_agc_variant and a.agc == 0.0 and M == 256 and not a.mix:
             # cfg3 with the AGC on (squelch threshold -a 10 between the tone and the noise channels): the PFB kernel
             # writes channel-major CF32, the time-parallel verified AGC tail (bit-identical to the sequential
             # recurrence) adds squelch + freqdem
@@ -641,7 +658,7 @@ def main():
                                               "traffic": (ta + tb) if (ta and tb) else None}
             ch2.close()
 
-        if world == 1 and not a.no_other_configs and not a.no_agc_variant and a.agc == 0.0 and M == 256 and a.demod == "fm" and not a.mix and nf == 262144:
+        if world == 1 and not per_rank and not a.no_other_configs and not a.no_agc_variant and a.agc == 0.0 and M == 256 and a.demod == "fm" and not a.mix and nf == 262144:
             # The other BASELINE shapes, each for ~0.5 s on the same (hot) board and the same 67.1 M input samples per step, so that a driver-run line
             # carries them too (verdict r04: "none of cfg2/cfg4/cfg5 figures is driver-run").  Whole-step figures (host clock around a back-to-back
             # loop); the kernels behind them are profiled under profiles/rNN_*.  Not the headline: `value` above is.
@@ -702,7 +719,7 @@ def main():
             res["other_configs"] = others
             del out2
 
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not per_rank and not a.no_cpu_baseline:
             x_host = xs[0][: 4096 * M * 4].cpu().numpy().view(np.complex64).reshape(-1)
             res["cpu_baseline"] = cpu_baseline(M, a.demod, a.kf, a.agc, x_host, a.cpu_seconds, a.mix)
         if side_state["error"]:

@@ -27,8 +27,8 @@
 //   radix-2 decimation-in-frequency stages whose partner values come through DPP row operations (distances 1 .. 8), ds_swizzle (16) and
 //   ds_bpermute (32) (no LDS image, no barrier); lane l ends up with
 //   the bins a' + (NP/64) bitrev6(l), stored as one 16-byte piece per pair.  The tail thread m = channel g + G m reads its four frames,
-//   freqdem against the stash (fm_quad), one 16-byte store per tile and row: 128 rows x 256 runs keep 4 MiB of 128-byte lines open (G = 8),
-//   which the L2s hold.
+//   freqdem against the stash (fm_quad); G = 8: its 16-byte pieces wait in 128 bytes of LDS per row and leave as a whole line per block of
+//   8 tiles (stored piece by piece the L2s evicted the half-written lines: 4.2x the output bytes in WRITE_SIZE).
 //
 // State arrays and tables are the plan's (kernels_pfb1024.hip): window uhist [13][1024] pre-mixed, DC state, freqdem history rp[] indexed by
 // the PRIMED channel k' = G m, tap table taps_q with the shard's phasors -- so ragged and short calls of the same handle can take the
@@ -58,7 +58,9 @@ template <int G> struct S1 {
     static constexpr int ST = YB + 2 * 4 * NP;     // last Y frame of every owned channel [NP] (FM)
     static constexpr int TT = ST + NP;             // 16 group totals
     static constexpr int RED = TT + 16;            // 8 reduction slots of the prologue
-    static constexpr int F2 = RED + 8;
+    static constexpr bool STAGE = G == 8;          // output lines staged in LDS until a row's 128 bytes are complete (G = 4: 32 KiB more than a CU has left)
+    static constexpr int SG = RED + 8;             // [NP][128 B]: the tail thread's own row, 16-byte slot p at p ^ (m & 7)
+    static constexpr int F2 = SG + (STAGE ? NP * 16 : 0);
     static_assert(G == 4 || G == 8, "built for strides 4 and 8 (stride 2 keeps k_run1024v2<FM, 2>)");
     static_assert(F2 * 8 <= 160 * 1024, "one workgroup per CU");
 };
@@ -288,15 +290,27 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                     *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = y;
                 }
             }
-            // ---- tail of item s - 2: thread m = owned channel m (global channel g + G m): its four frames, freqdem against the stash, one
-            // 16-byte (F32) / two 16-byte (CF32) stores into row m
+            // ---- tail of item s - 2: thread m = owned channel m (global channel g + G m): its four frames, freqdem against the stash.  A tile is
+            // 16 bytes (F32) / 32 bytes (CF32) of row m.  Stored as such (first version), the L2s do NOT hold the half-written lines until they are
+            // complete: WRITE_SIZE showed 140 MB per launch for 33.5 MB of output.  So (STAGE) the pieces wait in the thread's own 128 bytes of
+            // LDS (slot p at p ^ (m & 7): conflict-free b128 accesses) and leave as one line, eight stores in a row, when the block of TB tiles is
+            // complete (or the call ends inside it); no other thread touches them, so no barrier is involved.
             if (s >= 2 + nwarm && s - 2 < n_items) {
                 const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)(tile_begin + s - 2));
                 const float2 *Y = Yb + (s & 1u) * (4 * NP);
+                const unsigned ts = b & (TB - 1u);
+                // (the tile-major plane keeps direct stores: a block's lines of all rows are one contiguous 16 KiB there, written within four steps
+                // by one workgroup -- the L2s do merge those, and staging them measured 3 % slower)
+                const bool stage = K::STAGE && (FM || !A.tile_major);
+                const bool flush = stage && b >= first && (ts == TB - 1u || b + 1u == last);
                 for (int m = lt; m < NP; m += 256) {
                     float2 y[4];
 #pragma unroll
                     for (int f = 0; f < 4; f++) y[f] = Y[f * NP + m];
+                    char *sg = reinterpret_cast<char *>(L + K::SG) + 128 * m;
+                    const unsigned sw = (unsigned)m & 7u;
+                    const unsigned vo = (unsigned)m * ((!FM && A.tile_major) ? 128u : row_b);
+                    const unsigned line = (!FM && A.tile_major) ? (b / TB) * ((unsigned)NP * 128u) : (b / TB) * 128u;     // my row's line of this block
                     if (FM) {
                         const float2 prev = ST[m];
                         ST[m] = y[3];
@@ -304,14 +318,27 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                             const float2 rp[4] = {prev, y[0], y[1], y[2]};
                             float mq[4];
                             fm_quad(rp, y, fk, mq);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){mq[0], mq[1], mq[2], mq[3]}), ors, (int)((unsigned)m * row_b), (int)(16u * b), 0);
+                            const v4f v = {mq[0], mq[1], mq[2], mq[3]};
+                            if (stage) *reinterpret_cast<v4f *>(sg + 16u * (ts ^ sw)) = v;
+                            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)vo, (int)(16u * b), 0);
                         }
                     } else {
-                        // row-major: 32 bytes of row m; tile-major: pieces 2 (b & 3), 2 (b & 3) + 1 of channel m's line in block b >> 2
-                        const unsigned vo = (unsigned)m * (A.tile_major ? 128u : row_b);
-                        const unsigned so = A.tile_major ? (b >> 2) * ((unsigned)NP * 128u) + 32u * (b & 3u) : 32u * b;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){y[0].x, y[0].y, y[1].x, y[1].y}), ors, (int)vo, (int)so, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, (v4f){y[2].x, y[2].y, y[3].x, y[3].y}), ors, (int)vo, (int)(so + 16u), 0);
+                        const v4f v0 = {y[0].x, y[0].y, y[1].x, y[1].y}, v1 = {y[2].x, y[2].y, y[3].x, y[3].y};
+                        if (stage) {
+                            *reinterpret_cast<v4f *>(sg + 16u * ((2u * ts) ^ sw)) = v0;
+                            *reinterpret_cast<v4f *>(sg + 16u * ((2u * ts + 1u) ^ sw)) = v1;
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v0), ors, (int)vo, (int)(line + 32u * ts), 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v1), ors, (int)vo, (int)(line + 32u * ts + 16u), 0);
+                        }
+                    }
+                    if (flush) {
+                        const unsigned pmax = FM ? ts : 2u * ts + 1u;       // (a call that ends inside a block: the front part of the line)
+#pragma unroll
+                        for (unsigned pc = 0; pc < 8; pc++) {
+                            const v4f v = *reinterpret_cast<const v4f *>(sg + 16u * (pc ^ sw));
+                            if (pc <= pmax) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)vo, (int)(line + 16u * pc), 0);
+                        }
                     }
                 }
             }

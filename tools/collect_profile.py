@@ -64,8 +64,11 @@ def short_name(k):
     k = k.replace("void ", "").replace("csdr::(anonymous namespace)::", "").replace("csdr::", "").split("(")[0]
     base, _, targs = k.partition("<")
     first = targs.split(",")[0].strip(" >")
-    if first in ("true", "false") and (base.startswith("k_run") or base.startswith("k_tile")):
-        return base + ("<FM>" if first == "true" else "<CF32>")
+    if first in ("true", "false") and (base.startswith("k_run") or base.startswith("k_tile") or base.startswith("k_shard")):
+        # interleaved-shard instantiations carry their stride: k_run256v2<true, 8> -> k_run256v2<FM>/G8 (as csdr_chain_kernel_time names them)
+        second = targs.split(",")[1].strip(" >") if "," in targs else ""
+        stride = f"/G{second}" if (second.isdigit() and int(second) > 1 and base in ("k_run256v2", "k_run1024v2", "k_shard1024")) else ""
+        return base + ("<FM>" if first == "true" else "<CF32>") + stride
     if base == "k_pfb1024" and "," in targs and targs.split(",")[1].strip(" >") == "true":
         return "k_run1024" + ("<FM>" if first == "true" else "<CF32>")     # k_pfb1024<FM, DC = true> is what the C side calls k_run1024
     return base
