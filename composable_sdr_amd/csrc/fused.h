@@ -124,6 +124,7 @@ struct Run1024v2Host {
     // first tile, side [nruns][4][RUN1024_DCFIX_F] uncorrected Y of the channels 510..513 (FM), rt [2][RUN1024_DCFIX_F][4] the chain's
     // response to a unit state there; null: warm-up windows
     float2 *cpre = nullptr, *side = nullptr; const float2 *rt = nullptr;
+    int mfix = -1;              // k_shard1024: the shard's row among the four channels around DC (side [nruns][RUN1024_DCFIX_F], rt channel 0), -1: none
     bool dc_block;
     double beta;
     float fm_ref;

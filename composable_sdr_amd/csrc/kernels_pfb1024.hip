@@ -462,6 +462,7 @@ struct BigPlan {
     bool v3_ok = false, v3_last = false;      // k_run1024v3 (FM, whole band) selected; used by the last call
     bool v2_ok = false, v2_last = false;      // k_run1024v2 usable (whole band, not disabled); used by the last call
     bool s1_ok = false, s1_last = false;      // k_shard1024<.., G> usable (interleaved shard, G = 4, 8); used by the last call
+    int s1_mfix = -1;                         // the shard's row among the four channels around DC (k_shard1024_dcfix), -1: none
     float2 *d_tw = nullptr, *d_wpre = nullptr;
     float2 *d_uhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
     float2 *d_scratch = nullptr;     // yfirst | ylast
@@ -561,6 +562,24 @@ int big_create(const FusedConfig &cfg, BigPlan **out)
         p->v3_last = p->v3_ok && run1024_v3_runs(cfg.max_nf, cfg.fm, p->cus) != 0;
         if (p->v3_last) p->v2_last = false;
     }
+    if (p->s1_ok) {
+        // k_shard1024 without warm-up windows (as k_run1024v3 below): the state hand-over between the runs, the side copies of the ONE owned channel
+        // among the four around DC (510 .. 513; primed k' = k - g, row k' / G -- none for the shards 2 .. 5 of 8), and the chain's response to a
+        // unit DC state there (computed on the plan's phasor table, which carries the shard's shift: the primed spectrum)
+        p->s1_mfix = -1;
+        uint32_t kp = 0;
+        for (uint32_t k = 510; k <= 513; k++) if ((k + (uint32_t)PM - cfg.c0) % cfg.G == 0) { kp = (k + (uint32_t)PM - cfg.c0) % (uint32_t)PM; p->s1_mfix = (int)(kp / cfg.G); }
+        hipError_t e1 = hipMalloc((void **)&p->d_cpre, sizeof(float2) * (p->cus + 2)), e2 = hipMalloc((void **)&p->d_side, sizeof(float2) * (size_t)(p->cus + 1) * RUN1024_DCFIX_F);
+        if (e1 != hipSuccess || e2 != hipSuccess) return fail(hip_fail(e1 != hipSuccess ? e1 : e2, "hipMalloc", __FILE__, __LINE__));
+        CSDR_HIP(hipMemset(p->d_cpre, 0, sizeof(float2) * (p->cus + 2)));
+        if (cfg.dc_block && !(diag_env("CSDR_NOWU") && atoi(diag_env("CSDR_NOWU")) == 0)) {
+            hipError_t e3 = hipMalloc((void **)&p->d_rt, sizeof(float2) * 2 * RUN1024_DCFIX_F * 4);
+            if (e3 != hipSuccess) return fail(hip_fail(e3, "hipMalloc", __FILE__, __LINE__));
+            std::vector<float2> rt((size_t)2 * RUN1024_DCFIX_F * 4, make_float2(0.f, 0.f));
+            if (p->s1_mfix >= 0) dc_state_response(cfg, wpre.data(), 15u, (uint32_t)RUN1024_DCFIX_F, kp, rt.data());      // (channel 0 of the four is the owned one)
+            CSDR_HIP(hipMemcpy(p->d_rt, rt.data(), sizeof(float2) * rt.size(), hipMemcpyHostToDevice));
+        }
+    }
     if (p->v3_ok) {
         // k_run1024v3's state hand-over and the side copies of the four channels around DC (510..513): the kernel always writes them (a few
         // hundred bytes per run); launches without warm-up windows (dc_block, not CSDR_NOWU=0) also get the chain's response to a unit DC state
@@ -632,6 +651,7 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.tile_major = call.tile_major && (v3runs || s1runs) && !c.fm;
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0; H.fm_ref = c.fm_ref;
         if (v3runs) { H.cpre = p->d_cpre; H.side = p->d_side; H.rt = v3runs <= p->cus ? p->d_rt : nullptr; }
+        if (s1runs) { H.cpre = p->d_cpre; H.side = p->d_side; H.rt = p->d_rt; H.mfix = p->s1_mfix; }
         if (s1runs) { if ((r = shard1024_launch(H, c.fm, s1runs, s, timer))) return r; }
         else if (v3runs) { if ((r = run1024_v3_launch(H, c.fm, v3runs, s, timer))) return r; }
         else if ((r = run1024_v2_launch(H, c.fm, s, timer))) return r;

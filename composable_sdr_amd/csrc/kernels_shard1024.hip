@@ -33,8 +33,9 @@
 // State arrays and tables are the plan's (kernels_pfb1024.hip): window uhist [13][1024] pre-mixed, DC state, freqdem history rp[] indexed by
 // the PRIMED channel k' = G m, tap table taps_q with the shard's phasors -- so ragged and short calls of the same handle can take the
 // whole-band kernel + row gather and carry the same state.
-// Run starts: warm-up window of six read-only tiles for the DC state (as k_run1024v3 without RunArgs::nowu), three window-refill tiles, and
-// (FM) the muted tile in front of the run for the freqdem history.
+// Run starts: cold, from DC state 0 (Shard1024Args::nowu; the six read-only warm-up tiles of the first version were 9 % of the reads): three
+// window-refill tiles and (FM) the muted tile in front of the run for the freqdem history; what the missing state contributes to the ONE owned
+// channel among the four around DC (none for the shards 2 .. 5 of 8) is put back by k_shard1024_dcfix behind the launch, as k_run1024_dcfix does.
 #include "fused_v2_common.h"
 #include <type_traits>
 
@@ -58,9 +59,10 @@ template <int G> struct S1 {
     static constexpr int ST = YB + 2 * 4 * NP;     // last Y frame of every owned channel [NP] (FM)
     static constexpr int TT = ST + NP;             // 16 group totals
     static constexpr int RED = TT + 16;            // 8 reduction slots of the prologue
-    static constexpr bool STAGE = G == 8;          // output lines staged in LDS until a row's 128 bytes are complete (G = 4: 32 KiB more than a CU has left)
-    static constexpr int SG = RED + 8;             // [NP][128 B]: the tail thread's own row, 16-byte slot p at p ^ (m & 7)
-    static constexpr int F2 = SG + (STAGE ? NP * 16 : 0);
+    static constexpr int SGB = G == 8 ? 128 : 64;  // output bytes of a row staged in LDS before they leave in one piece: a whole 128-byte line at G = 8, half a
+                                                   // line at G = 4 (a CU has no 32 KiB left there; 64-byte pieces are what k_run256v2 stores, at 1.0x WRITE_SIZE)
+    static constexpr int SG = RED + 8;             // [NP][SGB]: the tail thread's own row, 16-byte slot p at p ^ (m & (SGB / 16 - 1))
+    static constexpr int F2 = SG + NP * SGB / 8;
     static_assert(G == 4 || G == 8, "built for strides 4 and 8 (stride 2 keeps k_run1024v2<FM, 2>)");
     static_assert(F2 * 8 <= 160 * 1024, "one workgroup per CU");
 };
@@ -80,6 +82,9 @@ struct Shard1024Args {
     float b256[17];             // beta^(256 g)
     PhaseK pk;
     unsigned long long *trace;  // debug (S1_TRACE build): [role][step < 96][4] stamps
+    uint32_t nowu;              // 1: a run starts cold from DC state 0 (no read-only warm-up tiles), leaves the state in front of tile last - 4 in
+    int mfix;                   //    cpre[w + 1] and (FM) the uncorrected Y of row mfix (the owned channel among 510 .. 513; -1: none) for its frames
+    float2 *cpre, *side;        //    -1 .. 31 in side [w][RUN1024_DCFIX_F]: k_shard1024_dcfix
 };
 
 // value of lane l ^ D: DPP inside a row of 16 lanes (no LDS latency), ds_swizzle across the rows of a half, ds_bpermute across the halves
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
     float2 c = make_float2(0.f, 0.f);                   // DC state v before the next tile (same in every lane)
     {
         float2 acc = make_float2(0.f, 0.f);
-        if (w > 0 && !rho) {
+        if (w > 0 && !rho && !A.nowu) {
             // read-only warm-up (as k_run1024v3): the DC state before tile_begin from the six tiles in front of it, one batch of loads.  A run
             // that starts fewer than six tiles into the call folds the tiles there are -- zeros stand for the others -- and takes the rest from
             // the stream's state below, which is then exact
@@ -292,25 +297,32 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
             }
             // ---- tail of item s - 2: thread m = owned channel m (global channel g + G m): its four frames, freqdem against the stash.  A tile is
             // 16 bytes (F32) / 32 bytes (CF32) of row m.  Stored as such (first version), the L2s do NOT hold the half-written lines until they are
-            // complete: WRITE_SIZE showed 140 MB per launch for 33.5 MB of output.  So (STAGE) the pieces wait in the thread's own 128 bytes of
-            // LDS (slot p at p ^ (m & 7): conflict-free b128 accesses) and leave as one line, eight stores in a row, when the block of TB tiles is
-            // complete (or the call ends inside it); no other thread touches them, so no barrier is involved.
+            // complete: WRITE_SIZE showed 140 MB per launch for 33.5 MB of output (G = 8), 154 for 67 (G = 4).  So the pieces wait in the
+            // thread's own SGB bytes of LDS (slot p at p ^ (m & (SGB / 16 - 1))) and leave together, SGB / 16 stores in a row, when they are
+            // complete (or the call ends inside them); no other thread touches them, so no barrier is involved.
             if (s >= 2 + nwarm && s - 2 < n_items) {
                 const unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)(tile_begin + s - 2));
                 const float2 *Y = Yb + (s & 1u) * (4 * NP);
-                const unsigned ts = b & (TB - 1u);
+                constexpr unsigned SGB = K::SGB, NSL = SGB / 16u, TF = SGB / (FM ? 16u : 32u);      // staged bytes per row, their 16-byte slots, tiles per flush
+                const unsigned ts = b & (TF - 1u);
                 // (the tile-major plane keeps direct stores: a block's lines of all rows are one contiguous 16 KiB there, written within four steps
                 // by one workgroup -- the L2s do merge those, and staging them measured 3 % slower)
-                const bool stage = K::STAGE && (FM || !A.tile_major);
-                const bool flush = stage && b >= first && (ts == TB - 1u || b + 1u == last);
+                const bool stage = FM || !A.tile_major;
+                const bool flush = stage && b >= first && (ts == TF - 1u || b + 1u == last);
                 for (int m = lt; m < NP; m += 256) {
                     float2 y[4];
 #pragma unroll
                     for (int f = 0; f < 4; f++) y[f] = Y[f * NP + m];
-                    char *sg = reinterpret_cast<char *>(L + K::SG) + 128 * m;
-                    const unsigned sw = (unsigned)m & 7u;
-                    const unsigned vo = (unsigned)m * ((!FM && A.tile_major) ? 128u : row_b);
-                    const unsigned line = (!FM && A.tile_major) ? (b / TB) * ((unsigned)NP * 128u) : (b / TB) * 128u;     // my row's line of this block
+                    char *sg = reinterpret_cast<char *>(L + K::SG) + SGB * m;
+                    const unsigned sw = (unsigned)m & (NSL - 1u);
+                    if (FM && w > 0 && m == A.mfix && b + 1u >= first && b < first + 8u) {
+                        // the uncorrected Y of the owned channel next to DC, frames -1 .. 31 of the run, for k_shard1024_dcfix
+                        float2 *sd = A.side + (size_t)w * RUN1024_DCFIX_F;
+                        const int i0 = 4 * (int)(b + 1u - first) - 3;          // frame f of this tile -> slot i0 + f (slot 0 = frame -1)
+#pragma unroll
+                        for (int f = 0; f < 4; f++)
+                            if (i0 + f >= 0) sd[i0 + f] = y[f];
+                    }
                     if (FM) {
                         const float2 prev = ST[m];
                         ST[m] = y[3];
@@ -318,26 +330,26 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                             const float2 rp[4] = {prev, y[0], y[1], y[2]};
                             float mq[4];
                             fm_quad(rp, y, fk, mq);
-                            const v4f v = {mq[0], mq[1], mq[2], mq[3]};
-                            if (stage) *reinterpret_cast<v4f *>(sg + 16u * (ts ^ sw)) = v;
-                            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)vo, (int)(16u * b), 0);
+                            *reinterpret_cast<v4f *>(sg + 16u * (ts ^ sw)) = (v4f){mq[0], mq[1], mq[2], mq[3]};
                         }
                     } else {
                         const v4f v0 = {y[0].x, y[0].y, y[1].x, y[1].y}, v1 = {y[2].x, y[2].y, y[3].x, y[3].y};
                         if (stage) {
                             *reinterpret_cast<v4f *>(sg + 16u * ((2u * ts) ^ sw)) = v0;
                             *reinterpret_cast<v4f *>(sg + 16u * ((2u * ts + 1u) ^ sw)) = v1;
-                        } else {
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v0), ors, (int)vo, (int)(line + 32u * ts), 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v1), ors, (int)vo, (int)(line + 32u * ts + 16u), 0);
+                        } else {                        // tile-major: pieces 2 (b & 3), 2 (b & 3) + 1 of channel m's line in block b >> 2
+                            const unsigned so = (b >> 2) * ((unsigned)NP * 128u) + 32u * (b & 3u);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v0), ors, (int)((unsigned)m * 128u), (int)so, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v1), ors, (int)((unsigned)m * 128u), (int)(so + 16u), 0);
                         }
                     }
                     if (flush) {
-                        const unsigned pmax = FM ? ts : 2u * ts + 1u;       // (a call that ends inside a block: the front part of the line)
+                        const unsigned pmax = FM ? ts : 2u * ts + 1u;       // (a call that ends inside a block: the front part of it)
+                        const unsigned so = (b / TF) * SGB;                  // my row's staged piece of this block
 #pragma unroll
-                        for (unsigned pc = 0; pc < 8; pc++) {
+                        for (unsigned pc = 0; pc < NSL; pc++) {
                             const v4f v = *reinterpret_cast<const v4f *>(sg + 16u * (pc ^ sw));
-                            if (pc <= pmax) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)vo, (int)(line + 16u * pc), 0);
+                            if (pc <= pmax) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, v), ors, (int)((unsigned)m * row_b), (int)(so + 16u * pc), 0);
                         }
                     }
                 }
@@ -403,6 +415,8 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
         bar();                                          // Q: y' (group carry still missing) and the group totals of item s are visible
         if (tr) tq[2] = __builtin_amdgcn_s_memtime();
         if (have) {
+            // no warm-up windows: the state in front of tile last - 4 is the next run's cold start (my own start error is beta^(>= 12 x 4096) of it)
+            if (tid == 0 && tile_begin + s + (unsigned)S1_HALO == last) A.cpre[w + 1] = c;
             // ---- column layout: sample of frame f, branch j + 256 (2 rho + qp) -> ring slot 4 PH + f (f < 3) / n3 (f = 3); group state chain V[g] (uniform)
             float2 n3[2];
 #define NW(f, qp) (*((f) < 3 ? &ring[2 * ((4 * PH + (f)) & 15) + (qp)] : &n3[qp]))
@@ -494,6 +508,37 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
     }
 }
 
+// What the DC state a run started without contributes to the owned channel next to DC over the run's first 32 frames: Y += cpre[w] x R (the
+// chain is linear up to Y).  CF32: in place on the row (or the tile-major plane); FM: freqdem of the corrected side copies.
+template <bool FM>
+__global__ __launch_bounds__(64) void k_shard1024_dcfix(Shard1024Args A, const float2 *__restrict__ rt, unsigned NP)
+{
+    const unsigned TB = FM ? 8u : 4u;
+    const unsigned w = blockIdx.x + 1u, fr = threadIdx.x;
+    unsigned first, last;
+    shard_bounds(A.nb, A.nruns, w, TB, first, last);
+    if (fr >= 32u || A.mfix < 0) return;
+    const float2 c = A.cpre[w];
+    const float2 *R = rt + (size_t)(A.parity0 & 1u) * RUN1024_DCFIX_F * 4;      // a tile is 4 frames: every cold start begins on the call's parity
+    auto corr = [&](unsigned i) { const float2 r = R[i * 4u]; return make_float2(c.x * r.x - c.y * r.y, c.x * r.y + c.y * r.x); };
+    const size_t t = (size_t)4 * first + fr;            // the frame in the call
+    if (t >= A.nf) return;
+    const unsigned k = (unsigned)A.mfix;
+    if (FM) {
+        const float2 *sd = A.side + (size_t)w * RUN1024_DCFIX_F;
+        const float2 p0 = sd[fr], p1 = sd[fr + 1u], d0 = corr(fr), d1 = corr(fr + 1u);
+        const FmK fk = {A.tiny, A.fm_ref, A.pk.hp, A.pk.pi};
+        reinterpret_cast<float *>(A.out)[(size_t)k * A.nf + t] =
+            fm_sample(make_float2(p0.x + d0.x, p0.y + d0.y), make_float2(p1.x + d1.x, p1.y + d1.y), fk);
+    } else {
+        float2 *o = reinterpret_cast<float2 *>(A.out) + (A.tile_major ? ((t >> 4) * NP + k) * 16u + (t & 15u) : (size_t)k * A.nf + t);
+        const float2 d1 = corr(fr + 1u);
+        float2 y = *o;
+        y.x += d1.x; y.y += d1.y;
+        *o = y;
+    }
+}
+
 }  // namespace
 
 // whole 4-frame tiles; at least two blocks (16 / 8 tiles) per run: a run >= 1 spends six read-only tiles and four halo tiles on its start
@@ -529,6 +574,9 @@ int shard1024_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_
     static unsigned long long *d_trace = nullptr;
     if (trace_file && !d_trace) CSDR_HIP(hipMalloc(&d_trace, 768 * sizeof(unsigned long long)));
     if (trace_file) { CSDR_HIP(hipMemsetAsync(d_trace, 0, 768 * sizeof(unsigned long long), s)); A.trace = d_trace; }
+    // no warm-up windows: whole runs of >= 16 tiles (a cold start is 4 tiles deep and the correction covers 8 more), the state arrays there
+    A.nowu = (h.rt && h.cpre && h.side && h.dc_block && nruns >= 2) ? 1u : 0u;
+    A.cpre = h.cpre; A.side = h.side; A.mfix = h.mfix;
     int r;
     if (timer && (r = timer->begin(s))) return r;
     if (h.G == 8) {
@@ -538,7 +586,11 @@ int shard1024_launch(const Run1024v2Host &h, bool fm, uint32_t nruns, hipStream_
         if (fm) hipLaunchKernelGGL((k_shard1024<true, 4>), dim3(nruns), dim3(512), 0, s, A);
         else hipLaunchKernelGGL((k_shard1024<false, 4>), dim3(nruns), dim3(512), 0, s, A);
     } else { set_error("k_shard1024: chan_stride %u is not built (4, 8)", h.G); return -1; }
-    if (timer && (r = timer->end(s))) return r;
+    if (A.nowu && A.mfix >= 0) {
+        if (fm) hipLaunchKernelGGL((k_shard1024_dcfix<true>), dim3(nruns - 1u), dim3(64), 0, s, A, h.rt, 1024u / h.G);
+        else hipLaunchKernelGGL((k_shard1024_dcfix<false>), dim3(nruns - 1u), dim3(64), 0, s, A, h.rt, 1024u / h.G);
+    }
+    if (timer && (r = timer->end(s))) return r;         // (the bracket covers the correction kernel)
     CSDR_HIP(hipGetLastError());
     if (trace_file) {                                   // debug: the last launch's stamps, raw uint64 [role][96][4]
         std::vector<unsigned long long> hbuf(768);
