@@ -90,7 +90,7 @@ static std::vector<double> firdes_kaiser(uint32_t N, double fc, double As)
     return h;
 }
 
-// ---- multi-stage resampler (msresamp_crcf's structure; "csdr msresamp v1" parameters, DESIGN.md 4.5) ----
+// ---- multi-stage resampler (msresamp_crcf's structure; "csdr msresamp v1" parameters, DESIGN.md 4.8) ----
 ResampDesign design_msresamp(float rate, float As)
 {
     ResampDesign d;

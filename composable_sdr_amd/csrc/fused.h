@@ -52,7 +52,7 @@ int  run256_v2_blocks_per_cu(bool fm);
 // RunArgs::nowu launches: the near-DC channels of every run's first 112 frames get what the true DC state at the run's start adds (Rt: host table
 // [2 parities][DCFIX_F][4], fused_common.h)
 int  run256_dcfix_launch(const void *run_args, bool fm, unsigned nruns, const float2 *Rt, hipStream_t s);
-// round 4's experiment (tools/variants/kernels_run256_v3.hip, NOT part of the product library: measured not faster):
+// round 4's experiment (tools/variants/kernels_run256_v3.hip, NOT part of the product library: measured not faster: DESIGN.md 8.1):
 // one 512-thread workgroup per CU, front / back wave roles; linked only by tools/variants/build_run256_v3.sh (-DCSDR_WITH_RUN256_V3)
 int  run256_v3_launch(const void *run_args, bool fm, unsigned nruns, hipStream_t s);
 
@@ -95,7 +95,7 @@ struct Run64v2Host {
     const float2 *x; float2 *out;
     const float *taps; const float2 *tw, *wpre;
     const float2 *uhist_in; float2 *uhist_out; const float2 *vend_in; float2 *vend_out;
-    // runs without warm-up windows (round 5, as k_run256v2: DESIGN 4.1e): cpre [nruns + 1] DC state in front of every run's halo tile,
+    // runs without warm-up windows (round 5, as k_run256v2: DESIGN 4): cpre [nruns + 1] DC state in front of every run's halo tile,
     // rt [2 parities][RUN64_DCFIX_F][4] the chain's response to a unit state at the channels 30..33; both null: warm-up windows
     float2 *cpre = nullptr; const float2 *rt = nullptr;
     uint32_t nf, nruns, parity0;
@@ -120,7 +120,7 @@ struct Run1024v2Host {
     uint32_t nf, nruns, parity0;
     uint32_t G = 1, g = 0;      // interleaved shard g of G (tables rotated by the plan)
     bool tile_major = false;    // k_run1024v3<CF32>: the lines of a 16-frame block back to back ([block][1024][128 B]) instead of row-major [1024][nf]
-    // k_run1024v3 without warm-up windows (round 5, as k_run256v2: DESIGN 4.1e): cpre [nruns + 1] DC state four tiles in front of every run's
+    // k_run1024v3 without warm-up windows (round 5, as k_run256v2: DESIGN 4): cpre [nruns + 1] DC state four tiles in front of every run's
     // first tile, side [nruns][4][RUN1024_DCFIX_F] uncorrected Y of the channels 510..513 (FM), rt [2][RUN1024_DCFIX_F][4] the chain's
     // response to a unit state there; null: warm-up windows
     float2 *cpre = nullptr, *side = nullptr; const float2 *rt = nullptr;

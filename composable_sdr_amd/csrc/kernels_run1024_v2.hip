@@ -1,7 +1,7 @@
 // Second-generation run kernel of the fused M = 1024 chain (BASELINE configs[3] shape).
 // ROUND 4: only the INTERLEAVED-SHARD instantiations k_run1024v2<FM, G>, G = 2, 4, 8, are still built (see "G > 1" below); every whole-band
 // call of whole tiles goes to k_run1024v3 (kernels_run1024_v3.hip), so the staging block and its flush (G == 1 paths, kept in the source as
-// the record of DESIGN 4.2c's measurements) are never instantiated.
+// the record of round 3's measurements: `git show 5b4db89:DESIGN.md`, section 4.2c) are never instantiated.
 //
 //   raw CF32 x --DC blocker--> y --NCO pre-mix, 14-tap polyphase FIR--> X_t[j] --1024-point forward DFT (16 x 16 x 4)--> Y_t[k]
 //              --per-channel freqdem--> out[1024][nf]              (8 B read + 4 / 8 B written per sample, Liquid.chs:575-589,

@@ -44,7 +44,7 @@ struct Run64v2Args {
     float alpha, beta, l2beta;
     float b16[16], b256[17];
     uint32_t nowu;              // 1: a run starts its halo tile from DC state 0 and leaves the state in front of its last tile in cpre[w + 1];
-    float2 *cpre;               //    k_run64_dcfix adds what the true state contributes to the channels 30..33 (DESIGN 4.1e, as k_run256v2)
+    float2 *cpre;               //    k_run64_dcfix adds what the true state contributes to the channels 30..33 (DESIGN 4, as k_run256v2)
 };
 
 // first half of the runs (dispatched first: the older workgroups of their CUs) share n0 tiles, the second half the rest

@@ -8,7 +8,7 @@
 //                thread's true start state, a second pass produces the outputs.  The state crosses chunks (and
 //                calls) exactly; only the f32 summation order differs from the sequential loop.
 //   k_firdecim : firDecimator m (Liquid.chs:485-501): y[j] = sum_i h[i] x[jM - i] over a per-channel history prefix.
-// Arithmetic recalled from liquid-dsp 1.3.2 (iirdes / iirfiltsos / firdecim): unpinned, DESIGN.md 4.6.
+// Arithmetic recalled from liquid-dsp 1.3.2 (iirdes / iirfiltsos / firdecim): unpinned, DESIGN.md 4.8.
 #include "../../include/csdr.h"
 #include "csdr_internal.h"
 

@@ -158,7 +158,7 @@ int csdr_freqdem_destroy(csdr_freqdem *h);
  * Butterworth low-pass and are ignored, as in liquid.  x, y are [nchan][n] F32.
  * firDecimator m  (Liquid.chs:485-501) = firdecim_rrrf_create_kaiser(m, 10, 60) (imports
  * :473-483): x is [nchan][n] F32 with n % m == 0 (the reference's `div`), y is [nchan][n/m].
- * Arithmetic recalled from liquid-dsp 1.3.2 (unpinned, DESIGN.md 4.6).
+ * Arithmetic recalled from liquid-dsp 1.3.2 (unpinned, DESIGN.md 4.8).
  * ------------------------------------------------------------------------ */
 typedef struct csdr_iirfilt csdr_iirfilt;
 int csdr_iirfilt_create(uint32_t order, float fc, float f0, float ap, float as_db, uint32_t nchan, uint32_t max_samples,
@@ -179,7 +179,7 @@ int csdr_firdecim_destroy(csdr_firdecim *h);
  *   samples of room (= the reference's 2*ceil(r*nx), :81).
  *   Structure = liquid-dsp's msresamp (half-band decimators + one arbitrary-rate
  *   polyphase stage); liquid's internal filter parameters are not recoverable from
- *   the reference, so they are fixed by this library (DESIGN.md 4.5): unpinned.
+ *   the reference, so they are fixed by this library (DESIGN.md 4.8): unpinned.
  *   rate == 0: pass-through (the reference's nullPtr resampler, :100-103);
  *   rate > 2: CSDR_ERR_INVALID.  CSDR_QUIET in the environment silences the print.
  * ------------------------------------------------------------------------ */

@@ -3,7 +3,7 @@
 k_run256v2 issues its output stores from inline asm with a scalar base and no wait states in front (1 % of the launch).
 That is only safe while hipcc does not spill SGPRs in the kernel: a base reloaded from a spill lane (v_readlane = a VALU
 write of an SGPR) must be five wait states old before a VMEM instruction reads it, and the hazard recognizer does not look
-into inline asm ("Inline-asm hazards").  k_run1024v2 does spill SGPRs and pays for the wait states."""
+into inline asm (fused_v2_common.h, dma_tile).  k_run1024v2 does spill SGPRs and pays for the wait states."""
 import os
 import re
 import shutil

@@ -2262,7 +2262,7 @@ def test_fused_interleaved_shard_run_sized_calls_match_whole_band(M, G, demod, a
     state carried from call to call): every shard g must reproduce the rows g, g + G, ... of the whole-band fused chain on the
     same calls (same kernels upstream of pass 1, so FM agrees to the rounding of a differently pruned butterfly).
     With the AGC on (k_run256v2<CF32, G> into the shard's [M / G][nf] plane + k_agc_spec on it: the configuration behind the
-    per-rank AGC figures of DESIGN 4.1c) the mute mask must equal the whole band's bit for bit, and the first run-sized call is
+    per-rank AGC figures of DESIGN 4.1 / 6) the mute mask must equal the whole band's bit for bit, and the first run-sized call is
     also compared with rows g::G of the oracle directly."""
     kf = 0.3
     from composable_sdr_amd import _lib

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""cfg3 + AGC at the bench size: step time and repaired segments against the warm-up length W (CSDR_AGC_W), the numbers behind DESIGN 4.3c."""
+"""cfg3 + AGC at the bench size: step time and repaired segments against the warm-up length W (CSDR_AGC_W), the numbers behind DESIGN 4.7 (W = 1024)."""
 import os as _os; _os.environ.setdefault("CSDR_DIAG", "1")
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
