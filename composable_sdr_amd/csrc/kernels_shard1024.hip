@@ -24,8 +24,8 @@
 //            the same n1) -> partial folds P[part][f][n1] in LDS
 //
 //   The pruned DFT runs ACROSS THE LANES of a wave: lane l holds Z[l + 64 a], a < NP / 64; a radix-(NP/64) step on the registers, then six
-//   radix-2 decimation-in-frequency stages whose partner values come through DPP row operations (distances 1 .. 8), ds_swizzle (16) and
-//   ds_bpermute (32) (no LDS image, no barrier); lane l ends up with
+//   radix-2 decimation-in-frequency stages whose partner values come through DPP row operations (distances 1 .. 8) and
+//   v_permlane16_swap / v_permlane32_swap (16, 32): no LDS image, no LDS crossbar, no barrier; lane l ends up with
 //   the bins a' + (NP/64) bitrev6(l), stored as one 16-byte piece per pair.  The tail thread m = channel g + G m reads its four frames,
 //   freqdem against the stash (fm_quad); G = 8: its 16-byte pieces wait in 128 bytes of LDS per row and leave as a whole line per block of
 //   8 tiles (stored piece by piece the L2s evicted the half-written lines: 4.2x the output bytes in WRITE_SIZE).
@@ -87,8 +87,10 @@ struct Shard1024Args {
     float2 *cpre, *side;        //    -1 .. 31 in side [w][RUN1024_DCFIX_F]: k_shard1024_dcfix
 };
 
-// value of lane l ^ D: DPP inside a row of 16 lanes (no LDS latency), ds_swizzle across the rows of a half, ds_bpermute across the halves
-template <int D> __device__ __forceinline__ float lane_xor(float x)
+// value of lane l ^ D (upper: bit D of my lane index is set), without a trip through the LDS crossbar: DPP inside a row of 16 lanes,
+// v_permlane16_swap / v_permlane32_swap (gfx950) across rows and halves -- a ds_bpermute / ds_swizzle per value put ~450 cycles of latency on
+// each of the first two butterfly stages (phase trace: 1274 cycles for the two of them, 110 per DPP stage)
+template <int D> __device__ __forceinline__ float lane_xor(float x, bool upper)
 {
     const int v = __float_as_int(x);
     if (D == 1) return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));        // quad_perm [1,0,3,2]
@@ -98,8 +100,14 @@ template <int D> __device__ __forceinline__ float lane_xor(float x)
         return __int_as_float(__builtin_amdgcn_update_dpp(a, v, 0x114, 0xf, 0xA, false));               // row_shr:4 into the banks 1, 3 (lane i <- i - 4)
     }
     if (D == 8) return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));        // row_ror:8
-    if (D == 16) return __int_as_float(__builtin_amdgcn_ds_swizzle(v, 0x401F));                         // bit-mask mode: xor 16 inside 32 lanes
-    return __shfl_xor(x, 32);
+    if (D == 16) {
+        // swap the odd rows of the first copy with the even rows of the second: first = [r0, r0, r2, r2], second = [r1, r1, r3, r3]
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        return __uint_as_float(upper ? r[0] : r[1]);
+    }
+    // swap the upper half of the first copy with the lower half of the second: first = [lo, lo], second = [hi, hi]
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return __uint_as_float(upper ? r[0] : r[1]);
 }
 
 // run w: whole blocks of TB tiles (a row's 128-byte line), evenly; the call's last block may be a partial one
@@ -295,6 +303,7 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                     *reinterpret_cast<v4f *>(B + (raw_a ^ (unsigned)(i << 4))) = y;
                 }
             }
+            if (S1_TRACE == 2 && tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq[1] = __builtin_amdgcn_s_memtime(); }
             // ---- tail of item s - 2: thread m = owned channel m (global channel g + G m): its four frames, freqdem against the stash.  A tile is
             // 16 bytes (F32) / 32 bytes (CF32) of row m.  Stored as such (first version), the L2s do NOT hold the half-written lines until they are
             // complete: WRITE_SIZE showed 140 MB per launch for 33.5 MB of output (G = 8), 154 for 67 (G = 4).  So the pieces wait in the
@@ -383,20 +392,23 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                 // six radix-2 stages across the lanes: partner l ^ d; lower lane x + p, upper lane (p - x) W_2d^(l & (d - 1))
                 auto stage = [&](auto dc, const int i) {
                     constexpr int D = decltype(dc)::value;
-                    const unsigned sgn = (l6 & D) ? 0x80000000u : 0u;
+                    const bool upper = (l6 & D) != 0;
+                    const unsigned sgn = upper ? 0x80000000u : 0u;
 #pragma unroll
                     for (int k = 0; k < PPL; k++) {
-                        const v2f p = {lane_xor<D>(z[k].x), lane_xor<D>(z[k].y)};
+                        const v2f p = {lane_xor<D>(z[k].x, upper), lane_xor<D>(z[k].y, upper)};
                         const v2f xs = {__uint_as_float(__float_as_uint(z[k].x) ^ sgn), __uint_as_float(__float_as_uint(z[k].y) ^ sgn)};
                         v2f y = p + xs;
                         if (D > 1) y = cmul_v(y, tws[i]);
                         z[k] = y;
                     }
                 };
+                if (S1_TRACE == 2 && tr) tq[1] = __builtin_amdgcn_s_memtime();
                 stage(std::integral_constant<int, 32>(), 0);
                 if (dma) { dma_piece(dsrc, goff, ddst, 2); dma_piece(dsrc, goff, ddst, 3); }
                 stage(std::integral_constant<int, 16>(), 1);
                 if (dma) { dma_piece(dsrc, goff, ddst, 4); dma_piece(dsrc, goff, ddst, 5); }
+                if (S1_TRACE == 2 && tr) tq[2] = __builtin_amdgcn_s_memtime();
                 stage(std::integral_constant<int, 8>(), 2);
                 if (dma) { dma_piece(dsrc, goff, ddst, 6); dma_piece(dsrc, goff, ddst, 7); }
                 stage(std::integral_constant<int, 4>(), 3);
@@ -411,9 +423,9 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
                 for (int it = 2; it < 8; it++) dma_piece(dsrc, goff, ddst, it);
             }
         }
-        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq[1] = __builtin_amdgcn_s_memtime(); }
+        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq[S1_TRACE == 2 ? (rho ? 3 : 2) : 1] = __builtin_amdgcn_s_memtime(); }
         bar();                                          // Q: y' (group carry still missing) and the group totals of item s are visible
-        if (tr) tq[2] = __builtin_amdgcn_s_memtime();
+        if (S1_TRACE != 2 && tr) tq[2] = __builtin_amdgcn_s_memtime();
         if (have) {
             // no warm-up windows: the state in front of tile last - 4 is the next run's cold start (my own start error is beta^(>= 12 x 4096) of it)
             if (tid == 0 && tile_begin + s + (unsigned)S1_HALO == last) A.cpre[w + 1] = c;
@@ -472,7 +484,7 @@ __global__ __launch_bounds__(512) void k_shard1024(Shard1024Args A)
             for (int qp = 0; qp < 2; qp++) ring[2 * ((4 * PH + 3) & 15) + qp] = n3[qp];
 #undef NW
         }
-        if (tr) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq[3] = __builtin_amdgcn_s_memtime(); }
+        if (tr && (S1_TRACE != 2 || !rho)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq[3] = __builtin_amdgcn_s_memtime(); }
         if (rho) {
             // image s + 1 has landed: everything older than the eight DMA instructions of image s + 2 (when there is one)
             if (s + AHEAD < n_items) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
