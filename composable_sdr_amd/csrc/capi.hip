@@ -633,7 +633,7 @@ const RouteRow ROUTES[] = {
      "channelizer -> CF32 plane (tile-major for run-sized calls of whole tiles) -> k_agc_spec_tm | k_agc_spec -> k_agc_fix [-> k_mix]"},
     {64, ST1, PLAN_SMALL64, "fused-k_run64",
      "k_run64v2 (CF32 output, whole band, nf % 64 == 0, >= 8 tiles of 64 frames per run)", "k_run64<FM | CF32> (FM output, shards, ragged calls)",
-     "k_run64<CF32> -> k_agc_spec -> k_agc_fix [-> k_mix]"},
+     "k_run64v2 -> CF32 plane (tile-major, run-sized calls) -> k_agc_spec_tm | k_run64<CF32> -> k_agc_spec; -> k_agc_fix [-> k_mix]"},
     {1024, ST1 | ST2 | ST4 | ST8, PLAN_BIG1024, "fused-k_run1024",
      "k_run1024v3<FM | CF32> (whole band, calls of whole 4-frame tiles; a call that ends inside a 128-byte line stores the front part of it); "
      "k_shard1024<FM | CF32, G> (interleaved shards G = 4, 8: fold of the aliasing branches behind the FIR + a (1024 / G)-point DFT across the lanes; run-sized calls of whole tiles); "
@@ -888,7 +888,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             // (the fused M = 256 plans may write it tile-major for k_agc_spec_tm, which reads up to a segment in front of / behind the plane)
             // The guards (2 x 64 KiB per channel: 128 MiB at 1024 channels) exist only where a call can take that route: a time-parallel
             // tail (not CSDR_FLAG_AGC_SEQUENTIAL), a channel count k_agc_spec_tm takes, calls of >= 4 W = 4096 frames
-            const bool tm_possible = (h->fused || h->big) && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL) && h->max_nf >= 4096u &&
+            const bool tm_possible = (h->fused || h->big || h->small) && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL) && h->max_nf >= 4096u &&
                                      (C % 64u == 0 || (C < 64u && 64u % C == 0));
             h->a_guard = tm_possible ? agc_tail_tm_guard(C) : 0;
             if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf + 2 * h->a_guard))) return fail(r);
@@ -1231,7 +1231,7 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         FusedCall fcall{};
         // AGC tail behind the fused M = 256 / M = 1024 chains, run-sized calls of whole tiles: the plane between the two kernels is tile-major
         const bool tm = agc_on && h->agc_tail && h->a_guard && Z != (float2 *)d_out && agc_tail_tm_supported(h->agc_tail, nf) &&
-                        (h->fused ? fused_tile_major_ok(h->fused, nf) : (h->big && big_tile_major_ok(h->big, nf)));
+                        (h->fused ? fused_tile_major_ok(h->fused, nf) : h->big ? big_tile_major_ok(h->big, nf) : (h->small && small_tile_major_ok(h->small, nf)));
         fcall.tile_major = tm;
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         fcall.indep = h->call_indep; fcall.ev_tail = h->call_ev_tail;

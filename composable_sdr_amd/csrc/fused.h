@@ -65,6 +65,7 @@ int  small_reset(SmallPlan *plan, hipStream_t s);
 int  small_process(SmallPlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
 void small_seek(SmallPlan *plan, uint64_t frames);
 const char *small_name(const SmallPlan *plan);
+bool small_tile_major_ok(const SmallPlan *plan, uint32_t nf);     // the call goes to k_run64v2 as whole 64-frame tiles, no mix inside the plan
 void small_destroy(SmallPlan *plan);
 
 
@@ -100,6 +101,7 @@ struct Run64v2Host {
     float2 *cpre = nullptr; const float2 *rt = nullptr;
     uint32_t nf, nruns, parity0;
     uint32_t G = 1, g = 0;      // interleaved shard g of G (tables rotated by the plan)
+    bool tile_major = false;    // CF32 plane of the AGC route: [block of 16 frames][64][128 B]
     bool dc_block;
     double beta;
 };

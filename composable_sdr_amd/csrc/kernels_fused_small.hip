@@ -442,6 +442,11 @@ int small_reset(SmallPlan *p, hipStream_t s)
 
 void small_seek(SmallPlan *p, uint64_t frames) { p->frames_done = frames; }
 
+bool small_tile_major_ok(const SmallPlan *p, uint32_t nf)
+{
+    return p && p->v2_ok && !p->cfg.mix && !p->cfg.fm && (uint64_t)p->cfg.C * nf * 8u < (1ull << 32) && run64_v2_runs(nf, p->cus) != 0;
+}
+
 int small_process(SmallPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *timer)
 {
     const FusedConfig &c = p->cfg;
@@ -450,6 +455,7 @@ int small_process(SmallPlan *p, const FusedCall &call, hipStream_t s, KernelTime
     int r;
     const uint32_t v2runs = (p->v2_ok && (uint64_t)c.C * nf * 8u < (1ull << 32)) ? run64_v2_runs(nf, p->cus) : 0;
     p->v2_last = v2runs != 0;
+    if (call.tile_major && !v2runs) { set_error("small_process: tile-major output asked for a call k_run64v2 does not take"); return -1; }
     if (v2runs) {
         Run64v2Host H{};
         H.x = call.d_in; H.out = (float2 *)(c.mix ? p->d_premix : call.d_out);
@@ -457,6 +463,7 @@ int small_process(SmallPlan *p, const FusedCall &call, hipStream_t s, KernelTime
         H.uhist_in = p->d_yhist[p->cur]; H.uhist_out = p->d_yhist[p->cur ^ 1];
         H.vend_in = p->d_vend[p->cur]; H.vend_out = p->d_vend[p->cur ^ 1];
         H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
+        H.tile_major = call.tile_major;
         H.cpre = v2runs <= 1024u ? p->d_cpre : nullptr; H.rt = p->d_rt;
         H.dc_block = c.dc_block; H.beta = c.dc_block ? (double)c.dc.beta : 0.0;
         if ((r = run64_v2_launch(H, s, timer))) return r;

@@ -41,6 +41,7 @@ struct Run64v2Args {
     const float2 *uhist_in; float2 *uhist_out;    // [13][64] pre-mixed, DC-blocked window before / after the call
     const float2 *vend_in; float2 *vend_out;      // DC blocker state v1
     uint32_t nf, nb, nruns, n0, parity0, out_stride;
+    uint32_t tile_major;        // the lines of a 16-frame block back to back, [block][64][128 B] (the plane k_agc_spec_tm reads), instead of rows [64][nf]
     float alpha, beta, l2beta;
     float b16[16], b256[17];
     uint32_t nowu;              // 1: a run starts its halo tile from DC state 0 and leaves the state in front of its last tile in cpre[w + 1];
@@ -157,8 +158,12 @@ __global__ __launch_bounds__(256, 2) void k_run64v2(Run64v2Args A)
     // block-local layouts (float2 inside the block): X[i][jj] at 64 i + (jj ^ 4 i); Z[f][k1][b] at 64 f + ((4 k1 + b) ^ 4 f)
     const int fl = (tid & 63) >> 2, b1 = tid & 3;                               // pass 1: frame in the block, b
     const int f2 = tid & 15, k4 = (tid & 63) >> 4;                              // pass 2 / tail: frame in the block, channel group
-    const uint32_t voff = ((uint32_t)k4 * A.out_stride + 16u * qw + (uint32_t)f2) * 8u;     // + (4 m + 16 k2) rows, + 64 b frames
-    const size_t rowb = (size_t)A.out_stride * 8u;
+    // row-major: channel k, frame t at (k nf + t) 8; tile-major: ((t >> 4) 64 + k) 128 + (t & 15) 8 with t >> 4 = 4 b + qw, t & 15 = f2:
+    // a 16-lane row stores one 128-byte line either way
+    const uint32_t voff = A.tile_major ? (uint32_t)k4 * 128u + 8192u * qw + 8u * (uint32_t)f2
+                                       : ((uint32_t)k4 * A.out_stride + 16u * qw + (uint32_t)f2) * 8u;     // + (4 m + 16 k2) rows, + 64 b frames
+    const size_t rowb = A.tile_major ? (size_t)128 : (size_t)A.out_stride * 8u;
+    const size_t tileb = A.tile_major ? (size_t)32768 : (size_t)512;               // bytes between the first lines of consecutive tiles
 
     auto tile = [&](unsigned b_, const int par, const bool warm) {
         unsigned b = (unsigned)__builtin_amdgcn_readfirstlane((int)b_);
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void k_run64v2(Run64v2Args A)
         for (int i = 0; i < 16; i++) Bf[blk + 64 * fl + (unsigned)((4 * XIDX(i) + b1) ^ (4 * fl))] = to_f2(vv[i]);     // Z[fl][k1][b1]
         // ---- pass 2 + stores: lane (f2, k4): radix 4 over b for k1 = k4 + 4 m; Y[k1 + 16 k2] of frame 16 qw + f2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // next tile image (issued at the top of this tile): nothing else is outstanding
-        char *obase = reinterpret_cast<char *>(A.out) + (size_t)64 * b * 8u;
+        char *obase = reinterpret_cast<char *>(A.out) + tileb * b;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const int k1 = k4 + 4 * m;                  // (runtime k4: the address below is lane arithmetic)
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void k_run64_dcfix(Run64v2Args A, const float2
     const unsigned ch = e / RUN64_DCFIX_F, t = e % RUN64_DCFIX_F;
     const size_t fr = (size_t)64 * first + t;
     if (fr >= (size_t)64 * last) return;                // (runs are >= 14 tiles: never)
-    float2 *o = A.out + (size_t)(30u + ch) * A.out_stride + fr;
+    float2 *o = A.out + (A.tile_major ? ((fr >> 4) * 64u + (30u + ch)) * 16u + (fr & 15u) : (size_t)(30u + ch) * A.out_stride + fr);
     const float2 r = rt[((size_t)par * RUN64_DCFIX_F + t) * 4u + ch];
     float2 y = *o;
     y.x += c.x * r.x - c.y * r.y; y.y += c.x * r.y + c.y * r.x;
@@ -353,7 +358,7 @@ int run64_v2_launch(const Run64v2Host &h, hipStream_t s, KernelTimer *timer)
     Run64v2Args A{};
     A.x = h.x; A.out = h.out; A.taps = h.taps; A.tw = h.tw; A.wpre = h.wpre;
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
-    A.nf = h.nf; A.nb = h.nf / 64u; A.nruns = h.nruns; A.parity0 = h.parity0; A.out_stride = h.nf;
+    A.nf = h.nf; A.nb = h.nf / 64u; A.nruns = h.nruns; A.parity0 = h.parity0; A.out_stride = h.nf; A.tile_major = h.tile_major ? 1u : 0u;
     {
         static const double wt = diag_env("CSDR_RUN64_WEIGHT") ? atof(diag_env("CSDR_RUN64_WEIGHT")) : 1.1;   // share of the older workgroup of a CU (1 = even; 1.1 measured best: 243 vs 250 us)
         A.n0 = (h.nruns >= 2 && !(h.nruns & 1u) && wt > 1.0 && wt < 1.5) ? (uint32_t)std::llround(0.5 * wt * (double)A.nb) : 0u;

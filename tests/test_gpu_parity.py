@@ -1533,6 +1533,45 @@ def test_agc_tail_tile_major_route_at_1024_channels_is_bit_identical_to_sequenti
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("demod", ["fm", "none"])
+def test_agc_tail_tile_major_route_at_64_channels_is_bit_identical_to_sequential(demod, monkeypatch):
+    """The same at M = 64 (round 6): k_run64v2 writes the plane tile-major -- a 16-lane row of its stores is one 128-byte line either
+    way -- for k_agc_spec_tm (64 channels = exactly one wave per time position); against the one-lane-per-channel kernels behind the
+    row-major plane, BIT FOR BIT, keyed signal, state carried over run-sized, ragged and short calls, with and without the cold-start
+    correction of the four channels around DC (k_run64_dcfix on the tile-major plane)."""
+    import torch
+    from composable_sdr_amd import _lib
+    M, kf = 64, 0.3
+    knob(monkeypatch, "CSDR_AGC_W", "512")
+    knob(monkeypatch, "CSDR_AGC_L_TM", "688")
+    knob(monkeypatch, "CSDR_RUN64_V2_ALL", "1")          # k_run64v2 below its size threshold (3072 tiles), so that the test stays small
+    frames = [16384, 16384 + 64, 33, 8192 + 128]
+    dev = torch.device("cuda", 0)
+    xd = _bursty_torch(M, sum(frames), 978, dev)
+    kw = dict(channels=M, demod=demod, kf=kf, agc=8.0, max_frames=max(frames))
+    a = cs.Chain(flags=_lib.FLAG_QUIET, **kw)
+    b = cs.Chain(flags=_lib.FLAG_QUIET | _lib.FLAG_AGC_SEQUENTIAL, **kw)
+    w = 1 if demod == "fm" else 2
+    pos, names = 0, []
+    for f in frames:
+        oa = torch.zeros(M * f * w, dtype=torch.float32, device=dev); ob = torch.zeros_like(oa)
+        ptr = xd.data_ptr() + pos * M * 8
+        a.process_device(ptr, M * f, oa.data_ptr(), 0)
+        b.process_device(ptr, M * f, ob.data_ptr(), 0)
+        torch.cuda.synchronize()
+        names.append(a.kernel_time()[0])
+        assert torch.equal(oa.view(torch.int32), ob.view(torch.int32)), (demod, f, pos)
+        opened = float((ob != 0).float().mean())
+        assert 0.02 < opened < 0.98 or f < 100, opened
+        pos += f
+    checked, redone = a.agc_stats()
+    tmc = a.agc_tile_major_calls()
+    print(f"tile-major AGC tail at 64 channels, {demod}: {tmc} of {len(frames)} calls on k_agc_spec_tm ({names}); segments checked {checked}, recomputed {redone}")
+    assert tmc == 3 and names[0] == names[1] == names[3] == "k_run64v2"
+    a.status(); b.status()
+    a.close(); b.close()
+
+
 def test_agc_tail_steady_state_needs_no_recompute():
     """on a stationary signal (the bench's) the speculation always verifies after the first call"""
     from composable_sdr_amd import _lib
