@@ -643,7 +643,7 @@ const RouteRow ROUTES[] = {
      "k_front4096 (DC blocker + pre-mix + FIR, branch-tiled: four sibling workgroups per frame, radix-4 split of the DFT on the registers) -> z (8 B / sample) "
      "-> k_back4096<CF32 | FM | FM,mix> (four 1024-point DFTs per frame, 16-frame blocks, whole 128-byte lines per row) [-> k_mix4096_finish]; whole band; "
      "DeNo --mix without the AGC keeps the any-M route's mix identity",
-     "the same kernels (any call size; short calls use fewer runs)", "k_front4096 -> k_back4096<CF32> -> CF32 plane -> k_agc_spec -> k_agc_fix [-> k_mix]"},
+     "the same kernels (any call size; short calls use fewer runs)", "k_front4096 -> k_back4096<CF32> -> CF32 plane (tile-major: calls of whole 16-frame blocks, >= 4096 frames) -> k_agc_spec_tm | k_agc_spec -> k_agc_fix [-> k_mix]"},
     {0, ST_ANY, PLAN_GENERIC, "generic",
      "k_dc_tile -> k_pfb_fir (M = 1024, forced generic: k_pfb1024) -> k_fft_r16 | k_fft_pow2 | k_dft_direct [interleaved shard: k_fold + (M / G)-point DFT] "
      "-> k_transpose_fm | k_mix_frames | k_transpose;  DeNo --mix over all channels: k_dc_fold + k_mixid_finish (M % 4096 == 0) | k_dc_tile + k_branch0_fir "
@@ -888,7 +888,7 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             // (the fused M = 256 plans may write it tile-major for k_agc_spec_tm, which reads up to a segment in front of / behind the plane)
             // The guards (2 x 64 KiB per channel: 128 MiB at 1024 channels) exist only where a call can take that route: a time-parallel
             // tail (not CSDR_FLAG_AGC_SEQUENTIAL), a channel count k_agc_spec_tm takes, calls of >= 4 W = 4096 frames
-            const bool tm_possible = (h->fused || h->big || h->small) && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL) && h->max_nf >= 4096u &&
+            const bool tm_possible = (h->fused || h->big || h->small || h->huge) && !(cfg->flags & CSDR_FLAG_AGC_SEQUENTIAL) && h->max_nf >= 4096u &&
                                      (C % 64u == 0 || (C < 64u && 64u % C == 0));
             h->a_guard = tm_possible ? agc_tail_tm_guard(C) : 0;
             if ((r = dev_alloc(&h->d_A, (size_t)C * h->max_nf + 2 * h->a_guard))) return fail(r);
@@ -1231,7 +1231,7 @@ static int chain_process_device_inner(csdr_chain *h, const void *d_in, uint32_t 
         FusedCall fcall{};
         // AGC tail behind the fused M = 256 / M = 1024 chains, run-sized calls of whole tiles: the plane between the two kernels is tile-major
         const bool tm = agc_on && h->agc_tail && h->a_guard && Z != (float2 *)d_out && agc_tail_tm_supported(h->agc_tail, nf) &&
-                        (h->fused ? fused_tile_major_ok(h->fused, nf) : h->big ? big_tile_major_ok(h->big, nf) : (h->small && small_tile_major_ok(h->small, nf)));
+                        (h->fused ? fused_tile_major_ok(h->fused, nf) : h->big ? big_tile_major_ok(h->big, nf) : h->small ? small_tile_major_ok(h->small, nf) : (h->huge && huge_tile_major_ok(h->huge, nf)));
         fcall.tile_major = tm;
         fcall.d_in = (const float2 *)d_in; fcall.d_out = agc_on ? (void *)Z : d_out; fcall.nf = nf; fcall.theta0 = h->theta;
         fcall.indep = h->call_indep; fcall.ev_tail = h->call_ev_tail;

@@ -89,6 +89,7 @@ int  huge_reset(HugePlan *plan, hipStream_t s);
 int  huge_process(HugePlan *plan, const FusedCall &call, hipStream_t s, KernelTimer *timer);
 void huge_seek(HugePlan *plan, uint64_t frames);
 const char *huge_name(const HugePlan *plan);
+bool huge_tile_major_ok(const HugePlan *plan, uint32_t nf);      // CF32 output, whole 16-frame blocks, no mix inside the plan
 void huge_destroy(HugePlan *plan);
 
 // k_run64v2 (kernels_run64_v2.hip): whole-band M = 64 calls with CF32 output and nf % 64 == 0; same state buffers as k_run64

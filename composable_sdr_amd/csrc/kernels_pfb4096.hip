@@ -241,6 +241,7 @@ struct Back4096Args {
     void *out;                  // MODE 0: [4096][nf] CF32; 1: [4096][nf] F32; 2: partial mixes [nblk][4][16] F32
     const float2 *tw;           // W1024^i
     uint32_t nf, out_stride;
+    uint32_t tile_major;        // MODE 0: the 128-byte lines of a 16-frame block back to back, [block][4096][128 B] (the plane k_agc_spec_tm reads); nf % 16 == 0
     PhaseK pk; float fm_ref, tiny;
 };
 
@@ -384,7 +385,8 @@ __global__ __launch_bounds__(1024, 1) void k_back4096(Back4096Args A)
             for (int i = 0; i < 8; i++) {
                 const int rowl = 64 * (int)wv + 8 * i + (lane >> 3), piece = lane & 7;
                 const float2 a = *reinterpret_cast<const float2 *>(T + rowl * K_ROWB + 16 * piece), b = *reinterpret_cast<const float2 *>(T + rowl * K_ROWB + 16 * piece + 8);
-                float2 *dst = reinterpret_cast<float2 *>(A.out) + (size_t)(4 * rowl + (int)r) * A.out_stride + col0 + 2 * piece;
+                float2 *dst = reinterpret_cast<float2 *>(A.out) + (A.tile_major ? ((size_t)blk * 4096u + (size_t)(4 * rowl + (int)r)) * 16u + 2 * piece
+                                                                                : (size_t)(4 * rowl + (int)r) * A.out_stride + col0 + 2 * piece);
                 *reinterpret_cast<float4 *>(dst) = make_float4(a.x, a.y, b.x, b.y);
             }
         } else {
@@ -507,6 +509,8 @@ int huge_process(HugePlan *p, const FusedCall &call, hipStream_t s, KernelTimer 
     hipLaunchKernelGGL(k_front4096, dim3(4 * A.nruns), dim3(512), 0, s, A);
     Back4096Args Bk{};
     Bk.z = p->d_z; Bk.tw = p->d_tw; Bk.nf = nf; Bk.out_stride = nf;
+    Bk.tile_major = (call.tile_major && !c.fm && !c.mix) ? 1u : 0u;
+    if (call.tile_major && (!Bk.tile_major || (nf & 15u))) { set_error("huge_process: tile-major output asked for a call k_back4096<CF32> does not take"); return -1; }
     Bk.pk = phase_consts(1.0f); Bk.pk.hp *= c.fm_ref; Bk.pk.pi *= c.fm_ref; Bk.pk.ref = c.fm_ref;
     Bk.fm_ref = c.fm_ref; Bk.tiny = 1e-37f;
     const uint32_t nblk = (nf + 15) / 16;
@@ -535,5 +539,7 @@ int huge_process(HugePlan *p, const FusedCall &call, hipStream_t s, KernelTimer 
     p->frames_done += nf;
     return 0;
 }
+
+bool huge_tile_major_ok(const HugePlan *p, uint32_t nf) { return p && !p->cfg.fm && !p->cfg.mix && nf && (nf & 15u) == 0; }
 
 }  // namespace csdr

@@ -1572,6 +1572,38 @@ def test_agc_tail_tile_major_route_at_64_channels_is_bit_identical_to_sequential
     a.close(); b.close()
 
 
+def test_agc_tail_tile_major_route_at_4096_channels_is_bit_identical_to_sequential(monkeypatch):
+    """The same at M = 4096 (round 6): k_back4096<CF32> stores its 16-frame blocks' lines back to back for k_agc_spec_tm (64 channel groups
+    of 64); FM output against the one-lane-per-channel kernels behind the row-major plane, BIT FOR BIT, over a tile-major, a second
+    tile-major and a short row-major call with the state carried."""
+    import torch
+    from composable_sdr_amd import _lib
+    M, kf = 4096, 0.3
+    knob(monkeypatch, "CSDR_AGC_W", "512")
+    knob(monkeypatch, "CSDR_AGC_L_TM", "688")
+    frames = [4096, 2048 + 16, 33]
+    dev = torch.device("cuda", 0)
+    xd = _bursty_torch(M, sum(frames), 979, dev)
+    kw = dict(channels=M, demod="fm", kf=kf, agc=8.0, max_frames=max(frames))
+    a = cs.Chain(flags=_lib.FLAG_QUIET, **kw)
+    b = cs.Chain(flags=_lib.FLAG_QUIET | _lib.FLAG_AGC_SEQUENTIAL, **kw)
+    assert "fused-4096" in a.path
+    pos = 0
+    for f in frames:
+        oa = torch.zeros(M * f, dtype=torch.float32, device=dev); ob = torch.zeros_like(oa)
+        ptr = xd.data_ptr() + pos * M * 8
+        a.process_device(ptr, M * f, oa.data_ptr(), 0)
+        b.process_device(ptr, M * f, ob.data_ptr(), 0)
+        torch.cuda.synchronize()
+        assert torch.equal(oa.view(torch.int32), ob.view(torch.int32)), (f, pos)
+        pos += f
+    tmc = a.agc_tile_major_calls()
+    print(f"tile-major AGC tail at 4096 channels: {tmc} of {len(frames)} calls on k_agc_spec_tm; segments {a.agc_stats()}")
+    assert tmc == 2
+    a.status(); b.status()
+    a.close(); b.close()
+
+
 def test_agc_tail_steady_state_needs_no_recompute():
     """on a stationary signal (the bench's) the speculation always verifies after the first call"""
     from composable_sdr_amd import _lib
