@@ -88,3 +88,24 @@ def test_agc_spec_tm_keeps_its_block_registers_out_of_scratch(tmp_path):
     for b in blocks:
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, b[:600]
         assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_shard1024_keeps_its_window_and_taps_in_registers(tmp_path):
+    """k_shard1024<FM | CF32, G> (round 6; 512 threads, one workgroup per CU = two waves per SIMD = 256 VGPRs): the 16-frame x 2-branch window
+    ring (64 VGPRs) and the 28 taps + 4 phasors of a thread's two branches must stay in registers for the whole run -- a VGPR spill would put
+    a scratch round trip into every step -- and the three tile buffers, the partial folds, Y, the stash and the per-row output staging must
+    fit a CU's 160 KiB.  (SGPR spills are tolerated here: the DMA asm block puts seven wait states between a reloaded scalar and the
+    VMEM instruction that reads it, fused_v2_common.h dma_piece.)"""
+    src = os.path.join(ROOT, "composable_sdr_amd", "csrc")
+    out = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-c", os.path.join(src, "kernels_shard1024.hip"),
+                          "-o", str(tmp_path / "s1.o"), "-Rpass-analysis=kernel-resource-usage"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    blocks = [b for b in re.split(r"remark: Function Name: ", out.stderr)[1:] if "k_shard1024I" in b.splitlines()[0]]
+    assert len(blocks) == 4                               # <FM | CF32> x G = 4, 8
+    for b in blocks:
+        assert int(re.search(r"VGPRs Spill: (\d+)", b).group(1)) == 0, b[:600]
+        assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, b[:600]
+        assert int(re.search(r"LDS Size \[bytes/block\]: (\d+)", b).group(1)) <= 160 * 1024
+        assert int(re.search(r"Occupancy \[waves/SIMD\]: (\d+)", b).group(1)) == 2
