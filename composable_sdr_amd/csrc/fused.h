@@ -119,7 +119,6 @@ struct Run1024v2Host {
     const float4 *taps_q;       // [4][4][256] float4: taps of branch 256 q + j (14) + its even-frame pre-mix phasor
     const float2 *tw;
     const float2 *uhist_in; float2 *uhist_out; const float2 *vend_in; float2 *vend_out; const float2 *rp_in; float2 *rp_out;
-    char *stage;                // [nruns] output staging blocks of 128 KiB
     uint32_t nf, nruns, parity0;
     uint32_t G = 1, g = 0;      // interleaved shard g of G (tables rotated by the plan)
     bool tile_major = false;    // k_run1024v3<CF32>: the lines of a 16-frame block back to back ([block][1024][128 B]) instead of row-major [1024][nf]

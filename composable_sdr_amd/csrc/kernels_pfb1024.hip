@@ -466,7 +466,6 @@ struct BigPlan {
     float2 *d_tw = nullptr, *d_wpre = nullptr;
     float2 *d_uhist[2] = {nullptr, nullptr}, *d_vend[2] = {nullptr, nullptr}, *d_rp[2] = {nullptr, nullptr};
     float2 *d_scratch = nullptr;     // yfirst | ylast
-    char *d_stage = nullptr;         // (k_run1024v2's whole-band staging blocks: no longer built, never allocated)
     void *d_full = nullptr;          // interleaved shard, calls k_run1024v2 does not take: whole-band result [1024][max_nf] (allocated on first use)
     void *d_premix = nullptr;
     float2 *d_cpre = nullptr, *d_side = nullptr, *d_rt = nullptr;       // k_run1024v3 without warm-up windows (Run1024v2Host::cpre / side / rt)
@@ -479,7 +478,7 @@ void big_destroy(BigPlan *p)
 {
     if (!p) return;
     void *ptrs[] = {p->d_taps, p->d_taps_t, p->d_taps_q, p->d_tw, p->d_wpre, p->d_uhist[0], p->d_uhist[1], p->d_vend[0], p->d_vend[1], p->d_rp[0], p->d_rp[1],
-                    p->d_scratch, p->d_premix, p->d_stage, p->d_full, p->d_cpre, p->d_side, p->d_rt};
+                    p->d_scratch, p->d_premix, p->d_full, p->d_cpre, p->d_side, p->d_rt};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -645,7 +644,6 @@ int big_process(BigPlan *p, const FusedCall &call, hipStream_t s, KernelTimer *t
         H.uhist_in = p->d_uhist[p->cur]; H.uhist_out = p->d_uhist[p->cur ^ 1];
         H.vend_in = p->d_vend[p->cur]; H.vend_out = p->d_vend[p->cur ^ 1];
         H.rp_in = p->d_rp[p->cur]; H.rp_out = p->d_rp[p->cur ^ 1];
-        H.stage = p->d_stage;
         H.nf = nf; H.nruns = v2runs; H.parity0 = (uint32_t)(p->frames_done & 1);
         H.G = c.G; H.g = c.G > 1 ? c.c0 : 0u;
         H.tile_major = call.tile_major && (v3runs || s1runs) && !c.fm;

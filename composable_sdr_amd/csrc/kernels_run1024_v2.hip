@@ -1,11 +1,11 @@
-// Second-generation run kernel of the fused M = 1024 chain (BASELINE configs[3] shape).
-// ROUND 4: only the INTERLEAVED-SHARD instantiations k_run1024v2<FM, G>, G = 2, 4, 8, are still built (see "G > 1" below); every whole-band
-// call of whole tiles goes to k_run1024v3 (kernels_run1024_v3.hip), so the staging block and its flush (G == 1 paths, kept in the source as
-// the record of round 3's measurements: `git show 5b4db89:DESIGN.md`, section 4.2c) are never instantiated.
+// Second-generation run kernel of the fused M = 1024 chain, INTERLEAVED-SHARD instantiations k_run1024v2<FM, G> only (round 3).
+// Since round 6 the route table sends the strides G = 4, 8 to k_shard1024 (kernels_shard1024.hip) and only G = 2 comes here; the G = 4, 8
+// instantiations stay built behind CSDR_NO_SHARD1024=1 (the A/B of profiles/r06_shard1024_call_sizes.txt).  The whole-band form of this
+// kernel (a 128 KiB global staging block per workgroup, read back transposed: DESIGN of round 3, `git show 5b4db89:DESIGN.md` 4.2c) was
+// replaced by k_run1024v3 in round 4 and its code was removed from this file in round 6.
 //
-//   raw CF32 x --DC blocker--> y --NCO pre-mix, 14-tap polyphase FIR--> X_t[j] --1024-point forward DFT (16 x 16 x 4)--> Y_t[k]
-//              --per-channel freqdem--> out[1024][nf]              (8 B read + 4 / 8 B written per sample, Liquid.chs:575-589,
-//                                                                    828-862, 324-328)
+//   raw CF32 x --DC blocker--> y --NCO pre-mix, 14-tap polyphase FIR--> X_t[j] --1024-point forward DFT (16 x 16 x 4), pruned to the
+//              shard's bins--> Y_t[k], k = g (mod G) --per-channel freqdem--> out[1024 / G][nf]     (Liquid.chs:575-589, 828-862, 324-328)
 //
 // Built the way k_run256v2 is (kernels_fused_v2.hip): 256 threads, two workgroups per CU, a TILE is 4096 consecutive
 // samples = 4 frames, DMA'd into one of two 32 KiB LDS buffers a tile ahead and transformed in place:
@@ -15,13 +15,7 @@
 //   --pass 3, thread kk = k1 + 16 k2: radix 4 over d for all four frames--> Y[kk + 256 k3], frames 0..3 in registers.
 // Passes 1 and 2 read and write only their wave's frame block (an LDS image a wave writes and then reads needs no
 // barrier), so a tile takes 4 barriers.  The tail thread holds four consecutive frames of four channels: the previous
-// frame of a channel is a register-wide read of the stash (no DPP).
-// OUTPUT.  A tile holds 16 (F32) / 32 (CF32) bytes of every one of the 1024 channel rows; stored as such, 512 workgroups keep
-// 64 MiB of 128-byte lines half-written and the L2s (32 MiB) evict them piecemeal: 401 us (F32) / 550 us (CF32) per 67 M
-// samples against 300 / 275 us with the same bytes stored contiguously.  So a tile's results go, fully coalesced, into a
-// 128 KiB per-workgroup staging block [tile][channel][piece] (L2 / Infinity-Cache resident), and once a block spans a whole line per row
-// (8 tiles F32, 4 tiles CF32, aligned to absolute tile indices; a run that starts or ends inside a block writes partial lines there) the workgroup reads it back transposed and writes every
-// row's 128 bytes with eight lanes of one store instruction.
+// frame of a channel is a register-wide read of the stash (no DPP).  A tile's 16 bytes per owned row are stored directly.
 // The 56 taps of a thread's four branches do not fit next to the window: they are re-read per tile from a 64 KiB table
 // (L2-resident, fully coalesced 16-byte loads; the row of a branch ends with its even-frame pre-mix phasor, the odd-frame one
 // comes from a second table) at the top of the tile and
@@ -36,17 +30,11 @@
 #ifndef B2_FM_PACKED
 #define B2_FM_PACKED 1    // freqdem on packed pairs (fm_quad) or one sample at a time (fm_sample)
 #endif
-#ifndef B2_DIRECT
-#define B2_DIRECT 0      // 1: every tile stores its 16 / 32-byte row pieces straight into the rows (no staging block): the measured alternative
-#endif
 // Every asm store of more than 64 bits ends with s_nop 1: the store reads its data VGPRs for two more wait states, hipcc pads
 // that for its own stores but cannot see one inside inline asm (it reused the registers in the very next instruction: lanes
 // 12..15 of every row of 16 lost the second dword).
 #ifndef B2_STORE_MOD
 #define B2_STORE_MOD ""  // cache policy bits of the output stores (experiments: " nt", " sc1", " sc0 sc1")
-#endif
-#ifndef B2_VOFF
-#define B2_VOFF voff     // experiments: joff_t = rows 16 bytes apart (fully coalesced, wrong place)
 #endif
 
 namespace csdr {
@@ -68,7 +56,6 @@ struct Run1024v2Args {
     const float2 *uhist_in; float2 *uhist_out;    // [13][1024] pre-mixed, DC-blocked window before / after the call
     const float2 *vend_in; float2 *vend_out;      // DC blocker state v1
     const float2 *rp_in; float2 *rp_out;          // [1024] freqdem r'
-    char *stage;                // [nruns] staging blocks of 128 KiB
     uint32_t nf, nb, nruns, n0, parity0, out_stride;   // n0: tiles of the first half of the runs (0: even split)
     uint32_t g;                 // G > 1: shard index (informational: the tables carry the shift by g channels, see the kernel)
     float alpha, beta, l2beta, fm_ref, tiny;
@@ -105,7 +92,7 @@ __host__ __device__ __forceinline__ void run_bounds(uint32_t nb, uint32_t nruns,
 template <bool FM, int G>
 __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
 {
-    static_assert(G == 1 || (FM && (G == 2 || G == 4 || G == 8)), "interleaved shards: F32 output, G = 2, 4, 8");
+    static_assert(FM && (G == 2 || G == 4 || G == 8), "interleaved shards only: F32 output, G = 2, 4, 8");
     __shared__ __attribute__((aligned(16))) float2 L[B2_F2];
     float2 *tw1 = L + B2_TW1, *ST = L + B2_ST, *Tt = L + B2_TT, *red = ST;
     const int tid = threadIdx.x, j = tid;
@@ -345,19 +332,14 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
 #pragma unroll
         for (int a = 0; a < 16; a++) vv[a] = to_v(*reinterpret_cast<const float2 *>(B + fb + 512 * a + (x_a ^ (unsigned)((a & 3) << 5))));
         fft16_v(vv);
-        if (G == 1) {
 #pragma unroll
-            for (int i = 1; i < 16; i++) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (XIDX(i) - 1) + b1]));
-        } else {
-#pragma unroll
-            for (int i = 1; i < 16; i++)                // rows k1' = 0 mod G only (the spectrum arrives shifted by g: see the tables)
-                if (XIDX(i) % G == 0) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (XIDX(i) - 1) + b1]));
-        }
+        for (int i = 1; i < 16; i++)                // rows k1' = 0 mod G only (the spectrum arrives shifted by g: see the tables)
+            if (XIDX(i) % G == 0) vv[i] = cmul_v(vv[i], to_v(tw1[64 * (XIDX(i) - 1) + b1]));
 #pragma unroll
         for (int i = 0; i < 16; i++)
             if (XIDX(i) % G == 0) *reinterpret_cast<float2 *>(B + fb + 512 * XIDX(i) + (z1w ^ (unsigned)(((2 * XIDX(i)) & 6) << 4))) = to_f2(vv[i]);
         // ---- DFT pass 2: same wave, lane (k1, d): radix 16 over c (b = 4 c + d); a shard's lanes of the rows it did not write sit it out
-        if (G == 1 || ((l2 >> 2) % G) == 0) {
+        if (((l2 >> 2) % G) == 0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const v4f v = *reinterpret_cast<const v4f *>(B + (z1r ^ (unsigned)(i << 4)));
@@ -374,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
         }
         bar();                                          // B_h: Z2 of all four frames complete
         // ---- DFT pass 3 + tail: thread kk = k1 + 16 k2, all four frames; Y[f][k3] = channel kk + 256 k3
-        if (G > 1 && ((tid & 15) % G) != 0) return;      // shard: threads of the rows it does not own are done (no barrier follows on this path)
+        if (((tid & 15) % G) != 0) return;              // threads of the rows the shard does not own are done (no barrier follows on this path)
         v2f y[4][4];
 #pragma unroll
         for (int f = 0; f < 4; f++) {
@@ -383,15 +365,7 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
             y[f][0] = (v2f){v0.x, v0.y}; y[f][1] = (v2f){v0.z, v0.w}; y[f][2] = (v2f){v1.x, v1.y}; y[f][3] = (v2f){v1.z, v1.w};
             bfly4_v(y[f][0], y[f][1], y[f][2], y[f][3]);
         }
-        // ---- tail: results into slot ts of the staging block (each store instruction: 1 KiB contiguous)
-#ifndef B2_HALF_LINES
-#define B2_HALF_LINES 0  // 1: blocks of half a line per row (4 / 2 tiles, 64 KiB of staging per workgroup): measured, slower
-#endif
-        constexpr unsigned PB = FM ? 16u : 32u;                                  // bytes per (tile, row) piece
-        constexpr unsigned TB = (FM ? 8u : 4u) >> B2_HALF_LINES;                 // tiles per block
-        constexpr unsigned UL = TB * PB / 16u;                                   // 16-byte units (= lanes) per row piece of a block: 8 or 4
-        const unsigned ts = b & (TB - 1u);
-        const char *sbase = A.stage + (size_t)w * 131072u + (size_t)ts * (1024u * PB);
+        // ---- tail: freqdem, then every owned row gets its 16 bytes of this tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // next tile image: nothing else is outstanding
         if (FM) {
             char *stp = reinterpret_cast<char *>(ST) + z2r_t;      // my 32 bytes of the stash: [kk][k3]
@@ -418,65 +392,12 @@ __global__ __launch_bounds__(256, 2) void k_run1024v2(Run1024v2Args A)
                     for (int u = 0; u < 4; u++) mq[u] = fm_sample(rp[u], rr[u], k1s);
                 }
                 const v4f mv = {mq[0], mq[1], mq[2], mq[3]};
-                const char *sp = sbase + k3 * (256 * 16);
-                const char *rowp = reinterpret_cast<const char *>(A.out) + (size_t)4 * b * esz + (size_t)k3 * 256 * A.out_stride * esz;
-                if (B2_ABLATE & 2) asm volatile("" :: "v"(mv), "s"(sp));
-                else if (G > 1) {
+                {
                     // row of (k1', k2, k3) in the shard's plane: k1'/G + (16/G) k2 + (256/G) k3; the k3 and frame terms are uniform
                     const unsigned mrow = ((unsigned)(tid & 15) / (unsigned)G + (16u / (unsigned)G) * ((unsigned)tid >> 4)) * A.out_stride * esz;
                     const char *rowg = reinterpret_cast<const char *>(A.out) + (size_t)4 * b * esz + (size_t)k3 * (256 / G) * A.out_stride * esz;
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"(mrow), "v"(mv), "s"(rowg) : "memory");
-                }
-                else if (B2_DIRECT) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(mv), "s"(rowp) : "memory");
-                else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"(joff_t), "v"(mv), "s"(sp) : "memory");
-            }
-        } else {
-            if (mute) return;
-#pragma unroll
-            for (int k3 = 0; k3 < 4; k3++) {
-                const v4f lo = {y[0][k3].x, y[0][k3].y, y[1][k3].x, y[1][k3].y}, hi = {y[2][k3].x, y[2][k3].y, y[3][k3].x, y[3][k3].y};
-                const char *sp = sbase + k3 * (256 * 32);
-                const char *rowp = reinterpret_cast<const char *>(A.out) + (size_t)4 * b * esz + (size_t)k3 * 256 * A.out_stride * esz;
-                if (B2_ABLATE & 2) asm volatile("" :: "v"(lo), "v"(hi), "s"(sp));
-                else if (B2_DIRECT) {
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(lo), "s"(rowp) : "memory");
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16" "\n\ts_nop 1" :: "v"((joff_t >> 4) * A.out_stride * esz), "v"(hi), "s"(rowp) : "memory");
-                } else {
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"(2u * joff_t), "v"(lo), "s"(sp) : "memory");
-                    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 offset:16" "\n\ts_nop 1" :: "v"(2u * joff_t), "v"(hi), "s"(sp) : "memory");
-                }
-            }
-        }
-        // ---- a block is complete (or the run ends): every row's 128 bytes leave in one piece
-        if (G == 1 && (ts == TB - 1u || b + 1 == last) && !(B2_ABLATE & (2 | 1024)) && !B2_DIRECT) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // the workgroup's staging stores are in L2 (one CU: same L1)
-            typedef unsigned v4u __attribute__((ext_vector_type(4)));
-            const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(A.stage) + (size_t)w * 131072u, 0, 131072, 0x00020000);
-            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, (int)(1024u * A.out_stride * esz), 0x00020000);
-            constexpr unsigned RW = 64u / UL, RS = 4u * RW, NS = 1024u / RS;       // rows per wave instruction, per step of the workgroup; steps
-            const unsigned lane = joff_t >> 4 & 63u, u = lane & (UL - 1u), rowl = RW * wave_u + lane / UL;    // 16-byte unit of the piece, row in a group of RS
-            const unsigned tsrc = FM ? u : (u >> 1);                            // the tile my unit comes from
-            const unsigned ld = FM ? (u * 1024u + rowl) * 16u : ((u >> 1) * 1024u + rowl) * 32u + (u & 1u) * 16u;
-            const unsigned st = rowl * A.out_stride * esz + u * 16u;
-            const unsigned o0 = 4u * (b - ts) * esz;                            // the block's first frame in a row
-            const unsigned ts_lo = (b - ts < first) ? (first & (TB - 1u)) : 0u;   // a run may start inside a block
-            const bool mine = tsrc <= ts && tsrc >= ts_lo;
-#ifndef B2_FLUSH_BATCH
-#define B2_FLUSH_BATCH 8                // 16 is no faster (the write-back is bandwidth-, not latency-bound), 32 spills
-#endif
-#pragma unroll 1
-            for (unsigned g = 0; g < NS / B2_FLUSH_BATCH; g++) {                 // loads of a batch go out together: one memory latency per batch
-                v4u v[B2_FLUSH_BATCH];
-#pragma unroll
-                for (unsigned i = 0; i < B2_FLUSH_BATCH; i++)
-                    v[i] = (B2_ABLATE & 256) ? (v4u){ld, st, g, i} : __builtin_amdgcn_raw_buffer_load_b128(srs, (int)ld, (int)((B2_FLUSH_BATCH * g + i) * RS * PB), 0);
-                if (B2_ABLATE & 512) {
-#pragma unroll
-                    for (unsigned i = 0; i < B2_FLUSH_BATCH; i++) asm volatile("" :: "v"(v[i]));
-                } else if (mine) {
-#pragma unroll
-                    for (unsigned i = 0; i < B2_FLUSH_BATCH; i++)
-                        __builtin_amdgcn_raw_buffer_store_b128(v[i], ors, (int)st, (int)(o0 + (B2_FLUSH_BATCH * g + i) * RS * A.out_stride * esz), 0);
+                    if (B2_ABLATE & 2) asm volatile("" :: "v"(mv), "s"(rowg));
+                    else asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" "\n\ts_nop 1" :: "v"(mrow), "v"(mv), "s"(rowg) : "memory");
                 }
             }
         }
@@ -525,7 +446,7 @@ int run1024_v2_launch(const Run1024v2Host &h, bool fm, hipStream_t s, KernelTime
     Run1024v2Args A{};
     A.x = h.x; A.out = h.out; A.taps_q = h.taps_q; A.tw = h.tw;
     A.uhist_in = h.uhist_in; A.uhist_out = h.uhist_out; A.vend_in = h.vend_in; A.vend_out = h.vend_out;
-    A.rp_in = h.rp_in; A.rp_out = h.rp_out; A.stage = h.stage;
+    A.rp_in = h.rp_in; A.rp_out = h.rp_out;
     A.nf = h.nf; A.nb = h.nf / B2_T4; A.nruns = h.nruns; A.parity0 = h.parity0; A.out_stride = h.nf;
     {
         static const double wt = diag_env("CSDR_RUN1024_WEIGHT") ? atof(diag_env("CSDR_RUN1024_WEIGHT")) : 1.2;   // share of the older workgroup of a CU (1 = even)

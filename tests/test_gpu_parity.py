@@ -2440,6 +2440,34 @@ def test_fused_interleaved_shard_run_sized_call_matches_oracle_rows(M, nf, cases
             assert e < 1e-5 and np.abs(got - want).max() < 1e-4 * np.abs(w_cf).max()
 
 
+def test_run1024v2_shard_kernels_behind_the_knob_match_oracle_rows(monkeypatch):
+    """k_run1024v2<FM, 4 | 8> stay built behind CSDR_NO_SHARD1024=1 (the A/B of profiles/r06_shard1024_call_sizes.txt; stride 2 is their
+    default route): the same direct comparison with the oracle's rows, so that the round-6 removal of the kernel's whole-band code
+    paths is pinned for every instantiation that is still compiled."""
+    import torch
+    from composable_sdr_amd import _lib
+    from synth import synth_cf32_torch
+    knob(monkeypatch, "CSDR_NO_SHARD1024", "1")
+    M, nf, kf = 1024, 12288, 0.3
+    x = synth_cf32_torch(M * nf, M, torch.device("cuda", 0), seed=612).cpu().numpy().view(np.complex64).reshape(-1)
+    w_fm = O.Chain(M, demod="fm", kf=kf).process(x)
+    r = np.abs(O.Chain(M).process(x))
+    ref = 1.0 / (2 * np.pi * kf)
+    for G, g in [(8, 6), (4, 3), (2, 0)]:
+        ch = cs.Chain(channels=M, demod="fm", kf=kf, chan_first=g, chan_stride=G, max_frames=nf, flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS)
+        got = ch.process(x)
+        kname = ch.kernel_time()[0]
+        ch.close()
+        assert kname == f"k_run1024v2<FM>/G{G}", kname
+        want, rr = w_fm[g::G], r[g::G]
+        d = np.abs(wrap_pm(got.astype(np.float64) - want, 1.0 / kf))
+        rmin = np.minimum(rr, np.concatenate([np.zeros((rr.shape[0], 1), rr.dtype), rr[:, :-1]], axis=1))
+        strong = rmin > 0.25 * r.max()
+        smax = float(d[strong].max()) if strong.any() else 0.0
+        print(f"{kname} g={g} vs oracle rows: median {np.median(d):.2e}, weighted max {(d * rmin).max() / r.max():.2e}, strong max {smax:.2e}")
+        assert (d * rmin).max() / r.max() < 2 * ref * 1e-4 and np.median(d) < 2e-5 and smax < 2e-5
+
+
 def test_submit_device_on_interleaved_shard_with_short_chunks():
     """csdr_chain_submit_device on a chan_stride = 2 chain with chunks of 1 .. 6 whole tiles.  Shards never
     run as independent launches and must not save a tail (the copy of the last WU + 1 tiles would read in front of the chunk):
