@@ -711,6 +711,8 @@ def main():
             side("shard_g8_m1024_fm", "rank 0 of 8, interleaved channel shard of the 1024-ch PFB + FM chain (128 owned channels): BASELINE configs[3] per rank", 1024, 65536, "fm", 0.0, False, 8 + 4 / 8, 8, 0)
             side("shard_g8_m1024_fm_agc", "rank 0 of 8, interleaved channel shard of the 1024-ch PFB + AGC (-a 10) + FM chain", 1024, 65536, "fm", 10.0, False, 8 + 4 / 8, 8, 0)
             side("shard_g2_m1024_fm", "rank 0 of 2, interleaved channel shard of the 1024-ch PFB + FM chain", 1024, 65536, "fm", 0.0, False, 8 + 4 / 2, 2, 0)
+            side("shard_g8_m4096_deno_mix", "rank 0 of 8, interleaved channel shard of the 4096-ch PFB, DeNo --mix (the shard's mix identity: the 8 surviving polyphase "
+                 "branches; its partial mix is what the all-reduce sums): BASELINE configs[4] per rank", 4096, 16384, "none", 0.0, True, 8 + 8 / 4096, 8, 0)
             side("cfg2_agc", "64-ch PFB + AGC (-a 10), DeNo (configs[1] shape with the AGC on)", 64, 1048576, "none", 10.0, False, 16)
             side("cfg4_shape_1gpu_agc", "1024-ch PFB + AGC (-a 10) + FM, all channels on one GPU", 1024, 65536, "fm", 10.0, False, 12)
             side("ref_chunk_m256_fm", "the reference's own chunk: 256 ch x 4096 frames per call, FM", 256, 4096, "fm", 0.0, False, 12)

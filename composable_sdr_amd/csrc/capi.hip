@@ -122,6 +122,7 @@ struct csdr_chain {
     bool dft_backward = false;       // CSDR_FLAG_DFT_BACKWARD: rows leave through d_perm and a row permutation k -> (M - k) mod M
     void *d_perm = nullptr;
     bool mix_identity = false;       // DeNo --mix over all channels: M * (branch-0 FIR) instead of bank + DFT + sum
+    bool mix_identity_shard = false; // the same for an interleaved shard g of G: (M / G) * sum of the G surviving branches' FIRs (round 6)
     float2 *d_u0 = nullptr, *d_u0hist = nullptr;     // branch-0 samples of the call behind p - 1 of history; history between calls (two copies, ping-pong)
     int u0_cur = 0;
     float2 *d_u = nullptr, *d_hist_tmp = nullptr, *d_A = nullptr, *d_B = nullptr;
@@ -647,7 +648,8 @@ const RouteRow ROUTES[] = {
     {0, ST_ANY, PLAN_GENERIC, "generic",
      "k_dc_tile -> k_pfb_fir (M = 1024, forced generic: k_pfb1024) -> k_fft_r16 | k_fft_pow2 | k_dft_direct [interleaved shard: k_fold + (M / G)-point DFT] "
      "-> k_transpose_fm | k_mix_frames | k_transpose;  DeNo --mix over all channels: k_dc_fold + k_mixid_finish (M % 4096 == 0) | k_dc_tile + k_branch0_fir "
-     "(the sum of all bins of a frame is M x branch 0)",
+     "(the sum of all bins of a frame is M x branch 0);  DeNo --mix of an interleaved shard (M % 4096 == 0, G = 2, 4, 8): k_dc_fold8 + k_mixid_shard_finish "
+     "(the shard's channel sum is M / G x the phasor sum of the G surviving branches)",
      "the same kernels (any call size)", "... -> k_transpose -> k_agc_spec -> k_agc_fix [-> k_fm] [-> k_mix]"},
 };
 const RouteRow *route_select(uint32_t M, uint32_t p, uint32_t G, uint32_t flags)
@@ -713,7 +715,7 @@ static int chain_init_state(csdr_chain *h, hipStream_t s)
     h->theta = 0; h->tab_pos = 0; h->rp_cur = 0;
     CSDR_HIP(hipMemsetAsync(h->d_dcstate, 0, sizeof(float2), s));
     if (h->d_u) CSDR_HIP(hipMemsetAsync(h->d_u, 0, sizeof(float2) * (size_t)(h->p - 1) * h->M, s));
-    if (h->d_u0hist) { CSDR_HIP(hipMemsetAsync(h->d_u0hist, 0, sizeof(float2) * 2 * (h->p - 1), s)); h->u0_cur = 0; }
+    if (h->d_u0hist) { CSDR_HIP(hipMemsetAsync(h->d_u0hist, 0, sizeof(float2) * 2 * (h->p - 1) * (h->mix_identity_shard ? h->G : 1u), s)); h->u0_cur = 0; }
     if (h->d_agc) { int r = launch_agc_init(h->d_agc, h->C, s); if (r) return r; }
     if (h->agc_tail) agc_tail_reset(h->agc_tail);
     if (h->d_rp[0]) {
@@ -915,6 +917,12 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             if ((r = dev_alloc(&h->d_u0, (size_t)(h->p - 1) + h->max_nf)) || (r = dev_alloc(&h->d_u0hist, 2 * (h->p - 1)))) return fail(r);
             h->path = "generic+mix-identity"; h->timed_kernel = (M % 4096u == 0) ? "k_dc_fold" : "k_dc_tile";   // refined per call
         }
+        // interleaved shard, DeNo --mix, no AGC: only the G branches (M / G) n2 survive the shard's channel sum (kernels_dc_tile.hip, k_dc_fold8)
+        h->mix_identity_shard = M > 1 && (G == 2 || G == 4 || G == 8) && (uint64_t)C * G == M && cfg->mix && cfg->demod == CSDR_DEMOD_NONE && cfg->agc_threshold_db == 0.0f &&
+                                h->dctile && !(cfg->flags & CSDR_FLAG_NO_MIX_IDENTITY) && !am && M % 4096u == 0 && (M / G) % 512u == 0;
+        if (h->mix_identity_shard) {
+            if ((r = dev_alloc(&h->d_u0hist, 2 * (size_t)(h->p - 1) * G))) return fail(r);
+        }
         if (G > 1) {
             const uint32_t Mg = M / G;
             std::vector<float2> twg(Mg), ph(G + Mg);
@@ -925,7 +933,8 @@ int csdr_chain_create(const csdr_chain_cfg *cfg_in, csdr_chain **out)
             if ((r = dev_alloc(&h->d_tw_g, Mg)) || (r = dev_alloc(&h->d_fold_ph, G + Mg)) || (r = dev_alloc(&h->d_fold, (size_t)Mg * h->max_nf))) return fail(r);
             if (hipMemcpy(h->d_tw_g, twg.data(), sizeof(float2) * Mg, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy(h->d_fold_ph, ph.data(), sizeof(float2) * (G + Mg), hipMemcpyHostToDevice) != hipSuccess) { set_error("chain: fold table upload failed"); return fail(CSDR_ERR_HIP); }
-            h->path = "generic+pruned-dft";
+            h->path = h->mix_identity_shard ? "generic+pruned-dft+shard-mix-identity" : "generic+pruned-dft";
+            if (h->mix_identity_shard) h->timed_kernel = "k_dc_fold8";
         }
     }
     if ((cfg_in->flags & CSDR_FLAG_DFT_BACKWARD) && M > 1 && !(cfg_in->mix != 0)) {
@@ -1006,6 +1015,20 @@ static int chain_generic(csdr_chain *h, const float2 *d_in, uint32_t nx, void *d
     if (M > 1) {
         const size_t hist = (size_t)(h->p - 1) * M;
         nco.theta0 = h->theta; nco.d_theta = h->d_theta; nco.tab_len = h->tab_len; nco.tab_pos = h->tab_pos; nco.up = 0;
+        if (h->mix_identity_shard && dctile_mix_identity_shard_supported(h->dctile, M, nx, h->p, h->G)) {
+            // the shard's channel sum = (M / G) x sum of the G surviving branches' FIRs (whole frames of M % 4096 == 0 samples; other calls
+            // fall through to the pruned-DFT route below, which shares no state with this one but the DC blocker's: see the create-time note)
+            const size_t hs = (size_t)(h->p - 1) * h->G;
+            float2 *hin = h->d_u0hist + (size_t)h->u0_cur * hs, *hout = h->d_u0hist + (size_t)(h->u0_cur ^ 1) * hs;
+            h->timed_kernel = "k_dc_fold8";
+            if ((r = h->timer.begin(s))) return r;
+            if ((r = dctile_mix_identity_shard(h->dctile, d_in, nx, nco, h->d_nco_tab, h->d_taps, M, h->p, h->G, h->c0, hin, hout, (float2 *)d_out, s))) return r;
+            if ((r = h->timer.end(s))) return r;
+            h->u0_cur ^= 1;
+            h->theta += nx * h->d_theta;
+            if (h->tab_len) h->tab_pos = (uint32_t)(((uint64_t)h->tab_pos + nx) % h->tab_len);
+            return 0;
+        }
         if (h->mix_identity) {
             // sum over ALL channels of a frame = M * X_t[0]: DC blocker + pre-mix on the whole stream, every M-th sample kept,
             // then the 2m-tap FIR of polyphase branch 0 (no bank, no DFT, no channel sum; 8 B read per input sample)

@@ -158,6 +158,11 @@ int  dctile_process(DcTilePlan *plan, const float2 *x, float2 *y, uint32_t n, bo
 bool dctile_mix_identity_supported(const DcTilePlan *plan, uint32_t M, uint32_t n, uint32_t taps_p);
 int  dctile_mix_identity(DcTilePlan *plan, const float2 *x, uint32_t n, const NcoParams &nco, const float2 *nco_tab, const float *taps,
                          uint32_t M, uint32_t taps_p, const float2 *hist_in, float2 *hist_out, float2 *out, hipStream_t s);
+// the mix identity of an interleaved channel shard g of G (G <= 8, (M / G) % 512 == 0): (M / G) sum_{n2 < G} W_G^(n2 g) x (FIR of branch
+// (M / G) n2); hist_in / hist_out: [G][p - 1]
+bool dctile_mix_identity_shard_supported(const DcTilePlan *plan, uint32_t M, uint32_t n, uint32_t taps_p, uint32_t G);
+int  dctile_mix_identity_shard(DcTilePlan *plan, const float2 *x, uint32_t n, const NcoParams &nco, const float2 *nco_tab, const float *taps,
+                               uint32_t M, uint32_t taps_p, uint32_t G, uint32_t g, const float2 *hist_in, float2 *hist_out, float2 *out, hipStream_t s);
 int  launch_branch0_fir(const float2 *u0, const float *taps, float2 *out, float2 *hist_out, uint32_t M, uint32_t p, uint32_t nf, hipStream_t s);
 // sticky device-side error word (a look-back wait hit its spin limit); reads, then clears it; synchronises
 int  dctile_status(DcTilePlan *plan, unsigned *status);

@@ -310,6 +310,134 @@ __global__ __launch_bounds__(256) void k_mixid_finish(DcTileArgs D, const float2
     }
 }
 
+// ---- the mix identity of an INTERLEAVED CHANNEL SHARD (round 6; BASELINE configs[4] per rank: 4096 channels, DeNo --mix, rank g of G) ----
+// sum_{m < M/G} Y_t[g + G m] = sum_n X_t[n] W_M^(n g) sum_m W_(M/G)^(n m) = (M / G) sum_{n2 < G} X_t[(M / G) n2] W_G^(n2 g):
+// of the M polyphase branches only the G branches n = (M / G) n2 survive the shard's channel sum (all ranks together: M X_t[0], the
+// whole-band identity above).  So a rank needs the DC blocker on the whole stream, G picked samples per frame (DC state in front of
+// each: k_dc_fold8 leaves one zero-state aggregate and the first sample per 512-sample EIGHTH of a tile), their pre-mix, G 2m-tap
+// FIRs and a phasor sum -- no bank, no DFT, no channel sum; 8 B read per input sample like the whole-band identity.  The any-M route
+// with a pruned DFT that these configurations took before runs 678 us per 67.1 M samples at M = 4096, G = 8.
+__global__ __launch_bounds__(256) void k_dc_fold8(const float4 *__restrict__ x, float2 *__restrict__ agg, float2 *__restrict__ agg8, float2 *__restrict__ first8,
+                                                  uint32_t nb, float l2beta)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wid = (blockIdx.x * 256u + threadIdx.x) >> 6, nw = (gridDim.x * 256u) >> 6;
+    float w0[4], w1[4];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int n = 2 * (64 * it + lane);             // first of my two samples of piece `it` inside a 512-sample eighth
+        w0[it] = exp2f((float)(511 - n) * l2beta); w1[it] = exp2f((float)(510 - n) * l2beta);
+    }
+    const float be = exp2f(512.0f * l2beta);            // beta^512: one eighth further
+    float4 cur[4], nxt[4];
+    uint32_t b = wid;
+    if (b < nb) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) cur[it] = x[(size_t)b * 2048 + 64 * it + lane];
+    }
+    for (; b < nb; b += nw) {
+        float2 pe[8], x0[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            // next eighth (of this tile, or the first one of my next tile) in flight
+            const uint32_t bn = e < 7 ? b : b + nw;
+            const int en = e < 7 ? e + 1 : 0;
+            if (bn < nb) {
+#pragma unroll
+                for (int it = 0; it < 4; it++) nxt[it] = x[(size_t)bn * 2048 + 256 * en + 64 * it + lane];
+            }
+            float2 pp = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                pp = cfma(make_float2(cur[it].x, cur[it].y), w0[it], pp);
+                pp = cfma(make_float2(cur[it].z, cur[it].w), w1[it], pp);
+            }
+            pe[e] = pp;
+            x0[e] = make_float2(cur[0].x, cur[0].y);   // lane 0: the eighth's first sample
+#pragma unroll
+            for (int it = 0; it < 4; it++) cur[it] = nxt[it];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) { pe[e].x += __shfl_xor(pe[e].x, d); pe[e].y += __shfl_xor(pe[e].y, d); }
+        }
+        if (lane == 0) {
+            float2 a = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int e = 0; e < 8; e++) { a = cfma(a, be, pe[e]); agg8[(size_t)b * 8 + e] = pe[e]; first8[(size_t)b * 8 + e] = x0[e]; }
+            agg[b] = a;
+        }
+    }
+}
+
+struct ShardMixArgs { uint32_t G, Mg; float2 ph[8]; };      // W_G^(n2 g), n2 < G <= 8; Mg = M / G (a multiple of 512)
+
+__global__ __launch_bounds__(256) void k_mixid_shard_finish(DcTileArgs D, ShardMixArgs S, const float2 *__restrict__ agg, const float2 *__restrict__ agg8,
+                                                           const float2 *__restrict__ first8, const float *__restrict__ taps,
+                                                           const float2 *__restrict__ hist_in, float2 *__restrict__ hist_out,
+                                                           float2 *__restrict__ out, uint32_t M, uint32_t p, uint32_t nf)
+{
+    // a workgroup = 256 / G frames x the G surviving branches: thread (n2, fl) picks and filters ONE (branch, frame) pair -- with 256 frames
+    // per workgroup and a loop over the branches (first version) a 16 384-frame call was 64 workgroups on 256 CUs, each thread chasing
+    // G x (ten tile aggregates + up to seven eighths) through the L2 one after the other: 31 us against the whole-band finish's 8
+    __shared__ float2 u[8][128 + 32];                   // per surviving branch: p - 1 <= 32 samples of history in front
+    __shared__ float2 part[8][128];
+    const uint32_t tid = threadIdx.x, FW = 256u / S.G, n2 = tid / FW, fl = tid % FW, f0 = blockIdx.x * FW, tpf = M / 4096u, H = p - 1;
+    const float be = D.b256[2];                         // beta^512
+    auto picked = [&](int64_t f, uint32_t nb2) -> float2 {
+        if (f < 0) return hist_in[(size_t)nb2 * H + (size_t)((int64_t)H + f)];
+        const uint32_t o = S.Mg * nb2, b = (uint32_t)f * tpf + o / 4096u, e = (o % 4096u) / 512u, n0 = b * 4096u + 512u * e;
+        float2 v = dc_state_before(D, agg, b);          // in front of the tile; then through the eighths in front of mine
+        for (uint32_t k = 0; k < e; k++) { const float2 a = agg8[(size_t)b * 8 + k]; v = make_float2(fmaf(v.x, be, a.x), fmaf(v.y, be, a.y)); }
+        const float2 x0 = first8[(size_t)b * 8 + e];
+        float2 y = make_float2(fmaf(-D.alpha, v.x, x0.x), fmaf(-D.alpha, v.y, x0.y));
+        if (D.do_mix) {
+            float c_, s_;
+            if (D.nco.tab_len) { const float2 cs = D.nco_tab[(D.nco.tab_pos + n0) % D.nco.tab_len]; c_ = cs.x; s_ = cs.y; }
+            else {
+                const uint32_t theta = D.nco.theta0 + n0 * D.nco.d_theta;
+                sincosf((float)(6.283185307179586 * (double)(float)theta / 4294967296.0), &s_, &c_);
+            }
+            if (!D.nco.up) s_ = -s_;
+            y = make_float2(y.x * c_ - y.y * s_, y.x * s_ + y.y * c_);
+        }
+        const float2 w = S.ph[nb2];                     // the branch's share of the shard's shift: W_G^(n2 g)
+        return make_float2(y.x * w.x - y.y * w.y, y.x * w.y + y.y * w.x);
+    };
+    u[n2][H + fl] = (f0 + fl < nf) ? picked((int64_t)(f0 + fl), n2) : make_float2(0.f, 0.f);
+    if (fl < H) u[n2][fl] = picked((int64_t)f0 - (int64_t)H + (int64_t)fl, n2);
+    __syncthreads();
+    const uint32_t t = f0 + fl;
+    {
+        const uint32_t j = S.Mg * n2;                   // my surviving branch: taps h[(M - 1 - j) + n M]
+        float2 a2 = make_float2(0.f, 0.f);
+        for (uint32_t n = p; n-- > 0;) {                 // oldest tap first, like the bank's dot product
+            const float h = taps[(M - 1 - j) + (size_t)n * M];
+            const float2 w = u[n2][H + fl - n];
+            a2.x = fmaf(w.x, h, a2.x); a2.y = fmaf(w.y, h, a2.y);
+        }
+        part[n2][fl] = a2;
+    }
+    __syncthreads();
+    if (n2 == 0 && t < nf) {
+        float2 acc = part[0][fl];
+        for (uint32_t k = 1; k < S.G; k++) { acc.x += part[k][fl].x; acc.y += part[k][fl].y; }     // ascending branch order
+        out[t] = make_float2(acc.x * (float)S.Mg, acc.y * (float)S.Mg);
+    }
+    if (f0 + FW >= nf) {                                 // the workgroup with the call's last frame
+        if (fl < H) {
+            const int64_t f = (int64_t)nf - (int64_t)H + (int64_t)fl;
+            hist_out[(size_t)n2 * H + fl] = (f >= (int64_t)f0 - (int64_t)H) ? u[n2][(uint32_t)(f - ((int64_t)f0 - (int64_t)H))] : picked(f, n2);
+        }
+        if (tid == 0) {
+            const uint32_t b = D.nb - 1;
+            const float2 v = dc_state_before(D, agg, b), a = agg[b];
+            D.vend_out[0] = make_float2(fmaf(v.x, D.wtile[1], a.x), fmaf(v.y, D.wtile[1], a.y));
+        }
+    }
+}
+
 // DeNo --mix over ALL channels of an M-channel bank (Trans.hs:119-122 after Liquid.chs:843): sum_k Y_t[k] = M X_t[0], because
 // sum_k W_M^{jk} = M delta[j]: only polyphase branch 0 of every frame survives the channel sum.  u0[13 + t] = DC-blocked,
 // pre-mixed sample t*M of the stream (13 samples of history in front); out[t] = M sum_n h[(M-1) + n M] u0[13 + t - n].
@@ -344,6 +472,7 @@ struct DcTilePlan {
     unsigned *d_ticket = nullptr, *d_status = nullptr;
     u64 *d_agg = nullptr;
     float2 *d_part = nullptr;            // k_dc_fold: one aggregate and the first sample per tile
+    float2 *d_part8 = nullptr;           // k_dc_fold8 (shard mix identity; allocated on first use): 8 aggregates + 8 first samples per tile
     uint32_t cus = 256;
     float2 *d_vend[2] = {nullptr, nullptr};
     int cur = 0;
@@ -360,7 +489,7 @@ int dctile_status(DcTilePlan *p, unsigned *status)
 void dctile_destroy(DcTilePlan *p)
 {
     if (!p) return;
-    void *ptrs[] = {p->d_ticket, p->d_status, p->d_agg, p->d_part, p->d_vend[0], p->d_vend[1]};
+    void *ptrs[] = {p->d_ticket, p->d_status, p->d_agg, p->d_part, p->d_part8, p->d_vend[0], p->d_vend[1]};
     for (void *q : ptrs) if (q) (void)hipFree(q);
     delete p;
 }
@@ -425,6 +554,42 @@ int dctile_mix_identity(DcTilePlan *p, const float2 *x, uint32_t n, const NcoPar
     hipLaunchKernelGGL(k_dc_fold, dim3(wgs), dim3(256), 0, s, reinterpret_cast<const float4 *>(x), p->d_part, d_first, D.nb, l2b);
     hipLaunchKernelGGL(k_mixid_finish, dim3((nf + 255) / 256), dim3(256), 0, s, D, (const float2 *)p->d_part, (const float2 *)d_first, taps,
                        hist_in, hist_out, out, M, taps_p, nf);
+    CSDR_HIP(hipGetLastError());
+    p->cur ^= 1;
+    return 0;
+}
+
+// the same for the interleaved channel shard g of G: out[n / M] = (M / G) sum_{n2 < G} W_G^(n2 g) x (FIR of branch (M / G) n2); G <= 8,
+// (M / G) % 512 == 0; hist_in / hist_out: [G][p - 1] picked samples before / after the call (different buffers)
+bool dctile_mix_identity_shard_supported(const DcTilePlan *p, uint32_t M, uint32_t n, uint32_t taps_p, uint32_t G)
+{
+    return dctile_mix_identity_supported(p, M, n, taps_p) && (G == 2 || G == 4 || G == 8) && M % G == 0 && (M / G) % 512u == 0;
+}
+
+int dctile_mix_identity_shard(DcTilePlan *p, const float2 *x, uint32_t n, const NcoParams &nco, const float2 *nco_tab, const float *taps,
+                              uint32_t M, uint32_t taps_p, uint32_t G, uint32_t g, const float2 *hist_in, float2 *hist_out, float2 *out, hipStream_t s)
+{
+    if (!p->d_part8) CSDR_HIP(hipMalloc((void **)&p->d_part8, sizeof(float2) * 16 * (size_t)p->max_nb));
+    DcTileArgs D = p->proto;
+    D.x = x; D.y = nullptr; D.n = n; D.nb = n / 4096u;
+    D.pick = M; D.ypick = nullptr;
+    D.vend_in = p->d_vend[p->cur]; D.vend_out = p->d_vend[p->cur ^ 1];
+    D.nco = nco; D.nco_tab = nco_tab; D.do_mix = 1;
+    ShardMixArgs S{};
+    S.G = G; S.Mg = M / G;
+    for (uint32_t n2 = 0; n2 < G; n2++) {
+        const double a = -2.0 * 3.14159265358979323846 * (double)((n2 * g) % G) / (double)G;
+        S.ph[n2] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    const float l2b = (float)std::log2((double)D.beta);
+    uint32_t wgs = p->cus * 4u;                                      // four workgroups of four waves per CU, a tile per wave and round
+    if (wgs > (D.nb + 3) / 4) wgs = (D.nb + 3) / 4;
+    float2 *d_agg8 = p->d_part8, *d_first8 = p->d_part8 + (size_t)8 * p->max_nb;
+    const uint32_t nf = n / M;
+    hipLaunchKernelGGL(k_dc_fold8, dim3(wgs), dim3(256), 0, s, reinterpret_cast<const float4 *>(x), p->d_part, d_agg8, d_first8, D.nb, l2b);
+    const uint32_t FW = 256u / G;                                    // frames per workgroup of the finish
+    hipLaunchKernelGGL(k_mixid_shard_finish, dim3((nf + FW - 1) / FW), dim3(256), 0, s, D, S, (const float2 *)p->d_part, (const float2 *)d_agg8,
+                       (const float2 *)d_first8, taps, hist_in, hist_out, out, M, taps_p, nf);
     CSDR_HIP(hipGetLastError());
     p->cur ^= 1;
     return 0;

@@ -81,5 +81,5 @@ def test_route_table_names_every_product_kernel_family():
     from composable_sdr_amd import _lib
     t = _lib.lib().csdr_route_table().decode()
     for name in ("fused-256", "k_run256v2", "k_tile256", "fused-k_run64", "k_run64v2", "fused-k_run1024", "k_run1024v2", "k_shard1024", "generic",
-                 "k_dc_fold", "k_agc_spec_tm", "k_agc_fix", "tail-only"):
+                 "k_dc_fold", "k_dc_fold8", "k_agc_spec_tm", "k_agc_fix", "tail-only"):
         assert name in t, name

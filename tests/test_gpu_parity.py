@@ -2267,6 +2267,54 @@ def test_bench_layout_cfg5_shape_4096ch_mix_identity_whole_chunk_matches_oracle_
     assert np.abs(got - want).max() < tol
 
 
+@pytest.mark.parametrize("M,G", [(4096, 8), (4096, 4), (4096, 2), (8192, 8)])
+def test_shard_mix_identity_matches_oracle_rows_and_the_pruned_dft_route(M, G):
+    """BASELINE configs[4] per rank (4096 channels, DeNo --mix, channels split over the GPUs, one all-reduce): the channel sum of the
+    interleaved shard g of G is (M / G) x the phasor sum of the G surviving polyphase branches' FIRs (k_dc_fold8 + k_mixid_shard_finish,
+    round 6).  Against the oracle -- the left fold of the rows g, g + G, ... of O.Chain(M) -- and against the product's own bank + pruned
+    DFT + channel sum (CSDR_FLAG_NO_MIX_IDENTITY), over calls that carry the DC state, the branch histories and an odd NCO parity; and
+    the ranks' partial mixes add up to the whole-band mix (what the all-reduce returns)."""
+    from composable_sdr_amd import _lib
+    nfs = [40, 9, 130]
+    x = synth_cf32(M * sum(nfs), 256, seed=4100 + G)
+    x = (x + np.complex64(0.02 - 0.01j)).astype(np.complex64)        # a DC offset the blocker has to carry through the eighths of a tile
+    orc = O.Chain(M)
+    rows = [orc.process(x[sum(nfs[:i]) * M: sum(nfs[:i + 1]) * M]) for i in range(len(nfs))]
+    ymax = float(max(np.abs(r).max() for r in rows))
+    total = [np.zeros(nf, np.complex128) for nf in nfs]
+    for g in sorted({0, 1, G - 1} if G > 2 else {0, 1}):
+        kw = dict(channels=M, demod="none", mix=True, chan_first=g, chan_stride=G, max_frames=max(nfs))
+        ch = cs.Chain(flags=_lib.FLAG_QUIET | _lib.FLAG_TIME_KERNELS, **kw)
+        alt = cs.Chain(flags=_lib.FLAG_QUIET | _lib.FLAG_NO_MIX_IDENTITY, **kw)
+        assert "shard-mix-identity" in ch.path and "shard-mix-identity" not in alt.path
+        pos = 0
+        for i, nf in enumerate(nfs):
+            c = x[pos:pos + nf * M]; pos += nf * M
+            got, ref = ch.process(c), alt.process(c)
+            assert ch.kernel_time()[0] == "k_dc_fold8"
+            want = np.zeros(nf, np.complex64)
+            for r in rows[i][g::G]:                                  # strict left fold in f32, like Trans.hs:119-122
+                want = (want + r).astype(np.complex64)
+            tol = max(4e-7 * ymax * (M // G), 1e-5 * float(np.abs(want).max()))
+            print(f"shard mix identity M={M} G={G} g={g} nf={nf}: vs oracle rows {np.abs(got - want).max():.3e}, vs pruned-DFT route {np.abs(got - ref).max():.3e} "
+                  f"(tolerance {tol:.3e}, |out| max {np.abs(want).max():.2f})")
+            assert got.shape == want.shape == (nf,)
+            assert np.abs(got - want).max() < tol and np.abs(got - ref).max() < tol
+        ch.close(); alt.close()
+    if G == 2:                                                       # both ranks ran: their partial mixes add up to the whole-band mix
+        pos = 0
+        whole = cs.Chain(channels=M, demod="none", mix=True, max_frames=max(nfs))
+        parts = [cs.Chain(channels=M, demod="none", mix=True, chan_first=g, chan_stride=G, max_frames=max(nfs)) for g in range(G)]
+        for nf in nfs:
+            c = x[pos:pos + nf * M]; pos += nf * M
+            w = whole.process(c)
+            ssum = sum(pc.process(c).astype(np.complex128) for pc in parts)
+            assert np.abs(ssum - w).max() < max(4e-7 * ymax * M, 1e-5 * float(np.abs(w).max()))
+        whole.close()
+        for pc in parts:
+            pc.close()
+
+
 # --------------------------------------------------------------------------- pipelined device entry point
 @pytest.mark.parametrize("demod", ["fm", "none"])
 def test_submit_device_independent_launches_match_serial_calls(demod):
