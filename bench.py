@@ -235,8 +235,8 @@ def main():
     # C ABI's collective entry points (csdr_comm_* / csdr_chain_process_device_mix), which is how a one-GPU box exercises them
     chan = a.shard == "channel"
     per_rank = a.chan_stride if (a.chan_stride > 1 and world == 1 and not chan) else 0      # one rank's shard handle, alone on this GPU
-    if per_rank and (M % per_rank or a.mix or not 0 <= a.chan_first < per_rank):
-        raise SystemExit("--chan-stride must divide --channels, --chan-first must be below it, and --mix needs the collective (use --shard channel)")
+    if per_rank and (M % per_rank or not 0 <= a.chan_first < per_rank):
+        raise SystemExit("--chan-stride must divide --channels and --chan-first must be below it")
     if chan and M % world:
         raise SystemExit(f"--shard channel needs --gpus | --channels ({world} does not divide {M})")
     # time stripes: rank r's stripe is a different stretch of the stream (different seed offset);
@@ -523,7 +523,8 @@ def main():
         value = total_samples / dt / 1e6
         alg_bytes_per_sample = 8 + (out_elem / M if a.mix else out_elem)   # read CF32 once + write W
         if per_rank:
-            alg_bytes_per_sample = 8 + out_elem / per_rank               # one rank of a channel-shard run: the whole stream in, its 1 / G of the rows out
+            # one rank of a channel-shard run: the whole stream in, its 1 / G of the rows out (--mix: its partial mix, what the all-reduce sums)
+            alg_bytes_per_sample = 8 + (out_elem / M if a.mix else out_elem / per_rank)
         kavg_ms = kms / max(klaunches, 1)
         achieved_pairs = (nx * alg_bytes_per_sample) / (kavg_ms * 1e-3) / 1e9 if klaunches else None
         kreg_ms = kms_r / max(klaunches_r, 1)
@@ -559,7 +560,9 @@ def main():
         cfg_name = {(64, "none", False): "cfg2", (256, "fm", False): "cfg3", (1024, "fm", False): "cfg4 shape (one GPU)" if world == 1 else "cfg4",
                     (4096, "none", True): "cfg5 shape (one GPU)" if world == 1 else "cfg5"}.get((M, a.demod, bool(a.mix)), "custom")
         if per_rank:
-            cfg_name = (f"cfg4 per rank (rank {a.chan_first} of {per_rank})" if (M, a.demod) == (1024, "fm") else f"rank {a.chan_first} of {per_rank} of a channel-shard run")
+            cfg_name = (f"cfg4 per rank (rank {a.chan_first} of {per_rank})" if (M, a.demod, bool(a.mix)) == (1024, "fm", False) else
+                        f"cfg5 per rank (rank {a.chan_first} of {per_rank}: its partial mix)" if (M, a.demod, bool(a.mix)) == (4096, "none", True) else
+                        f"rank {a.chan_first} of {per_rank} of a channel-shard run")
         # which partition `value` is -- first key of `config`, so that a truncated copy of the line still says it
         if world == 1:
             sharding_txt = ((f"ONE RANK (chan_first {a.chan_first}) of an N = {per_rank} channel-shard run, alone on this GPU: owns channels {a.chan_first} + {per_rank} m; "
